@@ -1,0 +1,158 @@
+/*
+ * vlo.h — C ABI of the MI355X-native streaming video-LLM engine (libvlo.so).
+ *
+ * Drop-in boundary for the ONE hot path of showlab/videollm-online
+ * (BASELINE.json north_star): per-frame SigLIP ViT encode ->
+ * connector -> Llama streaming step over a growing KV cache -> samplers.
+ * The reference has no FFI; its boundary is the duck-typed Python surface that
+ * demo/inference.py uses on `self.model`.  Each entry point below names the
+ * reference call it replaces (paths relative to the reference tree; HF: paths
+ * relative to site-packages/transformers).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; no torch / HIP types
+ *     (`stream` is a hipStream_t passed as void*; NULL = the null stream).
+ *   - every function returning int: 0 = ok, < 0 = VLO_E_*; message via
+ *     vlo_last_error() (thread-local).  No exceptions cross the ABI.
+ *   - *_dev pointers are device pointers on the engine's GPU; inputs are
+ *     borrowed for the (stream-ordered) duration of the call, outputs are
+ *     written into caller-provided device buffers (the reference's
+ *     `inplace_output_ids` convention, models/modeling_live.py:173-182).
+ *   - weights are copied and re-packed into engine-owned HBM at load time;
+ *     the caller may free its copies afterwards.
+ *   - a session is NOT thread-safe; an engine may host many sessions.
+ */
+#ifndef VLO_H
+#define VLO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VLO_ABI_VERSION 1
+
+enum {
+    VLO_OK = 0,
+    VLO_E_INVALID = -1,     /* bad argument / shape */
+    VLO_E_HIP = -2,         /* HIP runtime error (message has the hipError string) */
+    VLO_E_NOMEM = -3,       /* KV pool or device memory exhausted */
+    VLO_E_STATE = -4,       /* call out of order (e.g. step before finalize) */
+    VLO_E_MISSING = -5,     /* weight not loaded */
+    VLO_E_UNSUPPORTED = -6  /* shape the kernels do not cover */
+};
+
+enum { VLO_DT_F32 = 0, VLO_DT_BF16 = 1, VLO_DT_F16 = 2 };
+
+typedef struct vlo_engine vlo_engine;
+typedef struct vlo_session vlo_session;
+
+/* Mirrors the fields LiveInfer reads from model.config (demo/inference.py:19-32;
+ * models/configuration_live.py:4-21) plus the HF LlamaConfig / SiglipVisionConfig
+ * dimensions the arithmetic needs. */
+typedef struct vlo_config {
+    int32_t abi_version;          /* = VLO_ABI_VERSION */
+    /* Llama */
+    int32_t hidden_size;
+    int32_t intermediate_size;
+    int32_t num_layers;
+    int32_t num_heads;
+    int32_t num_kv_heads;
+    int32_t vocab_size;
+    float   rope_theta;
+    float   rms_eps;
+    /* connector / frame tokens */
+    int32_t vision_hidden_size;   /* LiveConfigMixin.vision_hidden_size */
+    int32_t frame_num_tokens;     /* 1 (CLS) + pool_h*pool_w */
+    /* SigLIP vision tower (has_vit = 0: LLM only, vlo_visual_embed unavailable) */
+    int32_t has_vit;
+    int32_t vit_hidden_size;
+    int32_t vit_intermediate_size;
+    int32_t vit_num_layers;
+    int32_t vit_num_heads;
+    int32_t vit_image_size;       /* frame_resolution */
+    int32_t vit_patch_size;
+    float   vit_ln_eps;
+    int32_t pool_h, pool_w;       /* frame_token_pooled */
+    /* KV pool: total tokens the paged pool can hold across all sessions */
+    int64_t kv_pool_tokens;
+    /* tensor parallel (rank/size of this engine inside a TP group; 0/1 = none) */
+    int32_t tp_rank, tp_size;
+} vlo_config;
+
+/* ---- engine lifetime: replaces build_model_and_tokenizer(...)[0] + model.to('cuda')
+ *      (demo/inference.py:15-16; models/modeling_live.py:184-222) ------------------ */
+int  vlo_engine_create(const vlo_config *cfg, int device, vlo_engine **out);
+/* name = HF state-dict key ("model.layers.0.self_attn.q_proj.weight", "lm_head.weight",
+ * "connector.0.bias", "vision.encoder.layers.0.mlp.fc1.weight", ... ); optional
+ * "rope.inv_freq" [head_dim/2] f32 overrides the engine's own powf() table.
+ * data may be a host or a device pointer.  */
+int  vlo_engine_load_weight(vlo_engine *e, const char *name, const void *data, int dtype,
+                            const int64_t *shape, int ndim);
+int  vlo_engine_finalize(vlo_engine *e);              /* verifies completeness, builds tables */
+void vlo_engine_destroy(vlo_engine *e);
+int64_t vlo_engine_weight_bytes(const vlo_engine *e); /* packed bytes resident in HBM */
+
+/* ---- session = the KV handle (`past_key_values`, HF:cache_utils.py DynamicCache;
+ *      demo/inference.py:61,69-70,84-91) -------------------------------------------- */
+int     vlo_session_create(vlo_engine *e, int64_t max_tokens_hint, vlo_session **out);
+int     vlo_session_reset(vlo_session *s);            /* LiveInfer.reset(): past_key_values=None */
+int64_t vlo_session_len(const vlo_session *s);        /* DynamicCache.get_seq_length() */
+void    vlo_session_destroy(vlo_session *s);
+
+/* ---- model.visual_embed(frames) (models/modeling_live.py:21-27 ->
+ *      models/vision_live.py:10-30 -> HF SiglipVisionModel -> connector
+ *      models/live_llama/modeling_live_llama.py:18-22).
+ *      frames_dev: uint8 [B,3,R,R] NCHW;  out_dev: bf16 [B*frame_num_tokens, hidden_size] */
+int vlo_visual_embed(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_dev, void *stream);
+/* connector only (frames already encoded: the `hasattr(self,'vision_encode')` false branch,
+ * models/modeling_live.py:22-26).  feats_dev: bf16 [rows, vision_hidden_size] */
+int vlo_connector(vlo_engine *e, const void *feats_dev, int rows, void *out_dev, void *stream);
+
+/* ---- model.get_input_embeddings()(ids) (demo/inference.py:46,66).
+ *      ids_dev: int64 [k]; out_dev: bf16 [k, hidden_size] */
+int vlo_embed(vlo_engine *e, const int64_t *ids_dev, int k, void *out_dev, void *stream);
+
+/* ---- model(inputs_embeds=..., use_cache=True, past_key_values=...) (demo/inference.py:69;
+ *      models/live_llama/modeling_live_llama.py:24-53 -> HF LlamaForCausalLM.forward).
+ *      embeds_dev: bf16 [n, hidden_size].  Appends n tokens to the session's KV.
+ *      last_logits_dev: NULL or bf16 [vocab] receiving logits[:, -1] (the only row any
+ *      caller reads: demo/inference.py:76, models/modeling_live.py:177).
+ *      all_logits_dev: NULL or bf16 [n, vocab] (full HF output, for parity tests). */
+int vlo_llm_step(vlo_session *s, const void *embeds_dev, int n, void *last_logits_dev,
+                 void *all_logits_dev, void *stream);
+
+/* ---- streaming sampler (demo/inference.py:76-81) on the session's last-row logits:
+ *      softmax (model dtype), zero p[interval] if below threshold, argmax.
+ *      tok_dev: int64 [1]; p_interval_dev: NULL or float [1] (p before zeroing). */
+int vlo_stream_sample(vlo_session *s, float threshold, int interval_id, int64_t *tok_dev,
+                      float *p_interval_dev, void *stream);
+
+/* ---- fast_greedy_generate (models/modeling_live.py:173-182): up to max_new decode steps,
+ *      token i written to out_ids_dev[i] (int64), stops after writing eos.
+ *      force_len > 0: scheduled mode for throughput runs — argmax still computed each step,
+ *      but exactly force_len tokens are produced and the last is eos.
+ *      *n_written (host) receives i+1.  Synchronises the stream (the reference syncs once
+ *      per token at :179). */
+int vlo_greedy_generate(vlo_session *s, const void *embeds_dev, int m, int eos_token_id,
+                        int64_t *out_ids_dev, int max_new, int force_len, int *n_written, void *stream);
+
+/* ---- introspection for tests / bench ------------------------------------------------ */
+/* copy the session's K or V for (layer, kv_head) tokens [t0,t1) to dst_dev bf16 [t1-t0, head_dim] */
+int vlo_session_read_kv(vlo_session *s, int layer, int which /*0=K,1=V*/, int kv_head, int64_t t0, int64_t t1,
+                        void *dst_dev, void *stream);
+/* algorithmic bytes of a step with n new tokens at cache length Lc */
+double vlo_step_algorithmic_bytes(const vlo_engine *e, int64_t Lc, int n);
+/* raw skinny-GEMM entry used by unit tests: y[n,N] (f32) = x[n,K](bf16) @ W[N,K]^T (bf16), n<=16.
+ * W_dev is an ordinary row-major device tensor; packs on every call (tests only). */
+int vlo_test_gemv(const void *x_dev, const void *W_dev, float *y_dev, int n, int N, int K, void *stream);
+
+const char *vlo_last_error(void);
+int vlo_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLO_H */

@@ -1,0 +1,57 @@
+"""CPU-side checks of the drop-in boundary: libvlo.so loads and exports every symbol
+include/vlo.h declares (no compute calls — no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "vlo.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vlo_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_header_symbols():
+    import __graft_entry__ as G
+    G.build()
+    from videollm_online_amd import _C
+    L = _C.lib()
+    names = _declared()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(L, n), f"libvlo.so does not export {n}"
+    assert set(names) == set(_C.EXPORTS), set(names) ^ set(_C.EXPORTS)
+    assert L.vlo_abi_version() == _C.VLO_ABI_VERSION
+
+
+def test_error_convention_without_gpu():
+    from videollm_online_amd import _C
+    L = _C.lib()
+    h = ctypes.c_void_p()
+    cfg = _C.VloConfig()
+    cfg.abi_version = 999
+    rc = L.vlo_engine_create(ctypes.byref(cfg), 0, ctypes.byref(h))
+    assert rc == -1 and b"abi_version" in L.vlo_last_error()
+    assert L.vlo_session_len(None) == -1
+
+
+def test_product_path_has_no_oracle_or_cpu_fallback():
+    pkg = os.path.join(ROOT, "videollm-online_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cuh")):
+                s = open(os.path.join(dp, f)).read()
+                assert "oracle" not in s.replace("no oracle", ""), f"{f} references the oracle"
+
+
+def test_engine_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from videollm_online_amd.engine import Engine, EngineConfig
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        Engine(EngineConfig(64, 128, 1, 4, 2, 128))

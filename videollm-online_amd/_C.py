@@ -1,0 +1,81 @@
+"""ctypes binding of libvlo.so (include/vlo.h).  Fails loudly when the library is missing:
+there is no Python/CPU fallback for any entry point."""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  — loads torch's bundled libamdhip64 first so libvlo.so binds to the same HIP runtime
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvlo.so")
+
+VLO_ABI_VERSION = 1
+DT_F32, DT_BF16, DT_F16 = 0, 1, 2
+
+
+class VloConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("hidden_size", C.c_int32), ("intermediate_size", C.c_int32), ("num_layers", C.c_int32),
+        ("num_heads", C.c_int32), ("num_kv_heads", C.c_int32), ("vocab_size", C.c_int32),
+        ("rope_theta", C.c_float), ("rms_eps", C.c_float),
+        ("vision_hidden_size", C.c_int32), ("frame_num_tokens", C.c_int32),
+        ("has_vit", C.c_int32), ("vit_hidden_size", C.c_int32), ("vit_intermediate_size", C.c_int32),
+        ("vit_num_layers", C.c_int32), ("vit_num_heads", C.c_int32), ("vit_image_size", C.c_int32),
+        ("vit_patch_size", C.c_int32), ("vit_ln_eps", C.c_float), ("pool_h", C.c_int32), ("pool_w", C.c_int32),
+        ("kv_pool_tokens", C.c_int64), ("tp_rank", C.c_int32), ("tp_size", C.c_int32),
+    ]
+
+
+_lib = None
+
+EXPORTS = [
+    "vlo_abi_version", "vlo_last_error", "vlo_engine_create", "vlo_engine_load_weight", "vlo_engine_finalize",
+    "vlo_engine_destroy", "vlo_engine_weight_bytes", "vlo_session_create", "vlo_session_reset", "vlo_session_len",
+    "vlo_session_destroy", "vlo_visual_embed", "vlo_connector", "vlo_embed", "vlo_llm_step", "vlo_stream_sample",
+    "vlo_greedy_generate", "vlo_session_read_kv", "vlo_step_algorithmic_bytes", "vlo_test_gemv",
+]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc, gfx950).  The engine has no fallback path.")
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    L.vlo_abi_version.restype = i32
+    L.vlo_last_error.restype = C.c_char_p
+    L.vlo_engine_create.argtypes = [C.POINTER(VloConfig), i32, C.POINTER(vp)]
+    L.vlo_engine_load_weight.argtypes = [vp, C.c_char_p, vp, i32, C.POINTER(i64), i32]
+    L.vlo_engine_finalize.argtypes = [vp]
+    L.vlo_engine_destroy.argtypes = [vp]
+    L.vlo_engine_destroy.restype = None
+    L.vlo_engine_weight_bytes.argtypes = [vp]
+    L.vlo_engine_weight_bytes.restype = i64
+    L.vlo_session_create.argtypes = [vp, i64, C.POINTER(vp)]
+    L.vlo_session_reset.argtypes = [vp]
+    L.vlo_session_len.argtypes = [vp]
+    L.vlo_session_len.restype = i64
+    L.vlo_session_destroy.argtypes = [vp]
+    L.vlo_session_destroy.restype = None
+    L.vlo_visual_embed.argtypes = [vp, vp, i32, vp, vp]
+    L.vlo_connector.argtypes = [vp, vp, i32, vp, vp]
+    L.vlo_embed.argtypes = [vp, vp, i32, vp, vp]
+    L.vlo_llm_step.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.vlo_stream_sample.argtypes = [vp, C.c_float, i32, vp, vp, vp]
+    L.vlo_greedy_generate.argtypes = [vp, vp, i32, i32, vp, i32, i32, C.POINTER(i32), vp]
+    L.vlo_session_read_kv.argtypes = [vp, i32, i32, i32, i64, i64, vp, vp]
+    L.vlo_step_algorithmic_bytes.argtypes = [vp, i64, i32]
+    L.vlo_step_algorithmic_bytes.restype = C.c_double
+    L.vlo_test_gemv.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    if L.vlo_abi_version() != VLO_ABI_VERSION:
+        raise RuntimeError("libvlo.so ABI version mismatch — rebuild")
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != 0:
+        raise RuntimeError(f"libvlo error {rc}: {lib().vlo_last_error().decode()}")

@@ -1,0 +1,75 @@
+// engine.h — internal structures behind the opaque vlo_engine / vlo_session handles
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/vlo.h"
+#include "gemv.h"
+
+struct RawTensor {
+    void *ptr = nullptr;
+    int dtype = 0;
+    std::vector<int64_t> shape;
+};
+
+struct PackedLinear {
+    void *Wp = nullptr;
+    int N = 0, K = 0, NT = 0;
+    GemvPlan plan{};
+};
+
+struct LayerWeights {
+    PackedLinear qkv, o, gate_up, down;
+    void *ln_in = nullptr, *ln_post = nullptr;
+};
+
+struct VitState;
+
+struct vlo_engine {
+    vlo_config cfg{};
+    int device = 0;
+    int head_dim = 0;
+    bool finalized = false;
+    bool has_connector = false;
+    std::map<std::string, RawTensor> raw;      // row-major weights staged on the device until finalize
+    std::vector<void *> owned;                 // device allocations freed at destroy
+    int64_t weight_bytes = 0;
+
+    std::vector<LayerWeights> layers;
+    PackedLinear lm_head, conn0, conn2;
+    void *norm_w = nullptr, *embed = nullptr, *conn0_b = nullptr, *conn2_b = nullptr;
+    void *conn_x = nullptr, *conn_mid = nullptr, *conn_out = nullptr;
+    void *cos_tab = nullptr, *sin_tab = nullptr;
+    int64_t max_positions = 0;
+
+    // paged KV pool
+    void *k_pool = nullptr, *vt_pool = nullptr;
+    int pool_pages = 0;
+    int64_t page_elems = 0, layer_stride = 0;
+    std::vector<int> free_pages;
+    std::mutex pool_mu;
+
+    VitState *vit = nullptr;
+};
+
+struct vlo_session {
+    vlo_engine *e = nullptr;
+    int64_t len = 0;
+    bool has_logits = false;
+    std::vector<int> pages;
+    std::vector<void *> owned;
+    unsigned short *h = nullptr, *x = nullptr, *act = nullptr, *attn = nullptr, *q = nullptr, *emb1 = nullptr;
+    float *partial = nullptr, *partial2 = nullptr, *part_o = nullptr, *part_ml = nullptr;
+    int partial_ld = 0;
+    unsigned short *logits = nullptr, *last_logits = nullptr;
+    int64_t *tok = nullptr;
+    int64_t *host_tok = nullptr;
+    int *page_table = nullptr, *host_pt = nullptr;
+};
+
+int dev_alloc(void **p, size_t bytes);

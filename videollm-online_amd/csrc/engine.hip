@@ -1,0 +1,640 @@
+// engine.hip — host side of libvlo.so: the C ABI declared in include/vlo.h.
+//
+// Owns: packed weights in HBM, the paged KV pool, per-session workspaces; sequences the
+// gfx950 kernels of one Llama streaming step (gemv.hip, llm_ops.hip) and of the SigLIP
+// encode (vit.hip) on caller-provided HIP streams.  No torch types, no CPU fallback:
+// every entry point either runs the HIP path or returns an error.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/vlo.h"
+#include "common.cuh"
+#include "engine.h"
+#include "gemv.h"
+#include "llm_ops.h"
+#include "vit.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+const char *vlo_last_error(void) { return g_err.c_str(); }
+int vlo_abi_version(void) { return VLO_ABI_VERSION; }
+
+#define HIP_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess)                                                                                 \
+            return fail(VLO_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " @" + __FILE__ + ":" + \
+                                       std::to_string(__LINE__));                                             \
+    } while (0)
+
+// ------------------------------------------------------------------------------------
+// small device utilities
+// ------------------------------------------------------------------------------------
+__global__ void convert_kernel(const void *src, int sdt, void *dst, int ddt, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v;
+        if (sdt == VLO_DT_F32) v = ((const float *)src)[i];
+        else if (sdt == VLO_DT_BF16) v = bf2f(((const bf16_t *)src)[i]);
+        else v = h2f(((const f16_t *)src)[i]);
+        if (ddt == VLO_DT_F32) ((float *)dst)[i] = v;
+        else if (ddt == VLO_DT_BF16) ((bf16_t *)dst)[i] = f2bf(v);
+        else ((f16_t *)dst)[i] = f2h(v);
+    }
+}
+__global__ void sum_partials_kernel(const float *P, int ksplit, int ld, float *y, int n, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * N) return;
+    const int m = i / N, c = i % N;
+    float s = 0.f;
+    for (int k = 0; k < ksplit; ++k) s += P[((size_t)k * 16 + m) * ld + c];
+    y[i] = s;
+}
+
+static size_t dt_size(int dt) { return dt == VLO_DT_F32 ? 4 : 2; }
+
+int dev_alloc(void **p, size_t bytes) {
+    HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
+    return VLO_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// engine
+// ------------------------------------------------------------------------------------
+static bool name_is(const std::string &n, const char *suffix) {
+    const size_t l = strlen(suffix);
+    return n.size() >= l && n.compare(n.size() - l, l, suffix) == 0;
+}
+
+int vlo_engine_create(const vlo_config *cfg, int device, vlo_engine **out) {
+    if (!cfg || !out) return fail(VLO_E_INVALID, "null argument");
+    if (cfg->abi_version != VLO_ABI_VERSION) return fail(VLO_E_INVALID, "vlo_config.abi_version mismatch");
+    if (cfg->hidden_size <= 0 || cfg->num_heads <= 0 || cfg->num_kv_heads <= 0 || cfg->hidden_size % cfg->num_heads ||
+        cfg->num_heads % cfg->num_kv_heads || cfg->num_layers <= 0 || cfg->vocab_size <= 0 || cfg->intermediate_size <= 0)
+        return fail(VLO_E_INVALID, "bad Llama dimensions");
+    const int hd = cfg->hidden_size / cfg->num_heads;
+    if (hd != 64 && hd != 128) return fail(VLO_E_UNSUPPORTED, "head_dim must be 64 or 128");
+    if ((cfg->hidden_size & 31) || (cfg->intermediate_size & 31) || (cfg->vocab_size & 3))
+        return fail(VLO_E_UNSUPPORTED, "hidden/intermediate must be multiples of 32, vocab of 4");
+    if (cfg->tp_size > 1) return fail(VLO_E_UNSUPPORTED, "tensor parallel engines are not built in this round");
+    HIP_TRY(hipSetDevice(device));
+    vlo_engine *e = new vlo_engine();
+    e->cfg = *cfg;
+    e->device = device;
+    e->head_dim = hd;
+    if (e->cfg.kv_pool_tokens <= 0) e->cfg.kv_pool_tokens = 16384;
+    *out = e;
+    return VLO_OK;
+}
+
+void vlo_engine_destroy(vlo_engine *e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    for (auto &kv : e->raw) hipFree(kv.second.ptr);
+    for (void *p : e->owned) hipFree(p);
+    delete e;
+}
+
+int64_t vlo_engine_weight_bytes(const vlo_engine *e) { return e ? e->weight_bytes : 0; }
+
+int vlo_engine_load_weight(vlo_engine *e, const char *name, const void *data, int dtype, const int64_t *shape, int ndim) {
+    if (!e || !name || !data || !shape || ndim < 1 || ndim > 4) return fail(VLO_E_INVALID, "bad load_weight arguments");
+    if (e->finalized) return fail(VLO_E_STATE, "engine already finalized");
+    HIP_TRY(hipSetDevice(e->device));
+    const std::string n(name);
+    size_t numel = 1;
+    for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
+    // storage dtype inside the engine: LLM + connector bf16; ViT matmul weights f16, the rest of the ViT f32
+    int ddt = VLO_DT_BF16;
+    if (n == "rope.inv_freq") ddt = VLO_DT_F32;
+    if (n.rfind("vision.", 0) == 0) {
+        const bool is_mat = name_is(n, "proj.weight") || name_is(n, "fc1.weight") || name_is(n, "fc2.weight") ||
+                            name_is(n, "patch_embedding.weight") || name_is(n, "in_proj_weight");
+        ddt = is_mat ? VLO_DT_F16 : VLO_DT_F32;
+    }
+    void *stage = nullptr, *dst = nullptr;
+    HIP_TRY(hipMalloc(&dst, numel * dt_size(ddt)));
+    if (dtype == ddt) {
+        HIP_TRY(hipMemcpy(dst, data, numel * dt_size(ddt), hipMemcpyDefault));
+    } else {
+        HIP_TRY(hipMalloc(&stage, numel * dt_size(dtype)));
+        HIP_TRY(hipMemcpy(stage, data, numel * dt_size(dtype), hipMemcpyDefault));
+        int blocks = (int)((numel + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(convert_kernel, dim3(blocks), dim3(256), 0, 0, stage, dtype, dst, ddt, numel);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(stage));
+    }
+    auto it = e->raw.find(n);
+    if (it != e->raw.end()) hipFree(it->second.ptr);
+    RawTensor t;
+    t.ptr = dst;
+    t.dtype = ddt;
+    t.shape.assign(shape, shape + ndim);
+    e->raw[n] = t;
+    return VLO_OK;
+}
+
+static int take(vlo_engine *e, const std::string &name, std::vector<int64_t> shape, RawTensor *out) {
+    auto it = e->raw.find(name);
+    if (it == e->raw.end()) return fail(VLO_E_MISSING, "missing weight: " + name);
+    if (!shape.empty() && it->second.shape != shape) {
+        std::string s = "bad shape for " + name + ": got [";
+        for (auto d : it->second.shape) s += std::to_string(d) + ",";
+        s += "]";
+        return fail(VLO_E_INVALID, s);
+    }
+    *out = it->second;
+    return VLO_OK;
+}
+
+// pack a [N][K] bf16 linear into dst tiles (see gemv.hip)
+static int pack_into(vlo_engine *e, const std::string &name, int N, int K, void *dst, int tile_stride, int tile_offset) {
+    RawTensor t;
+    int rc = take(e, name, {N, K}, &t);
+    if (rc) return rc;
+    const int NT = (N + 15) / 16;
+    HIP_TRY(pack_weight_launch(t.ptr, dst, N, K, NT, tile_stride, tile_offset, 0));
+    return VLO_OK;
+}
+
+static int make_linear(vlo_engine *e, PackedLinear *pl, int N, int K, bool allow_ksplit) {
+    pl->N = N;
+    pl->K = K;
+    pl->NT = (N + 15) / 16;
+    if (gemv_plan(K, allow_ksplit, &pl->plan)) return fail(VLO_E_UNSUPPORTED, "no GEMV plan for K=" + std::to_string(K));
+    const size_t bytes = (size_t)pl->NT * 16 * K * 2;
+    int rc = dev_alloc(&pl->Wp, bytes);
+    if (rc) return rc;
+    e->owned.push_back(pl->Wp);
+    e->weight_bytes += (int64_t)bytes;
+    return VLO_OK;
+}
+
+static int take_vec(vlo_engine *e, const std::string &name, int64_t n, void **out) {
+    RawTensor t;
+    int rc = take(e, name, {n}, &t);
+    if (rc) return rc;
+    *out = t.ptr;
+    e->owned.push_back(t.ptr);
+    e->raw.erase(name);
+    e->weight_bytes += n * (int64_t)dt_size(t.dtype);
+    return VLO_OK;
+}
+
+static void drop_raw(vlo_engine *e, const std::string &name) {
+    auto it = e->raw.find(name);
+    if (it != e->raw.end()) {
+        hipFree(it->second.ptr);
+        e->raw.erase(it);
+    }
+}
+
+int vlo_engine_finalize(vlo_engine *e) {
+    if (!e) return fail(VLO_E_INVALID, "null engine");
+    if (e->finalized) return VLO_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    const vlo_config &c = e->cfg;
+    const int H = c.hidden_size, I = c.intermediate_size, hd = e->head_dim, nh = c.num_heads, nkv = c.num_kv_heads;
+    const int Nq = nh * hd, Nkv = nkv * hd, Nqkv = Nq + 2 * Nkv;
+    int rc;
+    e->layers.resize(c.num_layers);
+    for (int l = 0; l < c.num_layers; ++l) {
+        LayerWeights &L = e->layers[l];
+        const std::string p = "model.layers." + std::to_string(l) + ".";
+        if ((rc = make_linear(e, &L.qkv, Nqkv, H, true))) return rc;
+        if ((rc = pack_into(e, p + "self_attn.q_proj.weight", Nq, H, L.qkv.Wp, 1, 0))) return rc;
+        if ((rc = pack_into(e, p + "self_attn.k_proj.weight", Nkv, H, L.qkv.Wp, 1, Nq / 16))) return rc;
+        if ((rc = pack_into(e, p + "self_attn.v_proj.weight", Nkv, H, L.qkv.Wp, 1, (Nq + Nkv) / 16))) return rc;
+        if ((rc = make_linear(e, &L.o, H, Nq, true))) return rc;
+        if ((rc = pack_into(e, p + "self_attn.o_proj.weight", H, Nq, L.o.Wp, 1, 0))) return rc;
+        if ((rc = make_linear(e, &L.gate_up, 2 * I, H, false))) return rc;       // SwiGLU epilogue needs whole K
+        if (I % 16) return fail(VLO_E_UNSUPPORTED, "intermediate_size must be a multiple of 16");
+        if ((rc = pack_into(e, p + "mlp.gate_proj.weight", I, H, L.gate_up.Wp, 2, 0))) return rc;
+        if ((rc = pack_into(e, p + "mlp.up_proj.weight", I, H, L.gate_up.Wp, 2, 1))) return rc;
+        if ((rc = make_linear(e, &L.down, H, I, true))) return rc;
+        if ((rc = pack_into(e, p + "mlp.down_proj.weight", H, I, L.down.Wp, 1, 0))) return rc;
+        if ((rc = take_vec(e, p + "input_layernorm.weight", H, &L.ln_in))) return rc;
+        if ((rc = take_vec(e, p + "post_attention_layernorm.weight", H, &L.ln_post))) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+        for (const char *s : {"self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
+                              "self_attn.o_proj.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight"})
+            drop_raw(e, p + s);
+    }
+    if ((rc = take_vec(e, "model.norm.weight", H, &e->norm_w))) return rc;
+    if ((rc = make_linear(e, &e->lm_head, c.vocab_size, H, false))) return rc;
+    if ((rc = pack_into(e, "lm_head.weight", c.vocab_size, H, e->lm_head.Wp, 1, 0))) return rc;
+    {   // embedding table stays row-major (gather)
+        RawTensor t;
+        if ((rc = take(e, "model.embed_tokens.weight", {c.vocab_size, H}, &t))) return rc;
+        e->embed = t.ptr;
+        e->owned.push_back(t.ptr);
+        e->raw.erase("model.embed_tokens.weight");
+    }
+    // connector (optional: an LLM-only engine may omit it)
+    if (e->raw.count("connector.0.weight")) {
+        const int Hv = c.vision_hidden_size;
+        if ((rc = make_linear(e, &e->conn0, H, Hv, false))) return rc;
+        if ((rc = pack_into(e, "connector.0.weight", H, Hv, e->conn0.Wp, 1, 0))) return rc;
+        if ((rc = make_linear(e, &e->conn2, H, H, false))) return rc;
+        if ((rc = pack_into(e, "connector.2.weight", H, H, e->conn2.Wp, 1, 0))) return rc;
+        if ((rc = take_vec(e, "connector.0.bias", H, &e->conn0_b))) return rc;
+        if ((rc = take_vec(e, "connector.2.bias", H, &e->conn2_b))) return rc;
+        e->has_connector = true;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    drop_raw(e, "lm_head.weight");
+    drop_raw(e, "connector.0.weight");
+    drop_raw(e, "connector.2.weight");
+
+    // RoPE tables: cos/sin of pos * inv_freq in fp32, cast to bf16 (HF:modeling_llama.py:113-127)
+    {
+        const int half = hd / 2;
+        std::vector<float> inv(half);
+        if (e->raw.count("rope.inv_freq")) {
+            RawTensor t;
+            if ((rc = take(e, "rope.inv_freq", {half}, &t))) return rc;
+            HIP_TRY(hipMemcpy(inv.data(), t.ptr, half * sizeof(float), hipMemcpyDeviceToHost));
+            drop_raw(e, "rope.inv_freq");
+        } else {
+            for (int i = 0; i < half; ++i) inv[i] = 1.0f / powf(c.rope_theta, (float)(2 * i) / (float)hd);
+        }
+        e->pool_pages = (int)((c.kv_pool_tokens + VLO_PAGE_TOKENS - 1) / VLO_PAGE_TOKENS);
+        e->max_positions = (int64_t)e->pool_pages * VLO_PAGE_TOKENS;
+        std::vector<unsigned short> ct((size_t)e->max_positions * half), st((size_t)e->max_positions * half);
+        auto tobf = [](float f) {
+            unsigned u;
+            memcpy(&u, &f, 4);
+            u += 0x7fffu + ((u >> 16) & 1u);
+            return (unsigned short)(u >> 16);
+        };
+        for (int64_t p = 0; p < e->max_positions; ++p)
+            for (int i = 0; i < half; ++i) {
+                const float ang = inv[i] * (float)p;
+                ct[p * half + i] = tobf(cosf(ang));
+                st[p * half + i] = tobf(sinf(ang));
+            }
+        if ((rc = dev_alloc(&e->cos_tab, ct.size() * 2))) return rc;
+        if ((rc = dev_alloc(&e->sin_tab, st.size() * 2))) return rc;
+        e->owned.push_back(e->cos_tab);
+        e->owned.push_back(e->sin_tab);
+        HIP_TRY(hipMemcpy(e->cos_tab, ct.data(), ct.size() * 2, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->sin_tab, st.data(), st.size() * 2, hipMemcpyHostToDevice));
+    }
+    // KV pool
+    {
+        e->page_elems = (int64_t)nkv * VLO_PAGE_TOKENS * hd;
+        e->layer_stride = e->page_elems * e->pool_pages;
+        const size_t bytes = (size_t)e->layer_stride * c.num_layers * 2;
+        if ((rc = dev_alloc(&e->k_pool, bytes))) return rc;
+        if ((rc = dev_alloc(&e->vt_pool, bytes))) return rc;
+        e->owned.push_back(e->k_pool);
+        e->owned.push_back(e->vt_pool);
+        HIP_TRY(hipMemset(e->k_pool, 0, bytes));
+        HIP_TRY(hipMemset(e->vt_pool, 0, bytes));
+        e->free_pages.clear();
+        for (int p = e->pool_pages - 1; p >= 0; --p) e->free_pages.push_back(p);
+    }
+    if (c.has_vit) {
+        if ((rc = vit_finalize(e))) return rc;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    e->finalized = true;
+    return VLO_OK;
+}
+
+double vlo_step_algorithmic_bytes(const vlo_engine *e, int64_t Lc, int n) {
+    if (!e) return 0;
+    const vlo_config &c = e->cfg;
+    const double H = c.hidden_size, I = c.intermediate_size, hd = e->head_dim;
+    const double per_layer = (H * (c.num_heads * hd) * 2 + H * (c.num_kv_heads * hd) * 2 + 3.0 * H * I) * 2.0;
+    const double W = per_layer * c.num_layers + (double)c.vocab_size * H * 2.0;
+    const double kv = 2.0 * c.num_layers * c.num_kv_heads * hd * 2.0;
+    return W + kv * (double)(Lc + n) + kv * n + 2.0 * n * H * 2.0;
+}
+
+// ------------------------------------------------------------------------------------
+// sessions
+// ------------------------------------------------------------------------------------
+int vlo_session_create(vlo_engine *e, int64_t max_tokens_hint, vlo_session **out) {
+    if (!e || !out) return fail(VLO_E_INVALID, "null argument");
+    if (!e->finalized) return fail(VLO_E_STATE, "engine not finalized");
+    HIP_TRY(hipSetDevice(e->device));
+    (void)max_tokens_hint;
+    const vlo_config &c = e->cfg;
+    const int H = c.hidden_size, I = c.intermediate_size, hd = e->head_dim, nh = c.num_heads, nkv = c.num_kv_heads;
+    const int Nqkv = (nh + 2 * nkv) * hd;
+    vlo_session *s = new vlo_session();
+    s->e = e;
+    int rc = 0;
+    auto A = [&](void **p, size_t bytes) {
+        if (rc) return;
+        rc = dev_alloc(p, bytes);
+        if (!rc) {
+            s->owned.push_back(*p);
+            hipMemset(*p, 0, bytes);
+        }
+    };
+    A((void **)&s->h, (size_t)32 * H * 2);
+    A((void **)&s->x, (size_t)32 * H * 2);
+    A((void **)&s->act, (size_t)32 * I * 2);
+    A((void **)&s->attn, (size_t)32 * nh * hd * 2);
+    A((void **)&s->q, (size_t)16 * nh * hd * 2);
+    int ksmax = 1;
+    for (auto &L : e->layers) {
+        ksmax = std::max(ksmax, std::max(L.qkv.plan.ksplit, std::max(L.o.plan.ksplit, L.down.plan.ksplit)));
+    }
+    s->partial_ld = std::max(Nqkv, H);
+    A((void **)&s->partial, (size_t)ksmax * 16 * s->partial_ld * 4);
+    A((void **)&s->partial2, (size_t)ksmax * 16 * s->partial_ld * 4);
+    A((void **)&s->part_o, (size_t)VLO_MAX_SPLITS * nh * 16 * hd * 4);
+    A((void **)&s->part_ml, (size_t)VLO_MAX_SPLITS * nh * 16 * 2 * 4);
+    A((void **)&s->logits, (size_t)16 * c.vocab_size * 2);
+    A((void **)&s->tok, 64);
+    A((void **)&s->emb1, (size_t)32 * H * 2);
+    A((void **)&s->page_table, (size_t)e->pool_pages * 4);
+    if (rc) {
+        vlo_session_destroy(s);
+        return rc;
+    }
+    if (hipHostMalloc((void **)&s->host_tok, 64, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&s->host_pt, (size_t)e->pool_pages * 4, hipHostMallocDefault) != hipSuccess) {
+        vlo_session_destroy(s);
+        return fail(VLO_E_HIP, "hipHostMalloc failed");
+    }
+    s->last_logits = s->logits;
+    HIP_TRY(hipDeviceSynchronize());
+    *out = s;
+    return VLO_OK;
+}
+
+int vlo_session_reset(vlo_session *s) {
+    if (!s) return fail(VLO_E_INVALID, "null session");
+    std::lock_guard<std::mutex> g(s->e->pool_mu);
+    for (int p : s->pages) s->e->free_pages.push_back(p);
+    s->pages.clear();
+    s->len = 0;
+    s->has_logits = false;
+    return VLO_OK;
+}
+int64_t vlo_session_len(const vlo_session *s) { return s ? s->len : -1; }
+
+void vlo_session_destroy(vlo_session *s) {
+    if (!s) return;
+    hipSetDevice(s->e->device);
+    hipDeviceSynchronize();
+    vlo_session_reset(s);
+    for (void *p : s->owned) hipFree(p);
+    if (s->host_tok) hipHostFree(s->host_tok);
+    if (s->host_pt) hipHostFree(s->host_pt);
+    delete s;
+}
+
+static int ensure_pages(vlo_session *s, int64_t new_len, hipStream_t st) {
+    vlo_engine *e = s->e;
+    if (new_len > e->max_positions) return fail(VLO_E_NOMEM, "sequence exceeds kv_pool_tokens");
+    const int need = (int)((new_len + VLO_PAGE_TOKENS - 1) / VLO_PAGE_TOKENS);
+    const int have = (int)s->pages.size();
+    if (need <= have) return VLO_OK;
+    {
+        std::lock_guard<std::mutex> g(e->pool_mu);
+        if ((int)e->free_pages.size() < need - have) return fail(VLO_E_NOMEM, "KV pool exhausted");
+        for (int i = have; i < need; ++i) {
+            const int p = e->free_pages.back();
+            e->free_pages.pop_back();
+            s->pages.push_back(p);
+            s->host_pt[i] = p;      // pinned mirror is append-only => safe source for the async copy
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(s->page_table + have, s->host_pt + have, (size_t)(need - have) * 4, hipMemcpyHostToDevice, st));
+    return VLO_OK;
+}
+
+static KvGeom kv_geom(const vlo_session *s) {
+    const vlo_engine *e = s->e;
+    KvGeom g;
+    g.k_pool = (unsigned short *)e->k_pool;
+    g.vt_pool = (unsigned short *)e->vt_pool;
+    g.page_table = s->page_table;
+    g.layer_stride = e->layer_stride;
+    g.page_elems = e->page_elems;
+    g.num_kv_heads = e->cfg.num_kv_heads;
+    g.head_dim = e->head_dim;
+    return g;
+}
+
+static int run_gemv(const PackedLinear &pl, const unsigned short *x, int ldx, int n_rows, int epi, float *out_f32,
+                    unsigned short *out_bf16, int ldo, const void *bias, hipStream_t st) {
+    GemvArgs a;
+    a.Wp = pl.Wp;
+    a.x = x;
+    a.out_f32 = out_f32;
+    a.out_bf16 = out_bf16;
+    a.bias = (const unsigned short *)bias;
+    a.K = pl.K;
+    a.ldx = ldx;
+    a.ldo = ldo;
+    a.NT = pl.NT;
+    a.N_valid = pl.N;
+    a.n_rows = n_rows;
+    a.CT = 0;
+    HIP_TRY(gemv_launch(a, pl.plan, epi, st));
+    return VLO_OK;
+}
+
+// one chunk of m <= 16 new tokens whose embeddings are already in s->h
+static int run_chunk(vlo_session *s, int m, bool want_last, bool want_all, hipStream_t st) {
+    vlo_engine *e = s->e;
+    const vlo_config &c = e->cfg;
+    const int H = c.hidden_size, I = c.intermediate_size, hd = e->head_dim, nh = c.num_heads, nkv = c.num_kv_heads;
+    const int Nqkv = (nh + 2 * nkv) * hd;
+    int rc;
+    if ((rc = ensure_pages(s, s->len + m, st))) return rc;
+    const KvGeom kv = kv_geom(s);
+    const float *prev = nullptr;
+    int prev_ks = 0;
+    for (int l = 0; l < c.num_layers; ++l) {
+        const LayerWeights &L = e->layers[l];
+        HIP_TRY(add_rmsnorm_launch(s->h, prev, prev_ks, s->partial_ld, (const unsigned short *)L.ln_in, s->x, H, H, c.rms_eps, m, st));
+        if ((rc = run_gemv(L.qkv, s->x, H, m, EPI_PARTIAL_F32, s->partial, nullptr, s->partial_ld, nullptr, st))) return rc;
+        HIP_TRY(rope_kv_append_launch(s->partial, L.qkv.plan.ksplit, s->partial_ld, s->q, (const unsigned short *)e->cos_tab,
+                                      (const unsigned short *)e->sin_tab, kv, l, nh, s->len, m, st));
+        HIP_TRY(attention_launch(s->q, kv, l, nh, s->len, m, s->part_o, s->part_ml, s->attn, st));
+        if ((rc = run_gemv(L.o, s->attn, nh * hd, m, EPI_PARTIAL_F32, s->partial, nullptr, s->partial_ld, nullptr, st))) return rc;
+        HIP_TRY(add_rmsnorm_launch(s->h, s->partial, L.o.plan.ksplit, s->partial_ld, (const unsigned short *)L.ln_post, s->x, H, H,
+                                   c.rms_eps, m, st));
+        if ((rc = run_gemv(L.gate_up, s->x, H, m, EPI_SWIGLU, nullptr, s->act, I, nullptr, st))) return rc;
+        if ((rc = run_gemv(L.down, s->act, I, m, EPI_PARTIAL_F32, s->partial2, nullptr, s->partial_ld, nullptr, st))) return rc;
+        prev = s->partial2;
+        prev_ks = L.down.plan.ksplit;
+    }
+    if (want_last || want_all) {
+        HIP_TRY(add_rmsnorm_launch(s->h, prev, prev_ks, s->partial_ld, (const unsigned short *)e->norm_w, s->x, H, H, c.rms_eps, m, st));
+        if (want_all) {
+            if ((rc = run_gemv(e->lm_head, s->x, H, m, EPI_BF16, nullptr, s->logits, c.vocab_size, nullptr, st))) return rc;
+            s->last_logits = s->logits + (size_t)(m - 1) * c.vocab_size;
+        } else {
+            if ((rc = run_gemv(e->lm_head, s->x + (size_t)(m - 1) * H, H, 1, EPI_BF16, nullptr, s->logits, c.vocab_size, nullptr, st)))
+                return rc;
+            s->last_logits = s->logits;
+        }
+        s->has_logits = true;
+    }
+    s->len += m;
+    return VLO_OK;
+}
+
+int vlo_llm_step(vlo_session *s, const void *embeds_dev, int n, void *last_logits_dev, void *all_logits_dev, void *stream) {
+    if (!s || !embeds_dev || n <= 0) return fail(VLO_E_INVALID, "bad llm_step arguments");
+    vlo_engine *e = s->e;
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int H = e->cfg.hidden_size, V = e->cfg.vocab_size;
+    int rc;
+    for (int c0 = 0; c0 < n; c0 += 16) {
+        const int m = std::min(16, n - c0);
+        const bool last = (c0 + m == n);
+        HIP_TRY(copy_rows_launch((const unsigned short *)embeds_dev + (size_t)c0 * H, s->h, m, H, st));
+        if ((rc = run_chunk(s, m, last, all_logits_dev != nullptr, st))) return rc;
+        if (all_logits_dev)
+            HIP_TRY(hipMemcpyAsync((unsigned short *)all_logits_dev + (size_t)c0 * V, s->logits, (size_t)m * V * 2,
+                                   hipMemcpyDeviceToDevice, st));
+    }
+    if (last_logits_dev) HIP_TRY(hipMemcpyAsync(last_logits_dev, s->last_logits, (size_t)V * 2, hipMemcpyDeviceToDevice, st));
+    return VLO_OK;
+}
+
+int vlo_stream_sample(vlo_session *s, float threshold, int interval_id, int64_t *tok_dev, float *p_interval_dev, void *stream) {
+    if (!s || !tok_dev) return fail(VLO_E_INVALID, "bad stream_sample arguments");
+    if (!s->has_logits) return fail(VLO_E_STATE, "no logits: call vlo_llm_step first");
+    HIP_TRY(hipSetDevice(s->e->device));
+    HIP_TRY(stream_sample_launch(s->last_logits, s->e->cfg.vocab_size, threshold, interval_id, tok_dev, p_interval_dev,
+                                 (hipStream_t)stream));
+    return VLO_OK;
+}
+
+int vlo_embed(vlo_engine *e, const int64_t *ids_dev, int k, void *out_dev, void *stream) {
+    if (!e || !ids_dev || !out_dev || k <= 0) return fail(VLO_E_INVALID, "bad embed arguments");
+    if (!e->finalized) return fail(VLO_E_STATE, "engine not finalized");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(embed_gather_launch((const unsigned short *)e->embed, ids_dev, k, e->cfg.hidden_size, e->cfg.vocab_size,
+                                (unsigned short *)out_dev, (hipStream_t)stream));
+    return VLO_OK;
+}
+
+int vlo_greedy_generate(vlo_session *s, const void *embeds_dev, int m, int eos_token_id, int64_t *out_ids_dev, int max_new,
+                        int force_len, int *n_written, void *stream) {
+    if (!s || !embeds_dev || !out_ids_dev || m <= 0 || max_new <= 0) return fail(VLO_E_INVALID, "bad greedy_generate arguments");
+    vlo_engine *e = s->e;
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int V = e->cfg.vocab_size;
+    if (force_len > max_new) force_len = max_new;
+    int rc = vlo_llm_step(s, embeds_dev, m, nullptr, nullptr, stream);
+    if (rc) return rc;
+    int i = 0;
+    for (;; ++i) {
+        int mode = 0;
+        if (force_len > 0) mode = (i == force_len - 1) ? 2 : 1;
+        HIP_TRY(greedy_sample_launch(s->last_logits, V, out_ids_dev + i, eos_token_id, mode, st));
+        // the reference reads the token on the host every step (`if new_token_id == eos_token_id`, :179)
+        HIP_TRY(hipMemcpyAsync(s->host_tok, out_ids_dev + i, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (*s->host_tok == eos_token_id) break;
+        if (i == max_new - 1) break;
+        HIP_TRY(embed_gather_launch((const unsigned short *)e->embed, out_ids_dev + i, 1, e->cfg.hidden_size, V, s->emb1, st));
+        if ((rc = vlo_llm_step(s, s->emb1, 1, nullptr, nullptr, stream))) return rc;
+    }
+    if (n_written) *n_written = i + 1;
+    return VLO_OK;
+}
+
+int vlo_connector(vlo_engine *e, const void *feats_dev, int rows, void *out_dev, void *stream) {
+    if (!e || !feats_dev || !out_dev || rows <= 0) return fail(VLO_E_INVALID, "bad connector arguments");
+    if (!e->finalized || !e->has_connector) return fail(VLO_E_STATE, "connector weights not loaded");
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int H = e->cfg.hidden_size, Hv = e->cfg.vision_hidden_size;
+    int rc;
+    if (!e->conn_x) {
+        if ((rc = dev_alloc(&e->conn_x, (size_t)32 * Hv * 2))) return rc;
+        if ((rc = dev_alloc(&e->conn_mid, (size_t)32 * H * 2))) return rc;
+        if ((rc = dev_alloc(&e->conn_out, (size_t)32 * H * 2))) return rc;
+        e->owned.push_back(e->conn_x);
+        e->owned.push_back(e->conn_mid);
+        e->owned.push_back(e->conn_out);
+        HIP_TRY(hipMemset(e->conn_x, 0, (size_t)32 * Hv * 2));
+        HIP_TRY(hipMemset(e->conn_mid, 0, (size_t)32 * H * 2));
+    }
+    for (int r0 = 0; r0 < rows; r0 += 16) {
+        const int m = std::min(16, rows - r0);
+        HIP_TRY(copy_rows_launch((const unsigned short *)feats_dev + (size_t)r0 * Hv, (unsigned short *)e->conn_x, m, Hv, st));
+        if ((rc = run_gemv(e->conn0, (const unsigned short *)e->conn_x, Hv, m, EPI_BF16_GELU_ERF, nullptr,
+                           (unsigned short *)e->conn_mid, H, e->conn0_b, st))) return rc;
+        if ((rc = run_gemv(e->conn2, (const unsigned short *)e->conn_mid, H, m, EPI_BF16, nullptr,
+                           (unsigned short *)e->conn_out, H, e->conn2_b, st))) return rc;
+        HIP_TRY(copy_rows_launch((const unsigned short *)e->conn_out, (unsigned short *)out_dev + (size_t)r0 * H, m, H, st));
+    }
+    return VLO_OK;
+}
+
+int vlo_visual_embed(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_dev, void *stream) {
+    if (!e || !frames_dev || !out_dev || B <= 0) return fail(VLO_E_INVALID, "bad visual_embed arguments");
+    if (!e->finalized || !e->cfg.has_vit || !e->vit) return fail(VLO_E_STATE, "engine built without a vision tower");
+    HIP_TRY(hipSetDevice(e->device));
+    return vit_visual_embed(e, frames_dev, B, out_dev, (hipStream_t)stream);
+}
+
+int vlo_session_read_kv(vlo_session *s, int layer, int which, int kv_head, int64_t t0, int64_t t1, void *dst_dev, void *stream) {
+    if (!s || !dst_dev || layer < 0 || layer >= s->e->cfg.num_layers || kv_head < 0 || kv_head >= s->e->cfg.num_kv_heads ||
+        t0 < 0 || t1 > s->len || t1 < t0)
+        return fail(VLO_E_INVALID, "bad read_kv arguments");
+    HIP_TRY(hipSetDevice(s->e->device));
+    HIP_TRY(read_kv_launch(kv_geom(s), layer, which, kv_head, t0, t1, (unsigned short *)dst_dev, (hipStream_t)stream));
+    return VLO_OK;
+}
+
+int vlo_test_gemv(const void *x_dev, const void *W_dev, float *y_dev, int n, int N, int K, void *stream) {
+    if (!x_dev || !W_dev || !y_dev || n <= 0 || n > 16 || N <= 0 || (N & 3)) return fail(VLO_E_INVALID, "bad test_gemv arguments");
+    hipStream_t st = (hipStream_t)stream;
+    GemvPlan plan;
+    if (gemv_plan(K, true, &plan)) return fail(VLO_E_UNSUPPORTED, "no GEMV plan for K");
+    const int NT = (N + 15) / 16;
+    void *Wp = nullptr, *xp = nullptr;
+    float *P = nullptr;
+    HIP_TRY(hipMalloc(&Wp, (size_t)NT * 16 * K * 2));
+    HIP_TRY(hipMalloc(&xp, (size_t)32 * K * 2));
+    HIP_TRY(hipMalloc((void **)&P, (size_t)plan.ksplit * 16 * NT * 16 * 4));
+    HIP_TRY(hipMemsetAsync(xp, 0, (size_t)32 * K * 2, st));
+    HIP_TRY(hipMemcpyAsync(xp, x_dev, (size_t)n * K * 2, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(pack_weight_launch(W_dev, Wp, N, K, NT, 1, 0, st));
+    GemvArgs a;
+    a.Wp = Wp; a.x = (const unsigned short *)xp; a.out_f32 = P; a.out_bf16 = nullptr; a.bias = nullptr;
+    a.K = K; a.ldx = K; a.ldo = NT * 16; a.NT = NT; a.N_valid = N; a.n_rows = n; a.CT = 0;
+    HIP_TRY(gemv_launch(a, plan, EPI_PARTIAL_F32, st));
+    // partial layout is [ksplit][16][ldo]; y is [n][N]
+    {
+        // sum into a padded buffer then copy rows (ldo may exceed N)
+        float *Y = nullptr;
+        HIP_TRY(hipMalloc((void **)&Y, (size_t)16 * NT * 16 * 4));
+        hipLaunchKernelGGL(sum_partials_kernel, dim3((n * NT * 16 + 255) / 256), dim3(256), 0, st, P, plan.ksplit, NT * 16, Y, n, NT * 16);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy2DAsync(y_dev, (size_t)N * 4, Y, (size_t)NT * 16 * 4, (size_t)N * 4, n, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        hipFree(Y);
+    }
+    hipFree(Wp);
+    hipFree(xp);
+    hipFree(P);
+    return VLO_OK;
+}

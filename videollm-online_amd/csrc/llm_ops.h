@@ -1,0 +1,46 @@
+// llm_ops.h — host-visible launchers of llm_ops.hip (Llama step kernels other than the GEMVs)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VLO_PAGE_TOKENS 256      // tokens per KV page (multiple of 32)
+#define VLO_MAX_SPLITS 64        // max KV splits of the attention kernel
+
+// Paged KV pool geometry.  One page id addresses, for every layer, a K block
+// [kvh][PAGE][hd] and a V^T block [kvh][hd][PAGE] (V is stored transposed so the
+// P.V MFMA can take it as an A operand straight from HBM).
+struct KvGeom {
+    unsigned short *k_pool;      // [layer][page][kvh][PAGE][hd]   bf16
+    unsigned short *vt_pool;     // [layer][page][kvh][hd][PAGE]   bf16
+    const int *page_table;       // logical page -> physical page (device)
+    int64_t layer_stride;        // elements between layers  (= pool_pages * page_elems)
+    int64_t page_elems;          // kvh * PAGE * hd
+    int num_kv_heads, head_dim;
+};
+
+// h[m] (+)= bf16(sum_s partial[s][m]) ; x[m] = RMSNorm(h[m]) * w     (rows m < n)
+hipError_t add_rmsnorm_launch(unsigned short *h, const float *partial, int ksplit, int partial_ld,
+                              const unsigned short *w, unsigned short *x, int H, int ldx, float eps, int n,
+                              hipStream_t st);
+
+// split [ks][16][Nqkv] f32 partials into rotary q (bf16 [16][nh*hd]) and K / V^T cache rows
+hipError_t rope_kv_append_launch(const float *qkv_partial, int ksplit, int Nqkv, unsigned short *q_out,
+                                 const unsigned short *cos_tab, const unsigned short *sin_tab,
+                                 KvGeom kv, int layer, int num_heads, int64_t pos0, int n, hipStream_t st);
+
+// chunk attention (n <= 16 queries at positions pos0..pos0+n-1 against keys [0, pos0+n))
+hipError_t attention_launch(const unsigned short *q, KvGeom kv, int layer, int num_heads, int64_t pos0, int n,
+                            float *part_o, float *part_ml, unsigned short *out, hipStream_t st);
+
+hipError_t embed_gather_launch(const unsigned short *table, const int64_t *ids, int k, int H, int64_t vocab,
+                               unsigned short *out, hipStream_t st);
+
+// samplers on bf16 logits [V]
+hipError_t greedy_sample_launch(const unsigned short *logits, int V, int64_t *tok_out, int eos, int force_mode,
+                                hipStream_t st);
+hipError_t stream_sample_launch(const unsigned short *logits, int V, float threshold, int interval_id,
+                                int64_t *tok_out, float *p_interval_out, hipStream_t st);
+
+hipError_t copy_rows_launch(const unsigned short *src, unsigned short *dst, int rows, int H, hipStream_t st);
+hipError_t read_kv_launch(KvGeom kv, int layer, int which, int kv_head, int64_t t0, int64_t t1, unsigned short *dst,
+                          hipStream_t st);

@@ -1,0 +1,198 @@
+"""Thin torch-facing wrapper of the C ABI (include/vlo.h).  torch is plumbing only: it owns
+the caller-side device buffers and the HIP streams whose handles are passed down; every
+computation happens in libvlo.so's HIP kernels."""
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _C
+
+_DT = {torch.float32: _C.DT_F32, torch.bfloat16: _C.DT_BF16, torch.float16: _C.DT_F16}
+
+
+@dataclass
+class EngineConfig:
+    """Field names follow LlamaConfig / LiveConfigMixin (models/configuration_live.py:4-21)."""
+    hidden_size: int
+    intermediate_size: int
+    num_hidden_layers: int
+    num_attention_heads: int
+    num_key_value_heads: int
+    vocab_size: int
+    rope_theta: float = 10000.0
+    rms_norm_eps: float = 1e-5
+    vision_hidden_size: int = 1024
+    frame_num_tokens: int = 10
+    frame_token_pooled: tuple = (3, 3)
+    # vision tower (None = LLM-only engine)
+    vit: dict | None = None
+    kv_pool_tokens: int = 16384
+
+    def to_c(self) -> _C.VloConfig:
+        c = _C.VloConfig()
+        c.abi_version = _C.VLO_ABI_VERSION
+        c.hidden_size, c.intermediate_size, c.num_layers = self.hidden_size, self.intermediate_size, self.num_hidden_layers
+        c.num_heads, c.num_kv_heads, c.vocab_size = self.num_attention_heads, self.num_key_value_heads, self.vocab_size
+        c.rope_theta, c.rms_eps = self.rope_theta, self.rms_norm_eps
+        c.vision_hidden_size, c.frame_num_tokens = self.vision_hidden_size, self.frame_num_tokens
+        c.pool_h, c.pool_w = self.frame_token_pooled
+        c.kv_pool_tokens = self.kv_pool_tokens
+        c.tp_rank, c.tp_size = 0, 1
+        if self.vit:
+            v = self.vit
+            c.has_vit = 1
+            c.vit_hidden_size, c.vit_intermediate_size = v["hidden_size"], v["intermediate_size"]
+            c.vit_num_layers, c.vit_num_heads = v["num_layers"], v["num_heads"]
+            c.vit_image_size, c.vit_patch_size = v["image_size"], v["patch_size"]
+            c.vit_ln_eps = v.get("ln_eps", 1e-6)
+        return c
+
+
+def _stream_handle(stream=None):
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+def _ptr(t: torch.Tensor):
+    return C.c_void_p(t.data_ptr())
+
+
+class Session:
+    """KV handle: what the reference passes around as `past_key_values` (a DynamicCache).
+    Truthiness and get_seq_length() match the uses in demo/inference.py:61,98."""
+
+    def __init__(self, engine: "Engine", max_tokens_hint: int = 0):
+        self.engine = engine
+        h = C.c_void_p()
+        _C.check(_C.lib().vlo_session_create(engine._h, max_tokens_hint, C.byref(h)))
+        self._h = h
+
+    def __bool__(self):
+        return True
+
+    def get_seq_length(self) -> int:
+        return int(_C.lib().vlo_session_len(self._h))
+
+    __len__ = get_seq_length
+
+    def reset(self):
+        _C.check(_C.lib().vlo_session_reset(self._h))
+
+    def close(self):
+        if self._h:
+            _C.lib().vlo_session_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def read_kv(self, layer, which, kv_head, t0, t1):
+        out = torch.empty(t1 - t0, self.engine.head_dim, dtype=torch.bfloat16, device=self.engine.device)
+        _C.check(_C.lib().vlo_session_read_kv(self._h, layer, which, kv_head, t0, t1, _ptr(out), _stream_handle()))
+        return out
+
+
+class Engine:
+    def __init__(self, cfg: EngineConfig, device: int | str | torch.device = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("videollm-online_amd needs a ROCm GPU (MI355X); there is no CPU path")
+        self.cfg = cfg
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        self.head_dim = cfg.hidden_size // cfg.num_attention_heads
+        h = C.c_void_p()
+        cc = cfg.to_c()
+        _C.check(_C.lib().vlo_engine_create(C.byref(cc), self.device.index, C.byref(h)))
+        self._h = h
+        self._finalized = False
+
+    # ---- weights -------------------------------------------------------------------------
+    def load_weight(self, name: str, t: torch.Tensor):
+        t = t.detach().contiguous()
+        if t.dtype not in _DT:
+            raise TypeError(f"{name}: unsupported dtype {t.dtype}")
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        _C.check(_C.lib().vlo_engine_load_weight(self._h, name.encode(), _ptr(t), _DT[t.dtype], shape, t.dim()))
+
+    def load_weights(self, weights: dict):
+        for k, v in weights.items():
+            self.load_weight(k, v)
+
+    def finalize(self):
+        _C.check(_C.lib().vlo_engine_finalize(self._h))
+        self._finalized = True
+        return self
+
+    @property
+    def weight_bytes(self) -> int:
+        return int(_C.lib().vlo_engine_weight_bytes(self._h))
+
+    def step_algorithmic_bytes(self, Lc: int, n: int) -> float:
+        return float(_C.lib().vlo_step_algorithmic_bytes(self._h, Lc, n))
+
+    def new_session(self, max_tokens_hint: int = 0) -> Session:
+        return Session(self, max_tokens_hint)
+
+    def close(self):
+        if self._h:
+            _C.lib().vlo_engine_destroy(self._h)
+            self._h = None
+
+    # ---- ops (each mirrors one reference call; see include/vlo.h) --------------------------
+    def embed(self, ids: torch.Tensor, stream=None) -> torch.Tensor:
+        ids = ids.to(device=self.device, dtype=torch.long).contiguous().view(-1)
+        out = torch.empty(ids.numel(), self.cfg.hidden_size, dtype=torch.bfloat16, device=self.device)
+        _C.check(_C.lib().vlo_embed(self._h, _ptr(ids), ids.numel(), _ptr(out), _stream_handle(stream)))
+        return out
+
+    def connector(self, feats: torch.Tensor, stream=None) -> torch.Tensor:
+        feats = feats.to(device=self.device, dtype=torch.bfloat16).contiguous().view(-1, self.cfg.vision_hidden_size)
+        out = torch.empty(feats.shape[0], self.cfg.hidden_size, dtype=torch.bfloat16, device=self.device)
+        _C.check(_C.lib().vlo_connector(self._h, _ptr(feats), feats.shape[0], _ptr(out), _stream_handle(stream)))
+        return out
+
+    def visual_embed(self, frames_u8: torch.Tensor, stream=None, out: torch.Tensor | None = None) -> torch.Tensor:
+        assert frames_u8.dtype == torch.uint8 and frames_u8.dim() == 4 and frames_u8.is_cuda
+        frames_u8 = frames_u8.contiguous()
+        B = frames_u8.shape[0]
+        if out is None:
+            out = torch.empty(B * self.cfg.frame_num_tokens, self.cfg.hidden_size, dtype=torch.bfloat16, device=self.device)
+        _C.check(_C.lib().vlo_visual_embed(self._h, _ptr(frames_u8), B, _ptr(out), _stream_handle(stream)))
+        return out
+
+    def llm_step(self, session: Session, embeds: torch.Tensor, want_last=True, want_all=False, stream=None):
+        """Returns (last_logits [V] bf16 | None, all_logits [n,V] bf16 | None)."""
+        embeds = embeds.to(device=self.device, dtype=torch.bfloat16).contiguous().view(-1, self.cfg.hidden_size)
+        n = embeds.shape[0]
+        last = torch.empty(self.cfg.vocab_size, dtype=torch.bfloat16, device=self.device) if want_last else None
+        allr = torch.empty(n, self.cfg.vocab_size, dtype=torch.bfloat16, device=self.device) if want_all else None
+        _C.check(_C.lib().vlo_llm_step(session._h, _ptr(embeds), n, _ptr(last) if want_last else None,
+                                       _ptr(allr) if want_all else None, _stream_handle(stream)))
+        return last, allr
+
+    def stream_sample(self, session: Session, threshold: float, interval_id: int, stream=None, tok_out=None, p_out=None):
+        tok = tok_out if tok_out is not None else torch.empty(1, dtype=torch.long, device=self.device)
+        p = p_out if p_out is not None else torch.empty(1, dtype=torch.float32, device=self.device)
+        _C.check(_C.lib().vlo_stream_sample(session._h, threshold, interval_id, _ptr(tok), _ptr(p), _stream_handle(stream)))
+        return tok, p
+
+    def greedy_generate(self, session: Session, embeds: torch.Tensor, eos_token_id: int, inplace_output_ids: torch.Tensor,
+                        force_len: int = 0, stream=None) -> int:
+        embeds = embeds.to(device=self.device, dtype=torch.bfloat16).contiguous().view(-1, self.cfg.hidden_size)
+        assert inplace_output_ids.dtype == torch.long and inplace_output_ids.is_cuda and inplace_output_ids.is_contiguous()
+        n = C.c_int(0)
+        _C.check(_C.lib().vlo_greedy_generate(session._h, _ptr(embeds), embeds.shape[0], eos_token_id,
+                                              _ptr(inplace_output_ids), inplace_output_ids.numel(), force_len,
+                                              C.byref(n), _stream_handle(stream)))
+        return n.value
+
+
+def test_gemv(x: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
+    """y[n,N] f32 = x[n,K] @ W[N,K]^T through the packed MFMA GEMV (unit tests)."""
+    x, W = x.contiguous(), W.contiguous()
+    y = torch.empty(x.shape[0], W.shape[0], dtype=torch.float32, device=x.device)
+    _C.check(_C.lib().vlo_test_gemv(_ptr(x), _ptr(W), _ptr(y), x.shape[0], W.shape[0], W.shape[1], _stream_handle()))
+    return y
