@@ -1,0 +1,75 @@
+"""GPU parity of the SigLIP encode + token selection + connector (vlo_visual_embed) vs the oracle.
+
+The engine follows the reference's GPU numerics (fp16 matmuls under torch.cuda.amp.autocast,
+models/vision_live.py:13); the named CPU reference path is fp32.  Tolerance: the engine's error
+against the fp32 oracle must stay within 2x the error of the oracle's own fp16-autocast emulation
+(+ 2 bf16 ulps of the output scale, the output being bf16)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vlo_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(spec, vspec, w, vw):
+    from videollm_online_amd.engine import Engine, EngineConfig
+    cfg = EngineConfig(hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
+                       num_hidden_layers=spec.num_layers, num_attention_heads=spec.num_heads,
+                       num_key_value_heads=spec.num_kv_heads, vocab_size=spec.vocab_size, rope_theta=spec.rope_theta,
+                       rms_norm_eps=spec.rms_eps, vision_hidden_size=spec.vision_hidden_size, kv_pool_tokens=1024,
+                       frame_num_tokens=vspec.frame_num_tokens, frame_token_pooled=vspec.pooled,
+                       vit=dict(hidden_size=vspec.hidden_size, intermediate_size=vspec.intermediate_size,
+                                num_layers=vspec.num_layers, num_heads=vspec.num_heads, image_size=vspec.image_size,
+                                patch_size=vspec.patch_size, ln_eps=vspec.ln_eps))
+    e = Engine(cfg)
+    e.load_weights(w)
+    e.load_weights(vw)
+    return e.finalize()
+
+
+@pytest.mark.parametrize("llm,vit,B", [("toy128", "toy", 3), ("toy128", "toy", 1), ("tinyllama-2l", "siglip-l16-384-2l", 2)])
+def test_visual_embed_parity(llm, vit, B):
+    spec, vspec = O.LLM_SPECS[llm], O.VIT_SPECS[vit]
+    w = O.init_llm_weights(spec, seed=3)
+    vw = O.init_vit_weights(vspec, seed=1)
+    frames = O.synthetic_frames(B, vspec.image_size, seed=1234)
+    gold_llm = O.LlamaOracle(spec, w, torch.float32)
+    ref_llm = O.LlamaOracle(spec, w, torch.bfloat16)
+    gold = gold_llm.visual_embed(vw, vspec, frames)                       # fp32 everything
+    ref = ref_llm.visual_embed(vw, vspec, frames)                         # the CPU reference path (fp32 ViT, bf16 connector)
+    amp = ref_llm.visual_embed(vw, vspec, frames, mm_dtype=torch.float16)  # the GPU reference path, emulated
+    eng = _engine(spec, vspec, w, vw)
+    out = eng.visual_embed(frames.cuda()).cpu()
+    torch.cuda.synchronize()
+    assert out.shape == (B * vspec.frame_num_tokens, spec.hidden_size)
+    scale = gold.abs().max().item()
+    e = (out.float() - gold).abs().max().item()
+    a = (amp.float() - gold).abs().max().item()
+    r = (ref.float() - gold).abs().max().item()
+    print(f"[{llm}/{vit}] engine err {e:.4g}  fp16-autocast-emulation err {a:.4g}  cpu-ref(bf16 connector) err {r:.4g}  scale {scale:.3g}")
+    assert e <= 2.0 * max(a, r) + 2 * 2 ** -8 * scale
+    # mean error should be at the bf16-output rounding level
+    assert (out.float() - gold).abs().mean().item() <= 2.0 * max((amp.float() - gold).abs().mean().item(), 1e-3 * scale)
+    eng.close()
+
+
+def test_visual_embed_matches_reference_fixture(golden_dir):
+    """frame_embeds in the fixture were produced by the reference's LiveMixin.visual_embed."""
+    g = np.load(os.path.join(golden_dir, "llm_toy128_bf16.npz"))
+    gf = np.load(os.path.join(golden_dir, "llm_toy128_fp32.npz"))
+    spec, vspec = O.LLM_SPECS["toy128"], O.VIT_SPECS["toy"]
+    w = O.init_llm_weights(spec, seed=3)
+    vw = O.init_vit_weights(vspec, seed=1)
+    frames = O.synthetic_frames(3, vspec.image_size, seed=1234)
+    eng = _engine(spec, vspec, w, vw)
+    out = eng.visual_embed(frames.cuda()).cpu().float().numpy()
+    gold = gf["frame_embeds"]
+    e = np.abs(out - gold).max()
+    r = np.abs(g["frame_embeds"] - gold).max()
+    scale = np.abs(gold).max()
+    assert e <= 2.0 * r + 2 * 2 ** -8 * scale + 5e-3 * scale, (e, r, scale)
+    eng.close()

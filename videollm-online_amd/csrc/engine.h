@@ -73,3 +73,4 @@ struct vlo_session {
 };
 
 int dev_alloc(void **p, size_t bytes);
+int vlo_fail(int code, const std::string &msg);   // sets the thread-local error string, returns code

@@ -26,6 +26,7 @@ static int fail(int code, const std::string &msg) {
     g_err = msg;
     return code;
 }
+int vlo_fail(int code, const std::string &msg) { return fail(code, msg); }
 const char *vlo_last_error(void) { return g_err.c_str(); }
 int vlo_abi_version(void) { return VLO_ABI_VERSION; }
 
@@ -101,6 +102,7 @@ void vlo_engine_destroy(vlo_engine *e) {
     hipSetDevice(e->device);
     for (auto &kv : e->raw) hipFree(kv.second.ptr);
     for (void *p : e->owned) hipFree(p);
+    vit_destroy(e);
     delete e;
 }
 
@@ -306,6 +308,7 @@ int vlo_engine_finalize(vlo_engine *e) {
         for (int p = e->pool_pages - 1; p >= 0; --p) e->free_pages.push_back(p);
     }
     if (c.has_vit) {
+        if (!e->has_connector) return fail(VLO_E_MISSING, "vision tower needs the connector weights");
         if ((rc = vit_finalize(e))) return rc;
     }
     HIP_TRY(hipDeviceSynchronize());

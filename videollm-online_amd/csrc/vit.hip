@@ -1,5 +1,661 @@
-// vit.hip — placeholder until the SigLIP kernels land (next commit)
+// vit.hip — SigLIP vision tower + token selection on gfx950 (MFMA-bound part of the hot path).
+//
+// Restates, as hand-written HIP:
+//   _siglip_vision_encode                 models/vision_live.py:10-30   (rescale, normalize, ViT, CLS + 3x3 pool)
+//   SiglipVisionEmbeddings.forward        HF:models/siglip/modeling_siglip.py:175-186  (patch conv == GEMM, + pos)
+//   SiglipEncoderLayer.forward  x L       HF:...:335-357  (LN, MHSA :273-307, MLP :318-322 with tanh-GELU)
+//   post_layernorm + MAP head             HF:...:612-614, :633-644
+//   LiveMixin.visual_embed                models/modeling_live.py:21-27 (-> bf16 -> connector, gemv.hip)
+//
+// Precision follows the reference's GPU path (torch.cuda.amp.autocast, models/vision_live.py:13):
+// matmul operands and outputs fp16, accumulation fp32, LayerNorm / softmax / residual stream fp32.
+//
+// GEMM: out[m][n] = sum_k X[m][k] * W[n][k]; both operands K-contiguous.  v_mfma_f32_16x16x32_f16 with the
+// WEIGHT tile as the A operand and the ACTIVATION tile as the B operand, so a lane ends up holding 4
+// consecutive output columns of one token row (8-byte row-major stores).
+#include <string.h>
+
+#include <algorithm>
+
+#include "common.cuh"
 #include "vit.h"
-int vit_finalize(vlo_engine *) { return VLO_E_UNSUPPORTED; }
-int vit_visual_embed(vlo_engine *, const uint8_t *, int, void *, hipStream_t) { return VLO_E_UNSUPPORTED; }
-void vit_destroy(vlo_engine *) {}
+
+enum { EP_F16 = 0, EP_F16_GELU = 1, EP_RESID = 2, EP_PATCH = 3, EP_QKV = 4, EP_F32 = 5 };
+
+struct GemmArgs {
+    const f16_t *X;            // [M][ldx] fp16   (EP_PATCH: unused)
+    const uint8_t *frames;     // EP_PATCH: uint8 [B][3][R][R]
+    const f16_t *W;            // [N][K] fp16
+    const float *bias;         // [N] fp32
+    f16_t *out16;              // EP_F16 / EP_F16_GELU / EP_QKV (q,k part): [M][ldo]
+    f16_t *outVT;              // EP_QKV: V^T [B][heads][hd][S]
+    float *out32;              // EP_RESID / EP_PATCH: residual stream [M][N];  EP_F32: [M][ldo]
+    const float *pos;          // EP_PATCH: [S][N]
+    int M, N, K, ldx, ldo;
+    int S, R, P, G;            // tokens per frame, resolution, patch size, grid (EP_PATCH / EP_QKV)
+    int D, hd;                 // EP_QKV: hidden size, head dim
+};
+
+VLO_DEV float gelu_tanh_f(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    return 0.5f * x * (1.0f + tanhf(k0 * (x + k1 * x * x * x)));
+}
+VLO_DEV float rh(float x) { return h2f(f2h(x)); }     // fp16 rounding point
+
+#define GEMM_BK 64
+
+template <int BM, int BN, int EP>
+__global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs a) {
+    constexpr int MI = BM / 32, NI = BN / 32;          // 16x16 tiles per wave along m / n (2x2 waves)
+    __shared__ __attribute__((aligned(16))) f16_t sX[2][BM * GEMM_BK];
+    __shared__ __attribute__((aligned(16))) f16_t sW[2][BN * GEMM_BK];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int r16 = lane & 15, qd = lane >> 4;
+    constexpr int XCH = BM * 8 / 256, WCH = BN * 8 / 256;   // 16-byte chunks per thread per tile
+    uint4 rx[XCH], rw[WCH];
+
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int id = tid + i * 256, row = id >> 3, c = id & 7;
+            const int m = m0 + row;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (m < a.M) {
+                if (EP == EP_PATCH) {
+                    // im2col on the fly: k = ch*P*P + py*P + px ; 8 consecutive px -> 8 consecutive bytes
+                    const int k = k0 + c * 8;
+                    const int ch = k / (a.P * a.P), rem = k % (a.P * a.P), py = rem / a.P, px = rem % a.P;
+                    const int b = m / a.S, t = m % a.S, gy = t / a.G, gx = t % a.G;
+                    const uint8_t *src = a.frames + (((size_t)b * 3 + ch) * a.R + gy * a.P + py) * a.R + gx * a.P + px;
+                    const uint2 raw = *reinterpret_cast<const uint2 *>(src);
+                    const uint8_t *e = reinterpret_cast<const uint8_t *>(&raw);
+                    f16_t o[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        // frames * rescale_factor, then (x - 0.5) / 0.5 in fp32, cast fp16 (vision_live.py:12)
+                        const float x = (float)e[j] * 0.00392156862745098f;
+                        o[j] = f2h((x - 0.5f) / 0.5f);
+                    }
+                    v = *reinterpret_cast<const uint4 *>(o);
+                } else {
+                    v = *reinterpret_cast<const uint4 *>(a.X + (size_t)m * a.ldx + k0 + c * 8);
+                }
+            }
+            rx[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int id = tid + i * 256, row = id >> 3, c = id & 7;
+            const int n = n0 + row;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (n < a.N) v = *reinterpret_cast<const uint4 *>(a.W + (size_t)n * a.K + k0 + c * 8);
+            rw[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int id = tid + i * 256, row = id >> 3, c = id & 7;
+            *reinterpret_cast<uint4 *>(&sX[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]) = rx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int id = tid + i * 256, row = id >> 3, c = id & 7;
+            *reinterpret_cast<uint4 *>(&sW[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]) = rw[i];
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = a.K / GEMM_BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile((kt + 1) * GEMM_BK);
+#pragma unroll
+        for (int kk = 0; kk < GEMM_BK / 32; ++kk) {
+            frag_ab fx[MI], fw[NI];
+            const int c = kk * 4 + qd;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int row = wm * (BM / 2) + i * 16 + r16;
+                fx[i] = *reinterpret_cast<const frag_ab *>(&sX[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]);
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int row = wn * (BN / 2) + j * 16 + r16;
+                fw[j] = *reinterpret_cast<const frag_ab *>(&sW[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = mfma_f16(fw[j], fx[i], acc[i][j]);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds out[m][n .. n+3], m = tile row (lane&15), n = tile col (lane>>4)*4
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * (BM / 2) + i * 16 + r16;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + qd * 4;
+            if (n >= a.N) continue;
+            const float4 bv = *reinterpret_cast<const float4 *>(a.bias + n);
+            float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
+            if (EP == EP_F16 || EP == EP_F16_GELU) {
+                ushort4 o;
+                if (EP == EP_F16_GELU) {
+                    o.x = f2h(gelu_tanh_f(rh(v[0]))); o.y = f2h(gelu_tanh_f(rh(v[1])));
+                    o.z = f2h(gelu_tanh_f(rh(v[2]))); o.w = f2h(gelu_tanh_f(rh(v[3])));
+                } else {
+                    o.x = f2h(v[0]); o.y = f2h(v[1]); o.z = f2h(v[2]); o.w = f2h(v[3]);
+                }
+                *reinterpret_cast<ushort4 *>(a.out16 + (size_t)m * a.ldo + n) = o;
+            } else if (EP == EP_F32) {
+                *reinterpret_cast<float4 *>(a.out32 + (size_t)m * a.ldo + n) = make_float4(rh(v[0]), rh(v[1]), rh(v[2]), rh(v[3]));
+            } else if (EP == EP_RESID) {
+                float4 *hp = reinterpret_cast<float4 *>(a.out32 + (size_t)m * a.N + n);
+                float4 hv = *hp;
+                hv.x += rh(v[0]); hv.y += rh(v[1]); hv.z += rh(v[2]); hv.w += rh(v[3]);
+                *hp = hv;
+            } else if (EP == EP_PATCH) {
+                const float4 pv = *reinterpret_cast<const float4 *>(a.pos + (size_t)(m % a.S) * a.N + n);
+                *reinterpret_cast<float4 *>(a.out32 + (size_t)m * a.N + n) =
+                    make_float4(rh(v[0]) + pv.x, rh(v[1]) + pv.y, rh(v[2]) + pv.z, rh(v[3]) + pv.w);
+            } else if (EP == EP_QKV) {
+                if (n < 2 * a.D) {
+                    ushort4 o;
+                    o.x = f2h(v[0]); o.y = f2h(v[1]); o.z = f2h(v[2]); o.w = f2h(v[3]);
+                    *reinterpret_cast<ushort4 *>(a.out16 + (size_t)m * a.ldo + n) = o;
+                } else {
+                    const int b = m / a.S, t = m % a.S;
+                    const int dcol = n - 2 * a.D, head = dcol / a.hd, d = dcol % a.hd;
+                    f16_t *vt = a.outVT + (((size_t)b * (a.D / a.hd) + head) * a.hd + d) * a.S + t;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vt[(size_t)r * a.S] = f2h(v[r]);
+                }
+            }
+        }
+    }
+}
+
+template <int EP>
+static hipError_t gemm_launch(const GemmArgs &a, hipStream_t st) {
+    if (a.K % GEMM_BK || (a.N & 3)) return hipErrorInvalidValue;
+    if (a.M <= 32) {
+        dim3 grid((a.N + 63) / 64, (a.M + 31) / 32);
+        hipLaunchKernelGGL((vit_gemm_kernel<32, 64, EP>), grid, dim3(256), 0, st, a);
+    } else {
+        dim3 grid((a.N + 63) / 64, (a.M + 63) / 64);
+        hipLaunchKernelGGL((vit_gemm_kernel<64, 64, EP>), grid, dim3(256), 0, st, a);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// LayerNorm (fp32 in, fp32 stats) -> fp16 (matmul operand) and optionally fp32
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vit_layernorm_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                            const float *__restrict__ b, f16_t *__restrict__ out16,
+                                                            float *__restrict__ out32, int D, float eps) {
+    __shared__ float sm[16];
+    const float *xr = x + (size_t)blockIdx.x * D;
+    float v[8];
+    int cnt = 0;
+    float s = 0.f;
+    for (int i = threadIdx.x * 4; i < D; i += 1024, ++cnt) {
+        const float4 t = *reinterpret_cast<const float4 *>(xr + i);
+        v[cnt * 4] = t.x; v[cnt * 4 + 1] = t.y; v[cnt * 4 + 2] = t.z; v[cnt * 4 + 3] = t.w;
+        s += t.x + t.y + t.z + t.w;
+    }
+    const float mean = block_sum(s, sm) / (float)D;
+    float q = 0.f;
+    for (int c = 0; c < cnt * 4; ++c) {
+        const float d = v[c] - mean;
+        q += d * d;
+    }
+    const float var = block_sum(q, sm) / (float)D;
+    const float rs = 1.0f / sqrtf(var + eps);
+    cnt = 0;
+    for (int i = threadIdx.x * 4; i < D; i += 1024, ++cnt) {
+        const float4 wv = *reinterpret_cast<const float4 *>(w + i);
+        const float4 bv = *reinterpret_cast<const float4 *>(b + i);
+        const float o0 = (v[cnt * 4] - mean) * rs * wv.x + bv.x, o1 = (v[cnt * 4 + 1] - mean) * rs * wv.y + bv.y;
+        const float o2 = (v[cnt * 4 + 2] - mean) * rs * wv.z + bv.z, o3 = (v[cnt * 4 + 3] - mean) * rs * wv.w + bv.w;
+        if (out16) {
+            ushort4 o;
+            o.x = f2h(o0); o.y = f2h(o1); o.z = f2h(o2); o.w = f2h(o3);
+            *reinterpret_cast<ushort4 *>(out16 + (size_t)blockIdx.x * D + i) = o;
+        }
+        if (out32) *reinterpret_cast<float4 *>(out32 + (size_t)blockIdx.x * D + i) = make_float4(o0, o1, o2, o3);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// non-causal MHSA, hd = 64.  grid = (S/64 q-tiles, heads, B); 4 waves x 16 query rows.
+// Same operand scheme as the Llama chunk attention (llm_ops.hip): K rows and V^T rows are MFMA
+// A operands read straight from global/L2, P^T never leaves the lanes that computed it.
+// ------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void vit_attn_kernel(const f16_t *__restrict__ qk, const f16_t *__restrict__ vT,
+                                                       f16_t *__restrict__ out, int S, int D, int nheads, float scale) {
+    constexpr int NKK = HD / 32, NDT = HD / 16;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int qrow = lane & 15, qd = lane >> 4;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 64 + w * 16;
+    const size_t ld = (size_t)2 * D;
+    const f16_t *qbase = qk + (size_t)b * S * ld + (size_t)head * HD;
+    const f16_t *kbase = qbase + D;
+    const f16_t *vbase = vT + ((size_t)b * nheads + head) * HD * S;
+
+    frag_ab qf[NKK];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+        frag_ab z = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (q0 + qrow < S) z = *reinterpret_cast<const frag_ab *>(qbase + (size_t)(q0 + qrow) * ld + kk * 32 + qd * 8);
+        qf[kk] = z;
+    }
+    f32x4 O[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) O[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mrun = -INFINITY, lrun = 0.f;
+
+    for (int kt0 = 0; kt0 < S; kt0 += 32) {
+        frag_ab kf[2][NKK];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int key = min(kt0 + t * 16 + qrow, S - 1);
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk)
+                kf[t][kk] = *reinterpret_cast<const frag_ab *>(kbase + (size_t)key * ld + kk * 32 + qd * 8);
+        }
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            s0 = mfma_f16(kf[0][kk], qf[kk], s0);
+            s1 = mfma_f16(kf[1][kk], qf[kk], s1);
+        }
+        const int kb = kt0 + qd * 4;
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] = (kb + r < S) ? s0[r] * scale : -INFINITY;
+            v[4 + r] = (kb + 16 + r < S) ? s1[r] * scale : -INFINITY;
+        }
+        float tmax = v[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) tmax = fmaxf(tmax, v[j]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(mrun, tmax);
+        const float alpha = __expf(mrun - m_new);
+        mrun = m_new;
+        float psum = 0.f;
+        frag_ab pb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float p = __expf(v[j] - m_new);
+            psum += p;
+            pb[j] = (short)f2h(p);
+        }
+        lrun = lrun * alpha + psum;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            const f16_t *vr = vbase + (size_t)(dt * 16 + qrow) * S + kt0 + qd * 4;
+            uint2 lo = make_uint2(0, 0), hi = make_uint2(0, 0);
+            if (kt0 + qd * 4 < S) lo = *reinterpret_cast<const uint2 *>(vr);
+            if (kt0 + 16 + qd * 4 < S) hi = *reinterpret_cast<const uint2 *>(vr + 16);
+            const uint4 pk = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            f32x4 o = O[dt];
+            o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
+            O[dt] = mfma_f16(__builtin_bit_cast(frag_ab, pk), pb, o);
+        }
+    }
+    lrun += __shfl_xor(lrun, 16, 64);
+    lrun += __shfl_xor(lrun, 32, 64);
+    if (q0 + qrow < S) {
+        const float inv = 1.0f / lrun;
+        f16_t *orow = out + ((size_t)b * S + q0 + qrow) * D + (size_t)head * HD;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            ushort4 o;
+            o.x = f2h(O[dt][0] * inv); o.y = f2h(O[dt][1] * inv); o.z = f2h(O[dt][2] * inv); o.w = f2h(O[dt][3] * inv);
+            *reinterpret_cast<ushort4 *>(orow + dt * 16 + qd * 4) = o;
+        }
+    }
+}
+
+// MAP head attention: one probe query per head over S keys.  grid = (heads, B), 256 threads.
+// kv: fp16 [B*S][2D] (K | V row-major), qp: fp16 [D] (probe @ Wq + bq, precomputed at load)
+__global__ __launch_bounds__(256) void map_attn_kernel(const f16_t *__restrict__ kv, const f16_t *__restrict__ qp,
+                                                       f16_t *__restrict__ out, int S, int D, int hd, float scale) {
+    extern __shared__ float prob[];            // [S]
+    __shared__ float sm[16];
+    const int head = blockIdx.x, b = blockIdx.y;
+    const f16_t *kb = kv + (size_t)b * S * 2 * D + (size_t)head * hd;
+    const f16_t *vb = kb + D;
+    float mx = -INFINITY;
+    for (int t = threadIdx.x; t < S; t += blockDim.x) {
+        float s = 0.f;
+        for (int d = 0; d < hd; ++d) s += h2f(qp[head * hd + d]) * h2f(kb[(size_t)t * 2 * D + d]);
+        s *= scale;
+        prob[t] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = block_max(mx, sm);
+    float sum = 0.f;
+    for (int t = threadIdx.x; t < S; t += blockDim.x) {
+        const float p = __expf(prob[t] - mx);
+        prob[t] = p;
+        sum += p;
+    }
+    sum = block_sum(sum, sm);
+    __syncthreads();
+    // 256 threads = hd(64) x 4 key groups
+    const int d = threadIdx.x % hd, grp = threadIdx.x / hd, ng = blockDim.x / hd;
+    float acc = 0.f;
+    for (int t = grp; t < S; t += ng) acc += rh(prob[t] / sum) * h2f(vb[(size_t)t * 2 * D + d]);
+    __syncthreads();
+    float *red = prob;                          // reuse
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (grp == 0) {
+        float tot = 0.f;
+        for (int g = 0; g < ng; ++g) tot += red[g * hd + d];
+        out[(size_t)b * D + head * hd + d] = f2h(tot);
+    }
+}
+
+// CLS + pooled tokens -> bf16 [B][1 + ph*pw][D]   (adaptive_avg_pool2d with exact G/ph blocks; vision_live.py:16-30)
+__global__ void pool_concat_kernel(const float *__restrict__ last, const float *__restrict__ cls, bf16_t *__restrict__ out, int G,
+                                   int D, int ph, int pw) {
+    const int b = blockIdx.y, tok = blockIdx.x, T = 1 + ph * pw, S = G * G;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float v;
+        if (tok == 0) {
+            v = cls[(size_t)b * D + d];
+        } else {
+            const int py = (tok - 1) / pw, px = (tok - 1) % pw;
+            // adaptive pooling windows: [floor(i*G/p), ceil((i+1)*G/p))
+            const int y0 = (py * G) / ph, y1 = ((py + 1) * G + ph - 1) / ph;
+            const int x0 = (px * G) / pw, x1 = ((px + 1) * G + pw - 1) / pw;
+            float s = 0.f;
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) s += last[((size_t)b * S + y * G + x) * D + d];
+            v = s / (float)((y1 - y0) * (x1 - x0));
+        }
+        out[((size_t)b * T + tok) * D + d] = f2bf(v);       // frames.to(self.dtype)  (modeling_live.py:25)
+    }
+}
+
+// residual for the MAP head: out32[b][d] = a16[b][d] + (acc16 computed by EP_F32 gemm) — done inline via EP_F32 + add
+__global__ void add_f16_f32_kernel(const f16_t *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = h2f(a[i]) + b[i];
+}
+__global__ void f16_to_f32_kernel(const f16_t *__restrict__ a, float *__restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = h2f(a[i]);
+}
+
+// ------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------
+struct VitLayer {
+    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+    f16_t *wqkv;
+    float *bqkv;
+    const f16_t *wo, *w1, *w2;
+    const float *bo, *b1, *b2;
+};
+
+struct VitState {
+    int D, I, L, nh, hd, R, P, G, S, ph, pw;
+    float eps;
+    const f16_t *wpe;
+    const float *bpe, *pos;
+    std::vector<VitLayer> layers;
+    const float *post_w, *post_b;
+    const f16_t *in_proj_w;      // [3D][D]
+    const float *in_proj_b;
+    const f16_t *hout_w, *hfc1_w, *hfc2_w;
+    const float *hout_b, *hln_w, *hln_b, *hfc1_b, *hfc2_b;
+    f16_t *q_probe;              // [D]
+    // workspace for up to Bcap frames
+    int Bcap = 0;
+    float *h = nullptr, *last = nullptr, *cls32 = nullptr, *tmp32 = nullptr;
+    f16_t *x16 = nullptr, *qk16 = nullptr, *vT = nullptr, *att16 = nullptr, *mid16 = nullptr, *kv16 = nullptr;
+    f16_t *hx16 = nullptr, *hmid16 = nullptr, *hatt16 = nullptr, *ho16 = nullptr;
+    bf16_t *tokens = nullptr;
+    std::vector<void *> ws;
+};
+
+
+#define VIT_TRY(expr)                                                                                    \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess) return vlo_fail(VLO_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+static int vtake(vlo_engine *e, const std::string &name, std::vector<int64_t> shape, int dtype, const void **out) {
+    auto it = e->raw.find(name);
+    if (it == e->raw.end()) return vlo_fail(VLO_E_MISSING, "missing weight: " + name);
+    if (it->second.shape != shape || it->second.dtype != dtype) return vlo_fail(VLO_E_INVALID, "bad shape/dtype for " + name);
+    *out = it->second.ptr;
+    e->owned.push_back(it->second.ptr);
+    size_t n = 1;
+    for (auto d : shape) n *= (size_t)d;
+    e->weight_bytes += (int64_t)(n * (dtype == VLO_DT_F32 ? 4 : 2));
+    e->raw.erase(it);
+    return VLO_OK;
+}
+
+int vit_finalize(vlo_engine *e) {
+    const vlo_config &c = e->cfg;
+    VitState *v = new VitState();
+    v->D = c.vit_hidden_size; v->I = c.vit_intermediate_size; v->L = c.vit_num_layers; v->nh = c.vit_num_heads;
+    v->hd = v->D / v->nh; v->R = c.vit_image_size; v->P = c.vit_patch_size; v->G = v->R / v->P; v->S = v->G * v->G;
+    v->ph = c.pool_h; v->pw = c.pool_w; v->eps = c.vit_ln_eps;
+    const int D = v->D, I = v->I;
+    if (v->hd != 64 || (D % 64) || (I % 64) || ((3 * v->P * v->P) % 64) || (v->P % 8) || c.vision_hidden_size != D ||
+        c.frame_num_tokens != 1 + v->ph * v->pw || (v->S % 4))
+        { delete v; return vlo_fail(VLO_E_UNSUPPORTED, "vision tower shape not covered by the kernels (need head_dim 64, dims % 64 == 0)"); }
+    int rc;
+#define TK(name, shape, dt, field) if ((rc = vtake(e, name, shape, dt, (const void **)&field))) { delete v; return rc; }
+    TK("vision.embeddings.patch_embedding.weight", (std::vector<int64_t>{D, 3, v->P, v->P}), VLO_DT_F16, v->wpe);
+    TK("vision.embeddings.patch_embedding.bias", (std::vector<int64_t>{D}), VLO_DT_F32, v->bpe);
+    TK("vision.embeddings.position_embedding.weight", (std::vector<int64_t>{v->S, D}), VLO_DT_F32, v->pos);
+    v->layers.resize(v->L);
+    for (int l = 0; l < v->L; ++l) {
+        VitLayer &Ly = v->layers[l];
+        const std::string p = "vision.encoder.layers." + std::to_string(l) + ".";
+        TK(p + "layer_norm1.weight", (std::vector<int64_t>{D}), VLO_DT_F32, Ly.ln1_w);
+        TK(p + "layer_norm1.bias", (std::vector<int64_t>{D}), VLO_DT_F32, Ly.ln1_b);
+        TK(p + "layer_norm2.weight", (std::vector<int64_t>{D}), VLO_DT_F32, Ly.ln2_w);
+        TK(p + "layer_norm2.bias", (std::vector<int64_t>{D}), VLO_DT_F32, Ly.ln2_b);
+        // fuse q,k,v into one [3D][D] weight
+        if ((rc = dev_alloc((void **)&Ly.wqkv, (size_t)3 * D * D * 2))) { delete v; return rc; }
+        if ((rc = dev_alloc((void **)&Ly.bqkv, (size_t)3 * D * 4))) { delete v; return rc; }
+        e->owned.push_back(Ly.wqkv);
+        e->owned.push_back(Ly.bqkv);
+        const char *nm[3] = {"q_proj", "k_proj", "v_proj"};
+        for (int j = 0; j < 3; ++j) {
+            const f16_t *wsrc;
+            const float *bsrc;
+            TK(p + "self_attn." + nm[j] + ".weight", (std::vector<int64_t>{D, D}), VLO_DT_F16, wsrc);
+            TK(p + "self_attn." + nm[j] + ".bias", (std::vector<int64_t>{D}), VLO_DT_F32, bsrc);
+            VIT_TRY(hipMemcpy(Ly.wqkv + (size_t)j * D * D, wsrc, (size_t)D * D * 2, hipMemcpyDeviceToDevice));
+            VIT_TRY(hipMemcpy(Ly.bqkv + (size_t)j * D, bsrc, (size_t)D * 4, hipMemcpyDeviceToDevice));
+        }
+        TK(p + "self_attn.out_proj.weight", (std::vector<int64_t>{D, D}), VLO_DT_F16, Ly.wo);
+        TK(p + "self_attn.out_proj.bias", (std::vector<int64_t>{D}), VLO_DT_F32, Ly.bo);
+        TK(p + "mlp.fc1.weight", (std::vector<int64_t>{I, D}), VLO_DT_F16, Ly.w1);
+        TK(p + "mlp.fc1.bias", (std::vector<int64_t>{I}), VLO_DT_F32, Ly.b1);
+        TK(p + "mlp.fc2.weight", (std::vector<int64_t>{D, I}), VLO_DT_F16, Ly.w2);
+        TK(p + "mlp.fc2.bias", (std::vector<int64_t>{D}), VLO_DT_F32, Ly.b2);
+    }
+    TK("vision.post_layernorm.weight", (std::vector<int64_t>{D}), VLO_DT_F32, v->post_w);
+    TK("vision.post_layernorm.bias", (std::vector<int64_t>{D}), VLO_DT_F32, v->post_b);
+    TK("vision.head.attention.in_proj_weight", (std::vector<int64_t>{3 * D, D}), VLO_DT_F16, v->in_proj_w);
+    TK("vision.head.attention.in_proj_bias", (std::vector<int64_t>{3 * D}), VLO_DT_F32, v->in_proj_b);
+    TK("vision.head.attention.out_proj.weight", (std::vector<int64_t>{D, D}), VLO_DT_F16, v->hout_w);
+    TK("vision.head.attention.out_proj.bias", (std::vector<int64_t>{D}), VLO_DT_F32, v->hout_b);
+    TK("vision.head.layernorm.weight", (std::vector<int64_t>{D}), VLO_DT_F32, v->hln_w);
+    TK("vision.head.layernorm.bias", (std::vector<int64_t>{D}), VLO_DT_F32, v->hln_b);
+    TK("vision.head.mlp.fc1.weight", (std::vector<int64_t>{I, D}), VLO_DT_F16, v->hfc1_w);
+    TK("vision.head.mlp.fc1.bias", (std::vector<int64_t>{I}), VLO_DT_F32, v->hfc1_b);
+    TK("vision.head.mlp.fc2.weight", (std::vector<int64_t>{D, I}), VLO_DT_F16, v->hfc2_w);
+    TK("vision.head.mlp.fc2.bias", (std::vector<int64_t>{D}), VLO_DT_F32, v->hfc2_b);
+    // probe query is input-independent: q = probe @ Wq^T + bq, once (fp16 like the autocast Linear)
+    {
+        const float *probe32;
+        TK("vision.head.probe", (std::vector<int64_t>{1, 1, D}), VLO_DT_F32, probe32);
+        f16_t *probe16;
+        if ((rc = dev_alloc((void **)&probe16, (size_t)D * 2)) || (rc = dev_alloc((void **)&v->q_probe, (size_t)D * 2))) { delete v; return rc; }
+        e->owned.push_back(probe16);
+        e->owned.push_back(v->q_probe);
+        std::vector<float> hp(D);
+        VIT_TRY(hipMemcpy(hp.data(), probe32, (size_t)D * 4, hipMemcpyDeviceToHost));
+        std::vector<f16_t> hp16(D);
+        for (int i = 0; i < D; ++i) { _Float16 t = (_Float16)hp[i]; memcpy(&hp16[i], &t, 2); }
+        VIT_TRY(hipMemcpy(probe16, hp16.data(), (size_t)D * 2, hipMemcpyHostToDevice));
+        GemmArgs a{};
+        a.X = probe16; a.W = v->in_proj_w; a.bias = v->in_proj_b; a.out16 = v->q_probe;
+        a.M = 1; a.N = D; a.K = D; a.ldx = D; a.ldo = D;
+        VIT_TRY(gemm_launch<EP_F16>(a, 0));
+        VIT_TRY(hipDeviceSynchronize());
+    }
+#undef TK
+    e->vit = v;
+    return VLO_OK;
+}
+
+static int vit_reserve(vlo_engine *e, VitState *v, int B) {
+    if (B <= v->Bcap) return VLO_OK;
+    hipDeviceSynchronize();
+    for (void *p : v->ws) hipFree(p);
+    v->ws.clear();
+    const size_t M = (size_t)B * v->S, D = v->D, I = v->I;
+    int rc = 0;
+    auto A = [&](void **p, size_t bytes) {
+        if (rc) return;
+        rc = dev_alloc(p, bytes);
+        if (!rc) v->ws.push_back(*p);
+    };
+    A((void **)&v->h, M * D * 4);
+    A((void **)&v->last, M * D * 4);
+    A((void **)&v->x16, M * D * 2);
+    A((void **)&v->qk16, M * 2 * D * 2);
+    A((void **)&v->vT, M * D * 2);
+    A((void **)&v->att16, M * D * 2);
+    A((void **)&v->mid16, M * I * 2);
+    A((void **)&v->kv16, M * 2 * D * 2);
+    A((void **)&v->hatt16, (size_t)B * D * 2);
+    A((void **)&v->ho16, (size_t)B * D * 2);
+    A((void **)&v->hx16, (size_t)B * D * 2);
+    A((void **)&v->hmid16, (size_t)B * I * 2);
+    A((void **)&v->cls32, (size_t)B * D * 4);
+    A((void **)&v->tmp32, (size_t)B * D * 4);
+    A((void **)&v->tokens, (size_t)B * (1 + v->ph * v->pw) * D * 2);
+    if (rc) return rc;
+    v->Bcap = B;
+    (void)e;
+    return VLO_OK;
+}
+
+int vit_visual_embed(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_dev, hipStream_t st) {
+    VitState *v = e->vit;
+    int rc;
+    if ((rc = vit_reserve(e, v, B))) return rc;
+    const int D = v->D, I = v->I, S = v->S, M = B * S;
+    const float scale = 1.0f / sqrtf((float)v->hd);
+    {   // patch embed + pos  -> residual stream h (fp32)
+        GemmArgs a{};
+        a.frames = frames_dev; a.W = v->wpe; a.bias = v->bpe; a.out32 = v->h; a.pos = v->pos;
+        a.M = M; a.N = D; a.K = 3 * v->P * v->P; a.S = S; a.R = v->R; a.P = v->P; a.G = v->G;
+        VIT_TRY(gemm_launch<EP_PATCH>(a, st));
+    }
+    for (int l = 0; l < v->L; ++l) {
+        const VitLayer &Ly = v->layers[l];
+        hipLaunchKernelGGL(vit_layernorm_kernel, dim3(M), dim3(256), 0, st, v->h, Ly.ln1_w, Ly.ln1_b, v->x16, (float *)nullptr, D, v->eps);
+        {
+            GemmArgs a{};
+            a.X = v->x16; a.W = Ly.wqkv; a.bias = Ly.bqkv; a.out16 = v->qk16; a.outVT = v->vT;
+            a.M = M; a.N = 3 * D; a.K = D; a.ldx = D; a.ldo = 2 * D; a.S = S; a.D = D; a.hd = v->hd;
+            VIT_TRY(gemm_launch<EP_QKV>(a, st));
+        }
+        hipLaunchKernelGGL((vit_attn_kernel<64>), dim3((S + 63) / 64, v->nh, B), dim3(256), 0, st, v->qk16, v->vT, v->att16, S, D, v->nh, scale);
+        {
+            GemmArgs a{};
+            a.X = v->att16; a.W = Ly.wo; a.bias = Ly.bo; a.out32 = v->h;
+            a.M = M; a.N = D; a.K = D; a.ldx = D;
+            VIT_TRY(gemm_launch<EP_RESID>(a, st));
+        }
+        hipLaunchKernelGGL(vit_layernorm_kernel, dim3(M), dim3(256), 0, st, v->h, Ly.ln2_w, Ly.ln2_b, v->x16, (float *)nullptr, D, v->eps);
+        {
+            GemmArgs a{};
+            a.X = v->x16; a.W = Ly.w1; a.bias = Ly.b1; a.out16 = v->mid16;
+            a.M = M; a.N = I; a.K = D; a.ldx = D; a.ldo = I;
+            VIT_TRY(gemm_launch<EP_F16_GELU>(a, st));
+        }
+        {
+            GemmArgs a{};
+            a.X = v->mid16; a.W = Ly.w2; a.bias = Ly.b2; a.out32 = v->h;
+            a.M = M; a.N = D; a.K = I; a.ldx = I;
+            VIT_TRY(gemm_launch<EP_RESID>(a, st));
+        }
+    }
+    // post layernorm: fp32 (pooling input) + fp16 (head K/V operand)
+    hipLaunchKernelGGL(vit_layernorm_kernel, dim3(M), dim3(256), 0, st, v->h, v->post_w, v->post_b, v->x16, v->last, D, v->eps);
+    {   // MAP head: K,V = last @ Wkv^T + bkv
+        GemmArgs a{};
+        a.X = v->x16; a.W = v->in_proj_w + (size_t)D * D; a.bias = v->in_proj_b + D; a.out16 = v->kv16;
+        a.M = M; a.N = 2 * D; a.K = D; a.ldx = D; a.ldo = 2 * D;
+        VIT_TRY(gemm_launch<EP_F16>(a, st));
+    }
+    hipLaunchKernelGGL(map_attn_kernel, dim3(v->nh, B), dim3(256), (size_t)std::max(S, 256) * 4, st, v->kv16, v->q_probe, v->hatt16, S, D, v->hd, scale);
+    {   // out_proj -> attention output a (fp16), kept as the residual
+        GemmArgs a{};
+        a.X = v->hatt16; a.W = v->hout_w; a.bias = v->hout_b; a.out16 = v->ho16;
+        a.M = B; a.N = D; a.K = D; a.ldx = D; a.ldo = D;
+        VIT_TRY(gemm_launch<EP_F16>(a, st));
+    }
+    hipLaunchKernelGGL(f16_to_f32_kernel, dim3((B * D + 255) / 256), dim3(256), 0, st, v->ho16, v->tmp32, B * D);
+    hipLaunchKernelGGL(vit_layernorm_kernel, dim3(B), dim3(256), 0, st, v->tmp32, v->hln_w, v->hln_b, v->hx16, (float *)nullptr, D, v->eps);
+    {
+        GemmArgs a{};
+        a.X = v->hx16; a.W = v->hfc1_w; a.bias = v->hfc1_b; a.out16 = v->hmid16;
+        a.M = B; a.N = I; a.K = D; a.ldx = D; a.ldo = I;
+        VIT_TRY(gemm_launch<EP_F16_GELU>(a, st));
+    }
+    {   // cls = residual + mlp(...)
+        GemmArgs a{};
+        a.X = v->hmid16; a.W = v->hfc2_w; a.bias = v->hfc2_b; a.out32 = v->tmp32;
+        a.M = B; a.N = D; a.K = I; a.ldx = I;
+        VIT_TRY(gemm_launch<EP_RESID>(a, st));
+    }
+    hipLaunchKernelGGL(pool_concat_kernel, dim3(1 + v->ph * v->pw, B), dim3(256), 0, st, v->last, v->tmp32, v->tokens, v->G, D, v->ph, v->pw);
+    VIT_TRY(hipGetLastError());
+    // connector (bf16 skinny GEMMs, gemv.hip)
+    return vlo_connector(e, v->tokens, B * (1 + v->ph * v->pw), out_dev, st);
+}
+
+void vit_destroy(vlo_engine *e) {
+    if (!e->vit) return;
+    for (void *p : e->vit->ws) hipFree(p);
+    delete e->vit;
+    e->vit = nullptr;
+}
