@@ -149,6 +149,13 @@ double vlo_step_algorithmic_bytes(const vlo_engine *e, int64_t Lc, int n);
  * W_dev is an ordinary row-major device tensor; packs on every call (tests only). */
 int vlo_test_gemv(const void *x_dev, const void *W_dev, float *y_dev, int n, int N, int K, void *stream);
 
+/* live kernel timing for bench.py's roofline: when enabled, every `stride`-th launch of the dominant
+ * kernel (the gate/up weight-streaming GEMV, gemv16_kernel<KF,SWIGLU>) is bracketed by HIP events on the
+ * stream it is launched on.  vlo_profile_read synchronises those events and returns the number of timed
+ * launches, their total milliseconds and the algorithmic bytes of ONE launch. */
+int vlo_profile_enable(vlo_engine *e, int stride);     /* stride <= 0 disables and clears */
+int vlo_profile_read(vlo_engine *e, int64_t *launches, double *total_ms, double *bytes_per_launch);
+
 const char *vlo_last_error(void);
 int vlo_abi_version(void);
 

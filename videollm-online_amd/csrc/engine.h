@@ -55,6 +55,14 @@ struct vlo_engine {
     std::mutex pool_mu;
 
     VitState *vit = nullptr;
+
+    // live timing of the dominant kernel (vlo_profile_*)
+    int prof_stride = 0;
+    int64_t prof_seen = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;   // pool
+    size_t prof_used = 0;
+    int64_t prof_launches = 0;
+    double prof_ms = 0.0;
 };
 
 struct vlo_session {

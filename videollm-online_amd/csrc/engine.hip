@@ -102,6 +102,7 @@ void vlo_engine_destroy(vlo_engine *e) {
     hipSetDevice(e->device);
     for (auto &kv : e->raw) hipFree(kv.second.ptr);
     for (void *p : e->owned) hipFree(p);
+    for (auto &pr : e->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     vit_destroy(e);
     delete e;
 }
@@ -455,6 +456,55 @@ static int run_gemv(const PackedLinear &pl, const unsigned short *x, int ldx, in
     return VLO_OK;
 }
 
+// ---- live timing of the dominant kernel -------------------------------------------------
+static void prof_flush(vlo_engine *e) {
+    for (size_t i = 0; i < e->prof_used; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(e->prof_events[i].second) == hipSuccess &&
+            hipEventElapsedTime(&ms, e->prof_events[i].first, e->prof_events[i].second) == hipSuccess) {
+            e->prof_ms += ms;
+            e->prof_launches++;
+        }
+    }
+    e->prof_used = 0;
+}
+static void prof_acquire(vlo_engine *e, hipEvent_t *a, hipEvent_t *b) {
+    if (e->prof_used == e->prof_events.size()) {
+        if (e->prof_events.size() >= 4096) {
+            prof_flush(e);
+        } else {
+            hipEvent_t x, y;
+            if (hipEventCreate(&x) != hipSuccess || hipEventCreate(&y) != hipSuccess) return;
+            e->prof_events.push_back({x, y});
+        }
+    }
+    *a = e->prof_events[e->prof_used].first;
+    *b = e->prof_events[e->prof_used].second;
+    e->prof_used++;
+}
+int vlo_profile_enable(vlo_engine *e, int stride) {
+    if (!e) return fail(VLO_E_INVALID, "null engine");
+    prof_flush(e);
+    e->prof_stride = stride > 0 ? stride : 0;
+    e->prof_seen = 0;
+    e->prof_launches = 0;
+    e->prof_ms = 0.0;
+    return VLO_OK;
+}
+int vlo_profile_read(vlo_engine *e, int64_t *launches, double *total_ms, double *bytes_per_launch) {
+    if (!e || !e->finalized) return fail(VLO_E_INVALID, "bad profile_read arguments");
+    HIP_TRY(hipSetDevice(e->device));
+    prof_flush(e);
+    if (launches) *launches = e->prof_launches;
+    if (total_ms) *total_ms = e->prof_ms;
+    if (bytes_per_launch) {
+        // gate+up weights [2I][H] bf16 streamed once + x [n<=16][H] in + act [n][I] out (n = 11 nominal)
+        const double H = e->cfg.hidden_size, I = e->cfg.intermediate_size;
+        *bytes_per_launch = 2.0 * I * H * 2.0 + 11.0 * H * 2.0 + 11.0 * I * 2.0;
+    }
+    return VLO_OK;
+}
+
 // one chunk of m <= 16 new tokens whose embeddings are already in s->h
 static int run_chunk(vlo_session *s, int m, bool want_last, bool want_all, hipStream_t st) {
     vlo_engine *e = s->e;
@@ -476,7 +526,13 @@ static int run_chunk(vlo_session *s, int m, bool want_last, bool want_all, hipSt
         if ((rc = run_gemv(L.o, s->attn, nh * hd, m, EPI_PARTIAL_F32, s->partial, nullptr, s->partial_ld, nullptr, st))) return rc;
         HIP_TRY(add_rmsnorm_launch(s->h, s->partial, L.o.plan.ksplit, s->partial_ld, (const unsigned short *)L.ln_post, s->x, H, H,
                                    c.rms_eps, m, st));
-        if ((rc = run_gemv(L.gate_up, s->x, H, m, EPI_SWIGLU, nullptr, s->act, I, nullptr, st))) return rc;
+        {
+            hipEvent_t ev0 = nullptr, ev1 = nullptr;
+            if (e->prof_stride > 0 && (e->prof_seen++ % e->prof_stride) == 0) prof_acquire(e, &ev0, &ev1);
+            if (ev0) hipEventRecord(ev0, st);
+            if ((rc = run_gemv(L.gate_up, s->x, H, m, EPI_SWIGLU, nullptr, s->act, I, nullptr, st))) return rc;
+            if (ev1) hipEventRecord(ev1, st);
+        }
         if ((rc = run_gemv(L.down, s->act, I, m, EPI_PARTIAL_F32, s->partial2, nullptr, s->partial_ld, nullptr, st))) return rc;
         prev = s->partial2;
         prev_ks = L.down.plan.ksplit;

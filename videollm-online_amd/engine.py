@@ -133,6 +133,15 @@ class Engine:
     def step_algorithmic_bytes(self, Lc: int, n: int) -> float:
         return float(_C.lib().vlo_step_algorithmic_bytes(self._h, Lc, n))
 
+    def profile_enable(self, stride: int = 1):
+        _C.check(_C.lib().vlo_profile_enable(self._h, stride))
+
+    def profile_read(self):
+        """(timed launches, total ms, algorithmic bytes per launch) of the dominant kernel (gate/up GEMV)."""
+        n, ms, b = C.c_int64(0), C.c_double(0), C.c_double(0)
+        _C.check(_C.lib().vlo_profile_read(self._h, C.byref(n), C.byref(ms), C.byref(b)))
+        return n.value, ms.value, b.value
+
     def new_session(self, max_tokens_hint: int = 0) -> Session:
         return Session(self, max_tokens_hint)
 
