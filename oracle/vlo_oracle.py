@@ -431,13 +431,24 @@ def stream_sample(logits_last: torch.Tensor, interval_id: int, threshold: float)
     return int(score.argmax(dim=-1)), p_int
 
 
+def top2_margin(logits_last: torch.Tensor, exclude: int | None = None):
+    """(top-1 minus top-2 logit, runner-up id) — test bookkeeping for near-tie detection."""
+    v = logits_last.float().clone()
+    if exclude is not None:
+        v[exclude] = -float("inf")
+    t = v.topk(2)
+    return float(t.values[0] - t.values[1]), int(t.indices[1])
+
+
 @torch.no_grad()
-def fast_greedy_generate(model: LlamaOracle, inputs_embeds, cache, eos_token_id: int, max_new: int = 100):
+def fast_greedy_generate(model: LlamaOracle, inputs_embeds, cache, eos_token_id: int, max_new: int = 100, margins=None):
     """models/modeling_live.py:173-182.  Returns (list of ids incl. a terminating EOS, cache)."""
     out = []
     for _ in range(max_new):
         logits, cache = model.forward(inputs_embeds, cache)
         tok = int(logits[-1].argmax(dim=-1))
+        if margins is not None:
+            margins.append(top2_margin(logits[-1]))
         out.append(tok)
         if tok == eos_token_id:
             break
@@ -515,11 +526,13 @@ class LiveInferOracle:
         if forced is not None:
             out, self.past_key_values = forced_generate(self.llm, emb, self.past_key_values, forced[1],
                                                         self.tok.eos_token_id)
+            margins = None
         else:
+            margins = []
             out, self.past_key_values = fast_greedy_generate(self.llm, emb, self.past_key_values,
-                                                             self.tok.eos_token_id, max_new)
+                                                             self.tok.eos_token_id, max_new, margins)
         self.last_ids = out[-1:]
-        self.trace.append(("response", video_time, query, list(out)))
+        self.trace.append(("response", video_time, query, list(out), margins))
         return query, out
 
     def _call_for_streaming(self):                                     # :54-82
@@ -537,6 +550,8 @@ class LiveInferOracle:
             self._frames_done += 1
             if self.query_queue and video_time >= self.query_queue[0][0]:                        # rule 2
                 return self.query_queue.popleft()
+            zeroed = float(logits[-1].softmax(dim=-1)[self.tok.interval_id]) < self.threshold
+            margin = top2_margin(logits[-1], self.tok.interval_id if zeroed else None)
             tok, p_int = stream_sample(logits[-1], self.tok.interval_id, self.threshold)        # rule 3
             forced = self.schedule(self._frames_done - 1) if self.schedule is not None else None
             if forced is not None:
@@ -544,7 +559,7 @@ class LiveInferOracle:
                 if tok == self.tok.interval_id and forced[0]:
                     raise ValueError("schedule needs stream_generation_ids[0] != interval_id")
             self.last_ids = [tok]
-            self.trace.append(("frame", video_time, tok, p_int, len(self.past_key_values)))
+            self.trace.append(("frame", video_time, tok, p_int, len(self.past_key_values), margin))
             if tok != self.tok.interval_id:
                 return video_time, None
         return None, None

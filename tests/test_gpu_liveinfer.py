@@ -32,16 +32,6 @@ def _build(spec, vspec, w, vw, toks, **kw):
     return eng, LiveInfer(model, tokens=st, frame_fps=2, **kw)
 
 
-def _events(trace):
-    out = []
-    for ev in trace:
-        if ev[0] == "frame":
-            out.append(("frame", ev[1], ev[2]))
-        else:
-            out.append(("response", ev[1], ev[2], tuple(ev[3])))
-    return out
-
-
 def _drive(li, frames, n, query_at=None):
     li.load_video(frames)
     if query_at is not None:
@@ -51,33 +41,53 @@ def _drive(li, frames, n, query_at=None):
         li()
 
 
+NEAR_TIE = 0.12     # logit units: ~4 bf16 ulps at |logit| ~ 4-8; ViT fp16-vs-fp32 + bf16 accumulation-order noise
+
+
 @pytest.mark.parametrize("prefetch", [True, False])
 @pytest.mark.parametrize("query_at", [0.0, 1.2, None])
 def test_free_running_stream_matches_oracle(prefetch, query_at):
+    """Identical decisions and greedy ids as the reference CPU path, event by event.  A divergence is
+    accepted only at a near-tie of the reference's own logits (top-2 margin < NEAR_TIE) where the
+    engine picked the runner-up; comparison stops there (the streams legitimately differ afterwards)."""
     spec, vspec = O.LLM_SPECS["toy128"], O.VIT_SPECS["toy"]
     w, vw = O.init_llm_weights(spec, seed=3), O.init_vit_weights(vspec, seed=1)
     toks = O.default_tokens(spec, seed=7, n_start=19)
     frames = O.synthetic_frames(6, vspec.image_size, seed=1234)
-    traces = {}
-    for name, dt in (("ref", torch.bfloat16), ("gold", torch.float32)):
-        o = O.LiveInferOracle(O.LlamaOracle(spec, w, dt), vw, vspec, toks, frame_fps=2, max_new=5)
-        _drive(o, frames, 6, query_at)
-        traces[name] = _events([e[:3] + e[3:4] if e[0] == "response" else e for e in o.trace])
+    o = O.LiveInferOracle(O.LlamaOracle(spec, w, torch.bfloat16), vw, vspec, toks, frame_fps=2, max_new=5)
+    _drive(o, frames, 6, query_at)
+    ref = o.trace
     eng, li = _build(spec, vspec, w, vw, toks, prefetch=prefetch, max_new_tokens=5)
     _drive(li, frames.cuda(), 6, query_at)
-    got = _events(li.trace)
-    ref, gold = traces["ref"], traces["gold"]
+    got = li.trace
     assert len(got) > 0
+    compared = 0
+    diverged = False
     for i, ev in enumerate(got):
-        if i < len(ref) and ev == ref[i]:
-            continue
-        # first divergence: acceptable only where the reference's own bf16 path disagrees with fp32 gold
-        # (a near-tie in the logits) and the engine sides with gold
-        assert i < len(gold) and i < len(ref) and ref[i] != gold[i], f"event {i}: engine {ev} vs reference {ref[i] if i < len(ref) else None}"
-        assert ev[:2] == gold[i][:2], f"event {i}: engine {ev} vs gold {gold[i]}"
-        break
-    else:
+        assert i < len(ref), "engine produced more events than the reference"
+        r = ref[i]
+        assert ev[0] == r[0] and ev[1] == r[1], f"event {i}: kind/time {ev[:2]} vs {r[:2]}"
+        if ev[0] == "frame":
+            if ev[2] != r[2]:
+                margin, runner = r[5]
+                assert margin < NEAR_TIE and ev[2] == runner, f"event {i}: token {ev[2]} vs {r[2]} (margin {margin}, runner-up {runner})"
+                diverged = True
+                break
+        else:
+            assert ev[2] == r[2]
+            for j, t in enumerate(ev[3]):
+                if j >= len(r[3]) or t != r[3][j]:
+                    margin, runner = r[4][j]
+                    assert margin < NEAR_TIE and t == runner, f"event {i} token {j}: {t} vs {r[3][j]} (margin {margin})"
+                    diverged = True
+                    break
+            if diverged:
+                break
+        compared += 1
+    if not diverged:
         assert len(got) == len(ref)
+    assert compared >= 2, f"diverged too early to be meaningful (after {compared} events)"
+    print(f"[liveinfer prefetch={prefetch} query_at={query_at}] {compared}/{len(ref)} events identical, diverged={diverged}")
     li.reset()
     eng.close()
 
