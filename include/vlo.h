@@ -156,6 +156,10 @@ int vlo_test_gemv(const void *x_dev, const void *W_dev, float *y_dev, int n, int
 int vlo_profile_enable(vlo_engine *e, int stride);     /* stride <= 0 disables and clears */
 int vlo_profile_read(vlo_engine *e, int64_t *launches, double *total_ms, double *bytes_per_launch);
 
+/* micro-benchmark of the weight-streaming GEMV on synthetic data (tools/bench_gemv.py): `nbuf` distinct
+ * packed weight images are cycled so the 256 MiB Infinity Cache cannot serve re-reads. */
+int vlo_bench_gemv(int N, int K, int n_rows, int epi, int iters, int nbuf, double *avg_us);
+
 const char *vlo_last_error(void);
 int vlo_abi_version(void);
 

@@ -431,13 +431,18 @@ def stream_sample(logits_last: torch.Tensor, interval_id: int, threshold: float)
     return int(score.argmax(dim=-1)), p_int
 
 
-def top2_margin(logits_last: torch.Tensor, exclude: int | None = None):
-    """(top-1 minus top-2 logit, runner-up id) — test bookkeeping for near-tie detection."""
+def top2_margin(logits_last: torch.Tensor, exclude: int | None = None, chosen: int | None = None):
+    """(top-1 minus top-2 logit, runner-up id) — test bookkeeping for near-tie detection.  With an exact
+    bf16 tie torch.argmax keeps the lower index while topk may order the pair either way, so the
+    runner-up is reported as "the top-2 entry that is not the chosen token"."""
     v = logits_last.float().clone()
     if exclude is not None:
         v[exclude] = -float("inf")
     t = v.topk(2)
-    return float(t.values[0] - t.values[1]), int(t.indices[1])
+    i0, i1 = int(t.indices[0]), int(t.indices[1])
+    if chosen is None:
+        chosen = int(v.argmax())
+    return float(t.values[0] - t.values[1]), (i1 if chosen == i0 else i0)
 
 
 @torch.no_grad()
@@ -448,7 +453,7 @@ def fast_greedy_generate(model: LlamaOracle, inputs_embeds, cache, eos_token_id:
         logits, cache = model.forward(inputs_embeds, cache)
         tok = int(logits[-1].argmax(dim=-1))
         if margins is not None:
-            margins.append(top2_margin(logits[-1]))
+            margins.append(top2_margin(logits[-1], None, tok))
         out.append(tok)
         if tok == eos_token_id:
             break
@@ -551,8 +556,8 @@ class LiveInferOracle:
             if self.query_queue and video_time >= self.query_queue[0][0]:                        # rule 2
                 return self.query_queue.popleft()
             zeroed = float(logits[-1].softmax(dim=-1)[self.tok.interval_id]) < self.threshold
-            margin = top2_margin(logits[-1], self.tok.interval_id if zeroed else None)
             tok, p_int = stream_sample(logits[-1], self.tok.interval_id, self.threshold)        # rule 3
+            margin = top2_margin(logits[-1], self.tok.interval_id if zeroed else None, tok)
             forced = self.schedule(self._frames_done - 1) if self.schedule is not None else None
             if forced is not None:
                 tok = self.tok.stream_generation_ids[0] if forced[0] else self.tok.interval_id

@@ -137,7 +137,8 @@ def test_golden_scripted_stream(golden_dir, name, seed):
         r = (r_ - g_).abs().max().item()
         assert e <= 1.5 * r + 1e-3 * g_.abs().max().item(), (s, e, r)
     assert int(tok) == int(refb["stream_tok"])
-    assert abs(float(p) - float(refb["p_interval"])) <= 3 * 2 ** -8 * float(refb["p_interval"]) + 1e-9
+    # p = softmax(l)[interval]: one bf16 ulp on that logit (~0.016-0.03) moves p by 1.5-3 %
+    assert abs(float(p) - float(refb["p_interval"])) <= 0.06 * float(refb["p_interval"]) + 1e-9
     ref_ids, gold_ids = refb["gen_ids"].tolist(), gold["gen_ids"].tolist()
     for i, t in enumerate(gen):       # identical greedy ids; at a bf16 near-tie the engine may side with fp32 gold
         if t != ref_ids[i]:
@@ -179,7 +180,7 @@ def test_samplers_match_torch():
             tok, p = eng.stream_sample(sess, thr, interval)
             rt, rp = O.stream_sample(logits.clone(), interval, thr)
             assert int(tok) == rt, (trial, thr)
-            assert abs(float(p) - rp) <= 2 ** -7 * rp + 1e-12
+            assert abs(float(p) - rp) <= 2 ** -7 * rp + 1e-12      # same logits in, so only bf16 rounding of p
     sess.close(); eng.close()
 
 

@@ -697,3 +697,39 @@ int vlo_test_gemv(const void *x_dev, const void *W_dev, float *y_dev, int n, int
     hipFree(P);
     return VLO_OK;
 }
+
+int vlo_bench_gemv(int N, int K, int n_rows, int epi, int iters, int nbuf, double *avg_us) {
+    if (N <= 0 || K <= 0 || n_rows <= 0 || n_rows > 16 || iters <= 0 || nbuf <= 0 || !avg_us) return fail(VLO_E_INVALID, "bad bench_gemv arguments");
+    GemvPlan plan;
+    if (gemv_plan(K, epi == EPI_PARTIAL_F32, &plan)) return fail(VLO_E_UNSUPPORTED, "no GEMV plan for K");
+    const int NT = (N + 15) / 16;
+    const size_t wbytes = (size_t)NT * 16 * K * 2;
+    std::vector<void *> Wp(nbuf, nullptr);
+    void *x = nullptr, *o32 = nullptr, *o16 = nullptr;
+    for (int i = 0; i < nbuf; ++i) {
+        HIP_TRY(hipMalloc(&Wp[i], wbytes));
+        HIP_TRY(hipMemset(Wp[i], 0x3c, wbytes));      // 0x3c3c = a small finite bf16
+    }
+    HIP_TRY(hipMalloc(&x, (size_t)32 * K * 2));
+    HIP_TRY(hipMemset(x, 0x3c, (size_t)32 * K * 2));
+    HIP_TRY(hipMalloc(&o32, (size_t)plan.ksplit * 16 * NT * 16 * 4));
+    HIP_TRY(hipMalloc(&o16, (size_t)16 * NT * 16 * 2));
+    GemvArgs a;
+    a.x = (const unsigned short *)x; a.out_f32 = (float *)o32; a.out_bf16 = (unsigned short *)o16; a.bias = nullptr;
+    a.K = K; a.ldx = K; a.ldo = (epi == EPI_SWIGLU) ? NT * 8 : NT * 16; a.NT = NT; a.N_valid = N; a.n_rows = n_rows; a.CT = 0;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) { a.Wp = Wp[i % nbuf]; HIP_TRY(gemv_launch(a, plan, epi, 0)); }
+    HIP_TRY(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) { a.Wp = Wp[i % nbuf]; HIP_TRY(gemv_launch(a, plan, epi, 0)); }
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = (double)ms * 1e3 / iters;
+    for (void *p : Wp) hipFree(p);
+    hipFree(x); hipFree(o32); hipFree(o16);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return VLO_OK;
+}

@@ -60,154 +60,197 @@ VLO_DEV float gelu_python_bf16(float x) {    // HF GELUActivation(use_gelu_pytho
     return rbf(a * s);
 }
 
-template <int KF, int EPI>
-__global__ __launch_bounds__(1024) void gemv16_kernel(GemvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float4 red[];
+// One (tile, lane) element of the reduced output -> epilogue.  s = sum over the block's waves.
+template <int EPI>
+VLO_DEV void gemv_epilogue(const GemvArgs &a, int tile, int l, float4 s, float4 s2, int kslice) {
+    const int m = l & 15;
+    if (m >= a.n_rows) return;
+    if (EPI == EPI_SWIGLU) {           // s = gate tile, s2 = up tile; `tile` is the pair index
+        const int col = tile * 16 + (l >> 4) * 4;
+        ushort4 o;
+        o.x = f2bf(silu_bf16(rbf(s.x)) * rbf(s2.x));
+        o.y = f2bf(silu_bf16(rbf(s.y)) * rbf(s2.y));
+        o.z = f2bf(silu_bf16(rbf(s.z)) * rbf(s2.z));
+        o.w = f2bf(silu_bf16(rbf(s.w)) * rbf(s2.w));
+        *reinterpret_cast<ushort4 *>(a.out_bf16 + (size_t)m * a.ldo + col) = o;
+        return;
+    }
+    const int col = tile * 16 + (l >> 4) * 4;
+    if (EPI == EPI_PARTIAL_F32) {
+        *reinterpret_cast<float4 *>(a.out_f32 + ((size_t)kslice * 16 + m) * a.ldo + col) = s;
+        return;
+    }
+    if (col >= a.N_valid) return;          // N padded to 16 at pack time; N_valid % 4 == 0
+    if (a.bias) {
+        const ushort4 b = *reinterpret_cast<const ushort4 *>(a.bias + col);
+        s.x += bf2f(b.x); s.y += bf2f(b.y); s.z += bf2f(b.z); s.w += bf2f(b.w);
+    }
+    ushort4 o;
+    if (EPI == EPI_BF16_GELU_ERF) {
+        o.x = f2bf(gelu_python_bf16(rbf(s.x))); o.y = f2bf(gelu_python_bf16(rbf(s.y)));
+        o.z = f2bf(gelu_python_bf16(rbf(s.z))); o.w = f2bf(gelu_python_bf16(rbf(s.w)));
+    } else {
+        o.x = f2bf(s.x); o.y = f2bf(s.y); o.z = f2bf(s.z); o.w = f2bf(s.w);
+    }
+    *reinterpret_cast<ushort4 *>(a.out_bf16 + (size_t)m * a.ldo + col) = o;
+}
+
+// Persistent, software-pipelined weight streamer.
+//   grid.y = K slices; grid.x blocks stride over groups of CTG consecutive column tiles.
+//   Wave w of a block owns KF weight fragments (K range) of every tile the block visits and keeps
+//   the matching activation fragments in VGPRs.  The loads of tile t+1 are issued before the MFMAs
+//   of tile t (two register sets), also across group boundaries, so the wave always has 16..32 KiB
+//   of HBM reads in flight.  Per group: partial tiles -> LDS (double-buffered), one barrier, the
+//   first CTG*64 threads reduce across waves and run the epilogue.
+template <int KF, int NW, int EPI>
+__global__ __launch_bounds__(NW * 64) void gemv16_kernel(GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float4 red[];      // [2][NW][CTG][64]
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
-    const int NW = blockDim.x >> 6;
     const int KFtot = a.K >> 5;
     const int kf0 = (blockIdx.y * NW + w) * KF;
+    const int CTG = a.CT;
 
-    // activation fragments (B operand): x[m = lane&15][k = (kf0+kf)*32 + (lane>>4)*8 ..]
     frag_ab xf[KF];
     {
         const bf16_t *xr = a.x + (size_t)(lane & 15) * a.ldx + (size_t)kf0 * 32 + (lane >> 4) * 8;
 #pragma unroll
         for (int kf = 0; kf < KF; ++kf) xf[kf] = *reinterpret_cast<const frag_ab *>(xr + kf * 32);
     }
-    const int tile0 = blockIdx.x * a.CT;
-    const int ntiles = min(a.CT, a.NT - tile0);
-    for (int ct = 0; ct < ntiles; ++ct) {
-        const frag_ab *wp = reinterpret_cast<const frag_ab *>(a.Wp) + ((size_t)(tile0 + ct) * KFtot + kf0) * 64 + lane;
-        frag_ab wf[KF];
-#pragma unroll
-        for (int kf = 0; kf < KF; ++kf) wf[kf] = __builtin_nontemporal_load(wp + kf * 64);
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kf = 0; kf < KF; ++kf) acc = mfma_bf16(wf[kf], xf[kf], acc);
-        red[(w * a.CT + ct) * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    }
-    __syncthreads();
+    const frag_ab *wbase = reinterpret_cast<const frag_ab *>(a.Wp) + (size_t)kf0 * 64 + lane;
+    const size_t tile_stride = (size_t)KFtot * 64;
+    const int ngroups = (a.NT + CTG - 1) / CTG;
 
-    // cross-wave reduction + epilogue: thread t owns (tile ct = t/64, fragment lane l = t%64)
-    if (EPI == EPI_SWIGLU) {
-        // tiles come in (gate, up) pairs
-        const int npair = ntiles >> 1;
-        for (int t = threadIdx.x; t < npair * 64; t += blockDim.x) {
-            const int pr = t >> 6, l = t & 63;
-            float4 g = make_float4(0, 0, 0, 0), u = make_float4(0, 0, 0, 0);
-            for (int ww = 0; ww < NW; ++ww) {
-                const float4 a0 = red[(ww * a.CT + 2 * pr) * 64 + l];
-                const float4 a1 = red[(ww * a.CT + 2 * pr + 1) * 64 + l];
-                g.x += a0.x; g.y += a0.y; g.z += a0.z; g.w += a0.w;
-                u.x += a1.x; u.y += a1.y; u.z += a1.z; u.w += a1.w;
-            }
-            const int m = l & 15;
-            if (m < a.n_rows) {
-                const int col = ((tile0 >> 1) + pr) * 16 + (l >> 4) * 4;    // column in the [.., I] activation
-                ushort4 o;
-                o.x = f2bf(silu_bf16(rbf(g.x)) * rbf(u.x));
-                o.y = f2bf(silu_bf16(rbf(g.y)) * rbf(u.y));
-                o.z = f2bf(silu_bf16(rbf(g.z)) * rbf(u.z));
-                o.w = f2bf(silu_bf16(rbf(g.w)) * rbf(u.w));
-                *reinterpret_cast<ushort4 *>(a.out_bf16 + (size_t)m * a.ldo + col) = o;
-            }
-        }
-        return;
+    // rolling prefetch: w[kf] is re-loaded with the next tile's fragment right after the MFMA that
+    // consumed it, so KF x 1 KiB of HBM reads stay in flight per wave with one register set.
+    frag_ab wr[KF];
+    int g = blockIdx.x;
+    if (g < ngroups) {
+        const frag_ab *wp = wbase + (size_t)(g * CTG) * tile_stride;
+#pragma unroll
+        for (int kf = 0; kf < KF; ++kf) wr[kf] = __builtin_nontemporal_load(wp + kf * 64);
     }
-    for (int t = threadIdx.x; t < ntiles * 64; t += blockDim.x) {
-        const int ct = t >> 6, l = t & 63;
-        float4 s = make_float4(0, 0, 0, 0);
-        for (int ww = 0; ww < NW; ++ww) {
-            const float4 v = red[(ww * a.CT + ct) * 64 + l];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-        const int m = l & 15;
-        if (m >= a.n_rows) continue;
-        const int col = (tile0 + ct) * 16 + (l >> 4) * 4;
-        if (EPI == EPI_PARTIAL_F32) {
-            *reinterpret_cast<float4 *>(a.out_f32 + ((size_t)blockIdx.y * 16 + m) * a.ldo + col) = s;
-        } else {
-            if (col >= a.N_valid) continue;       // N padded to 16 at pack time; N_valid % 4 == 0
-            if (a.bias) {
-                const ushort4 b = *reinterpret_cast<const ushort4 *>(a.bias + col);
-                s.x += bf2f(b.x); s.y += bf2f(b.y); s.z += bf2f(b.z); s.w += bf2f(b.w);
-            }
-            ushort4 o;
-            if (EPI == EPI_BF16_GELU_ERF) {
-                o.x = f2bf(gelu_python_bf16(rbf(s.x))); o.y = f2bf(gelu_python_bf16(rbf(s.y)));
-                o.z = f2bf(gelu_python_bf16(rbf(s.z))); o.w = f2bf(gelu_python_bf16(rbf(s.w)));
+    int buf = 0;
+    for (; g < ngroups; g += gridDim.x) {
+        const int tile0 = g * CTG;
+        const int cnt = min(CTG, a.NT - tile0);
+        float4 *rb = red + (size_t)buf * NW * CTG * 64;
+        for (int ct = 0; ct < cnt; ++ct) {
+            // the next tile this wave will need (next in group, or first of the block's next group)
+            int nt = tile0 + ct + 1;
+            if (ct + 1 == cnt) nt = (g + gridDim.x < ngroups) ? (g + gridDim.x) * CTG : -1;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (nt >= 0) {
+                const frag_ab *wp = wbase + (size_t)nt * tile_stride;
+#pragma unroll
+                for (int kf = 0; kf < KF; ++kf) {
+                    acc = mfma_bf16(wr[kf], xf[kf], acc);
+                    wr[kf] = __builtin_nontemporal_load(wp + kf * 64);
+                }
             } else {
-                o.x = f2bf(s.x); o.y = f2bf(s.y); o.z = f2bf(s.z); o.w = f2bf(s.w);
+#pragma unroll
+                for (int kf = 0; kf < KF; ++kf) acc = mfma_bf16(wr[kf], xf[kf], acc);
             }
-            *reinterpret_cast<ushort4 *>(a.out_bf16 + (size_t)m * a.ldo + col) = o;
+            rb[(w * CTG + ct) * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
+        __syncthreads();
+        if (EPI == EPI_SWIGLU) {
+            const int npair = cnt >> 1;
+            for (int t = threadIdx.x; t < npair * 64; t += NW * 64) {
+                const int pr = t >> 6, l = t & 63;
+                float4 gsum = make_float4(0, 0, 0, 0), usum = make_float4(0, 0, 0, 0);
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww) {
+                    const float4 a0 = rb[(ww * CTG + 2 * pr) * 64 + l];
+                    const float4 a1 = rb[(ww * CTG + 2 * pr + 1) * 64 + l];
+                    gsum.x += a0.x; gsum.y += a0.y; gsum.z += a0.z; gsum.w += a0.w;
+                    usum.x += a1.x; usum.y += a1.y; usum.z += a1.z; usum.w += a1.w;
+                }
+                gemv_epilogue<EPI>(a, (tile0 >> 1) + pr, l, gsum, usum, blockIdx.y);
+            }
+        } else {
+            for (int t = threadIdx.x; t < cnt * 64; t += NW * 64) {
+                const int ct = t >> 6, l = t & 63;
+                float4 s = make_float4(0, 0, 0, 0);
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww) {
+                    const float4 v = rb[(ww * CTG + ct) * 64 + l];
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+                gemv_epilogue<EPI>(a, tile0 + ct, l, s, s, blockIdx.y);
+            }
+        }
+        buf ^= 1;
     }
 }
 
 // ------------------------------------------------------------------------------------
 // host side: plan + launch
 // ------------------------------------------------------------------------------------
-static const int kKFSet[] = {16, 14, 11, 8, 4, 2, 1};
+#include <stdlib.h>
+
+static int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+struct NwKf { int nw, kf; };
+// (waves per block, fragments per wave) combinations that are instantiated, in preference order
+static const NwKf kCombos[] = {{8, 16}, {8, 14}, {8, 11}, {8, 8}, {4, 16}, {4, 14}, {4, 11}, {8, 4}, {4, 8},
+                               {8, 2}, {4, 4}, {2, 11}, {8, 1}, {4, 2}, {2, 8}, {2, 4}, {4, 1}, {2, 2}, {2, 1}, {1, 1}};
 
 int gemv_plan(int K, bool allow_ksplit, GemvPlan *p) {
     if (K <= 0 || (K & 31)) return -1;
     const int KFtot = K >> 5;
-    // prefer many waves per block (deep load queues), then big KF, then a K split for long K
-    int best_score = -1;
-    for (int nw = 16; nw >= 1; nw >>= 1) {
-        for (int kf : kKFSet) {
-            if (KFtot % (nw * kf)) continue;
-            const int ks = KFtot / (nw * kf);
-            if (ks > 1 && !allow_ksplit) continue;
-            if (ks > 16) continue;
-            // score: 8 waves x KF in [8,16] is the sweet spot measured for K=4096/14336
-            int score = 0;
-            score += (nw == 8) ? 40 : (nw == 4 ? 25 : (nw == 16 ? 20 : (nw == 2 ? 10 : 0)));
-            score += (kf >= 8) ? 30 + kf : kf;
-            score -= 3 * (ks - 1);
-            if (score > best_score) {
-                best_score = score;
-                p->NW = nw; p->KF = kf; p->ksplit = ks;
-            }
-        }
+    const int force_nw = env_int("VLO_GEMV_NW", 0), force_kf = env_int("VLO_GEMV_KF", 0);
+    for (const NwKf &c : kCombos) {
+        if (force_nw && c.nw != force_nw) continue;
+        if (force_kf && c.kf != force_kf) continue;
+        if (KFtot % (c.nw * c.kf)) continue;
+        const int ks = KFtot / (c.nw * c.kf);
+        if (ks > 1 && !allow_ksplit) continue;
+        if (ks > 16) continue;
+        p->NW = c.nw; p->KF = c.kf; p->ksplit = ks;
+        return 0;
     }
-    return best_score < 0 ? -1 : 0;
+    return -1;
 }
 
-template <int EPI>
-static hipError_t launch_kf(const GemvArgs &a, const GemvPlan &p, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-    switch (p.KF) {
-#define VLO_CASE(KF_) \
-    case KF_: hipLaunchKernelGGL((gemv16_kernel<KF_, EPI>), grid, block, lds, st, a); break;
-        VLO_CASE(16) VLO_CASE(14) VLO_CASE(11) VLO_CASE(8) VLO_CASE(4) VLO_CASE(2) VLO_CASE(1)
-#undef VLO_CASE
+template <int KF, int NW>
+static hipError_t launch_epi(const GemvArgs &a, int epi, dim3 grid, size_t lds, hipStream_t st) {
+    dim3 block(NW * 64);
+    switch (epi) {
+    case EPI_PARTIAL_F32: hipLaunchKernelGGL((gemv16_kernel<KF, NW, EPI_PARTIAL_F32>), grid, block, lds, st, a); break;
+    case EPI_BF16: hipLaunchKernelGGL((gemv16_kernel<KF, NW, EPI_BF16>), grid, block, lds, st, a); break;
+    case EPI_BF16_GELU_ERF: hipLaunchKernelGGL((gemv16_kernel<KF, NW, EPI_BF16_GELU_ERF>), grid, block, lds, st, a); break;
+    case EPI_SWIGLU: hipLaunchKernelGGL((gemv16_kernel<KF, NW, EPI_SWIGLU>), grid, block, lds, st, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
 hipError_t gemv_launch(GemvArgs a, const GemvPlan &p, int epi, hipStream_t st) {
-    // CT: column tiles per block — aim at ~4 blocks per CU worth of blocks, cap LDS at 64 KiB
-    int ct = a.CT;
-    if (ct <= 0) {
-        const int target_blocks = 1024;
-        ct = (a.NT * p.ksplit + target_blocks - 1) / target_blocks;
-        if (ct < 1) ct = 1;
-        const int ct_max = 32 / p.NW > 0 ? 32 / p.NW : 1;      // NW*CT KiB of LDS (<= 32 KiB)
-        if (ct > ct_max) ct = ct_max;
-        if (epi == EPI_SWIGLU) ct = (ct + 1) & ~1;
-    }
-    a.CT = ct;
-    dim3 grid((a.NT + ct - 1) / ct, p.ksplit), block(p.NW * 64);
-    const size_t lds = (size_t)p.NW * ct * 64 * sizeof(float4);
-    switch (epi) {
-    case EPI_PARTIAL_F32: return launch_kf<EPI_PARTIAL_F32>(a, p, grid, block, lds, st);
-    case EPI_BF16: return launch_kf<EPI_BF16>(a, p, grid, block, lds, st);
-    case EPI_BF16_GELU_ERF: return launch_kf<EPI_BF16_GELU_ERF>(a, p, grid, block, lds, st);
-    case EPI_SWIGLU: return launch_kf<EPI_SWIGLU>(a, p, grid, block, lds, st);
-    }
+    static const int kCTG = env_int("VLO_GEMV_CTG", 2);
+    static const int kBPC = env_int("VLO_GEMV_BPC", 1);          // resident blocks per CU aimed at
+    static const int kCUs = 256;
+    int ctg = a.CT > 0 ? a.CT : kCTG;
+    if (epi == EPI_SWIGLU) ctg = (ctg + 1) & ~1;
+    a.CT = ctg;
+    const int ngroups = (a.NT + ctg - 1) / ctg;
+    int gx = (kCUs * kBPC) / p.ksplit;
+    if (gx < 1) gx = 1;
+    if (gx > ngroups) gx = ngroups;
+    // balance: every block should get the same number of groups where possible
+    const int per = (ngroups + gx - 1) / gx;
+    gx = (ngroups + per - 1) / per;
+    dim3 grid(gx, p.ksplit);
+    const size_t lds = (size_t)2 * p.NW * ctg * 64 * sizeof(float4);
+#define VLO_CASE(NW_, KF_) \
+    if (p.NW == NW_ && p.KF == KF_) return launch_epi<KF_, NW_>(a, epi, grid, lds, st);
+    VLO_CASE(8, 16) VLO_CASE(8, 14) VLO_CASE(8, 11) VLO_CASE(8, 8) VLO_CASE(4, 16) VLO_CASE(4, 14) VLO_CASE(4, 11)
+    VLO_CASE(8, 4) VLO_CASE(4, 8) VLO_CASE(8, 2) VLO_CASE(4, 4) VLO_CASE(2, 11) VLO_CASE(8, 1) VLO_CASE(4, 2)
+    VLO_CASE(2, 8) VLO_CASE(2, 4) VLO_CASE(4, 1) VLO_CASE(2, 2) VLO_CASE(2, 1) VLO_CASE(1, 1)
+#undef VLO_CASE
     return hipErrorInvalidValue;
 }
 

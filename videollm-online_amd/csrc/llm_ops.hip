@@ -20,8 +20,8 @@
 // ------------------------------------------------------------------------------------
 // residual add + RMSNorm.  One block per token row.
 // ------------------------------------------------------------------------------------
-#define RMS_THREADS 256
-#define RMS_MAXCH 4   // supports H <= 8 * 256 * 4 = 8192
+#define RMS_THREADS 512
+#define RMS_MAXCH 2   // supports H <= 8 * 512 * 2 = 8192
 
 __global__ __launch_bounds__(RMS_THREADS) void add_rmsnorm_kernel(bf16_t *__restrict__ h, const float *__restrict__ partial,
                                                                   int ksplit, int partial_ld, const bf16_t *__restrict__ w,

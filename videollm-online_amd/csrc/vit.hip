@@ -32,6 +32,7 @@ struct GemmArgs {
     float *out32;              // EP_RESID / EP_PATCH: residual stream [M][N];  EP_F32: [M][ldo]
     const float *pos;          // EP_PATCH: [S][N]
     int M, N, K, ldx, ldo;
+    int ksplit;                // EP_RESID only: K slices (grid.z), partial sums are atomically added into out32
     int S, R, P, G;            // tokens per frame, resolution, patch size, grid (EP_PATCH / EP_QKV)
     int D, hd;                 // EP_QKV: hidden size, head dim
 };
@@ -113,13 +114,15 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = a.K / GEMM_BK;
-    load_tile(0);
+    const int nk_all = a.K / GEMM_BK;
+    const int nk = (EP == EP_RESID && a.ksplit > 1) ? nk_all / a.ksplit : nk_all;
+    const int kbeg = (EP == EP_RESID && a.ksplit > 1) ? blockIdx.z * nk * GEMM_BK : 0;
+    load_tile(kbeg);
     store_tile(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile((kt + 1) * GEMM_BK);
+        if (kt + 1 < nk) load_tile(kbeg + (kt + 1) * GEMM_BK);
 #pragma unroll
         for (int kk = 0; kk < GEMM_BK / 32; ++kk) {
             frag_ab fx[MI], fw[NI];
@@ -166,10 +169,18 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs a) {
             } else if (EP == EP_F32) {
                 *reinterpret_cast<float4 *>(a.out32 + (size_t)m * a.ldo + n) = make_float4(rh(v[0]), rh(v[1]), rh(v[2]), rh(v[3]));
             } else if (EP == EP_RESID) {
-                float4 *hp = reinterpret_cast<float4 *>(a.out32 + (size_t)m * a.N + n);
-                float4 hv = *hp;
-                hv.x += rh(v[0]); hv.y += rh(v[1]); hv.z += rh(v[2]); hv.w += rh(v[3]);
-                *hp = hv;
+                float *hp = a.out32 + (size_t)m * a.N + n;
+                if (a.ksplit > 1) {
+                    // split-K: K-slice partial sums go straight into the fp32 residual stream (bias once);
+                    // skips the fp16 rounding of the Linear output, i.e. errs toward the fp32 reference
+                    const bool first = blockIdx.z == 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) atomicAdd(hp + r, first ? v[r] : acc[i][j][r]);
+                } else {
+                    float4 hv = *reinterpret_cast<float4 *>(hp);
+                    hv.x += rh(v[0]); hv.y += rh(v[1]); hv.z += rh(v[2]); hv.w += rh(v[3]);
+                    *reinterpret_cast<float4 *>(hp) = hv;
+                }
             } else if (EP == EP_PATCH) {
                 const float4 pv = *reinterpret_cast<const float4 *>(a.pos + (size_t)(m % a.S) * a.N + n);
                 *reinterpret_cast<float4 *>(a.out32 + (size_t)m * a.N + n) =
@@ -192,13 +203,21 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs a) {
 }
 
 template <int EP>
-static hipError_t gemm_launch(const GemmArgs &a, hipStream_t st) {
+static hipError_t gemm_launch(GemmArgs a, hipStream_t st) {
     if (a.K % GEMM_BK || (a.N & 3)) return hipErrorInvalidValue;
+    int ks = 1;
+    if (EP == EP_RESID) {
+        // few (M/64 x N/64) tiles at one frame: slice K until ~2 blocks per CU exist
+        const int tiles = ((a.N + 63) / 64) * ((a.M + 63) / 64);
+        const int nk = a.K / GEMM_BK;
+        while (ks < 8 && tiles * ks < 512 && nk % (ks * 2) == 0 && nk / (ks * 2) >= 4) ks *= 2;
+    }
+    a.ksplit = ks;
     if (a.M <= 32) {
-        dim3 grid((a.N + 63) / 64, (a.M + 31) / 32);
+        dim3 grid((a.N + 63) / 64, (a.M + 31) / 32, ks);
         hipLaunchKernelGGL((vit_gemm_kernel<32, 64, EP>), grid, dim3(256), 0, st, a);
     } else {
-        dim3 grid((a.N + 63) / 64, (a.M + 63) / 64);
+        dim3 grid((a.N + 63) / 64, (a.M + 63) / 64, ks);
         hipLaunchKernelGGL((vit_gemm_kernel<64, 64, EP>), grid, dim3(256), 0, st, a);
     }
     return hipGetLastError();
@@ -244,36 +263,50 @@ __global__ __launch_bounds__(256) void vit_layernorm_kernel(const float *__restr
 }
 
 // ------------------------------------------------------------------------------------
-// non-causal MHSA, hd = 64.  grid = (S/64 q-tiles, heads, B); 4 waves x 16 query rows.
-// Same operand scheme as the Llama chunk attention (llm_ops.hip): K rows and V^T rows are MFMA
-// A operands read straight from global/L2, P^T never leaves the lanes that computed it.
+// non-causal MHSA, hd = 64.  grid = (ceil(S/64) q-tiles, heads, B); 4 waves.
+// Every wave owns ALL 64 query rows of the block (4 sub-tiles of 16) and an interleaved quarter of
+// the key blocks (flash-decoding inside the block): K / V^T fragments fetched once per 32 keys feed
+// 32 MFMAs instead of 8, each wave runs ceil(S/128) iterations instead of S/32, and the four
+// partial (m, l, O) states are merged through LDS.  Operand scheme as in llm_ops.hip:
+//   S^T[key][q] = K[key][:].Q[q][:]   (K rows = MFMA A operand straight from global/L2)
+//   O^T[d][q]  += V^T[d][key].P^T[key][q]   (V^T rows = A operand; P^T stays in the producing lanes)
 // ------------------------------------------------------------------------------------
 template <int HD>
 __global__ __launch_bounds__(256) void vit_attn_kernel(const f16_t *__restrict__ qk, const f16_t *__restrict__ vT,
                                                        f16_t *__restrict__ out, int S, int D, int nheads, float scale) {
-    constexpr int NKK = HD / 32, NDT = HD / 16;
+    constexpr int NKK = HD / 32, NDT = HD / 16, QS = 4;
+    extern __shared__ __attribute__((aligned(16))) float4 lds4[];     // [4 waves][QS][NDT][64] O partials, then m/l
+    float *lds_ml = reinterpret_cast<float *>(lds4 + 4 * QS * NDT * 64);   // [4][QS][16][2]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int qrow = lane & 15, qd = lane >> 4;
     const int head = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 64 + w * 16;
+    const int q0 = blockIdx.x * 64;
     const size_t ld = (size_t)2 * D;
     const f16_t *qbase = qk + (size_t)b * S * ld + (size_t)head * HD;
     const f16_t *kbase = qbase + D;
     const f16_t *vbase = vT + ((size_t)b * nheads + head) * HD * S;
 
-    frag_ab qf[NKK];
+    frag_ab qf[QS][NKK];
 #pragma unroll
-    for (int kk = 0; kk < NKK; ++kk) {
-        frag_ab z = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (q0 + qrow < S) z = *reinterpret_cast<const frag_ab *>(qbase + (size_t)(q0 + qrow) * ld + kk * 32 + qd * 8);
-        qf[kk] = z;
+    for (int qs = 0; qs < QS; ++qs)
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            frag_ab z = {0, 0, 0, 0, 0, 0, 0, 0};
+            const int r = q0 + qs * 16 + qrow;
+            if (r < S) z = *reinterpret_cast<const frag_ab *>(qbase + (size_t)r * ld + kk * 32 + qd * 8);
+            qf[qs][kk] = z;
+        }
+    f32x4 O[QS][NDT];
+    float mrun[QS], lrun[QS];
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs) {
+        mrun[qs] = -INFINITY;
+        lrun[qs] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) O[qs][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    f32x4 O[NDT];
-#pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) O[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float mrun = -INFINITY, lrun = 0.f;
 
-    for (int kt0 = 0; kt0 < S; kt0 += 32) {
+    for (int kt0 = w * 32; kt0 < S; kt0 += 128) {
         frag_ab kf[2][NKK];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -282,58 +315,99 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const f16_t *__restrict__
             for (int kk = 0; kk < NKK; ++kk)
                 kf[t][kk] = *reinterpret_cast<const frag_ab *>(kbase + (size_t)key * ld + kk * 32 + qd * 8);
         }
-        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) {
-            s0 = mfma_f16(kf[0][kk], qf[kk], s0);
-            s1 = mfma_f16(kf[1][kk], qf[kk], s1);
-        }
-        const int kb = kt0 + qd * 4;
-        float v[8];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            v[r] = (kb + r < S) ? s0[r] * scale : -INFINITY;
-            v[4 + r] = (kb + 16 + r < S) ? s1[r] * scale : -INFINITY;
-        }
-        float tmax = v[0];
-#pragma unroll
-        for (int j = 1; j < 8; ++j) tmax = fmaxf(tmax, v[j]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(mrun, tmax);
-        const float alpha = __expf(mrun - m_new);
-        mrun = m_new;
-        float psum = 0.f;
-        frag_ab pb;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float p = __expf(v[j] - m_new);
-            psum += p;
-            pb[j] = (short)f2h(p);
-        }
-        lrun = lrun * alpha + psum;
+        frag_ab vf[NDT];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
             const f16_t *vr = vbase + (size_t)(dt * 16 + qrow) * S + kt0 + qd * 4;
             uint2 lo = make_uint2(0, 0), hi = make_uint2(0, 0);
             if (kt0 + qd * 4 < S) lo = *reinterpret_cast<const uint2 *>(vr);
             if (kt0 + 16 + qd * 4 < S) hi = *reinterpret_cast<const uint2 *>(vr + 16);
-            const uint4 pk = make_uint4(lo.x, lo.y, hi.x, hi.y);
-            f32x4 o = O[dt];
-            o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
-            O[dt] = mfma_f16(__builtin_bit_cast(frag_ab, pk), pb, o);
+            vf[dt] = __builtin_bit_cast(frag_ab, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        }
+        const int kb = kt0 + qd * 4;
+#pragma unroll
+        for (int qs = 0; qs < QS; ++qs) {
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                s0 = mfma_f16(kf[0][kk], qf[qs][kk], s0);
+                s1 = mfma_f16(kf[1][kk], qf[qs][kk], s1);
+            }
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = (kb + r < S) ? s0[r] * scale : -INFINITY;
+                v[4 + r] = (kb + 16 + r < S) ? s1[r] * scale : -INFINITY;
+            }
+            float tmax = v[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) tmax = fmaxf(tmax, v[j]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(mrun[qs], tmax);          // finite: every 32-key block holds >= 1 valid key
+            const float alpha = __expf(mrun[qs] - m_new);
+            mrun[qs] = m_new;
+            float psum = 0.f;
+            frag_ab pb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float p = __expf(v[j] - m_new);
+                psum += p;
+                pb[j] = (short)f2h(p);
+            }
+            lrun[qs] = lrun[qs] * alpha + psum;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                f32x4 o = O[qs][dt];
+                o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
+                O[qs][dt] = mfma_f16(vf[dt], pb, o);
+            }
         }
     }
-    lrun += __shfl_xor(lrun, 16, 64);
-    lrun += __shfl_xor(lrun, 32, 64);
-    if (q0 + qrow < S) {
-        const float inv = 1.0f / lrun;
-        f16_t *orow = out + ((size_t)b * S + q0 + qrow) * D + (size_t)head * HD;
+    // publish this wave's partial state
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs) {
+        float l = lrun[qs];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (qd == 0) {
+            lds_ml[((w * QS + qs) * 16 + qrow) * 2] = mrun[qs];
+            lds_ml[((w * QS + qs) * 16 + qrow) * 2 + 1] = l;
+        }
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
-            ushort4 o;
-            o.x = f2h(O[dt][0] * inv); o.y = f2h(O[dt][1] * inv); o.z = f2h(O[dt][2] * inv); o.w = f2h(O[dt][3] * inv);
-            *reinterpret_cast<ushort4 *>(orow + dt * 16 + qd * 4) = o;
+            const f32x4 o = O[qs][dt];
+            lds4[((w * QS + qs) * NDT + dt) * 64 + lane] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    __syncthreads();
+    // wave w finalises query sub-tile w
+    const int qs = w;
+    const int r = q0 + qs * 16 + qrow;
+    float M = -INFINITY;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) M = fmaxf(M, lds_ml[((ww * QS + qs) * 16 + qrow) * 2]);
+    float wgt[4], Lsum = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) {
+        const float ms = lds_ml[((ww * QS + qs) * 16 + qrow) * 2];
+        wgt[ww] = (ms == -INFINITY) ? 0.f : __expf(ms - M);
+        Lsum += lds_ml[((ww * QS + qs) * 16 + qrow) * 2 + 1] * wgt[ww];
+    }
+    if (r < S) {
+        const float inv = 1.0f / Lsum;
+        f16_t *orow = out + ((size_t)b * S + r) * D + (size_t)head * HD;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) {
+                const float4 o = lds4[((ww * QS + qs) * NDT + dt) * 64 + lane];
+                acc.x += o.x * wgt[ww]; acc.y += o.y * wgt[ww]; acc.z += o.z * wgt[ww]; acc.w += o.w * wgt[ww];
+            }
+            ushort4 o16;
+            o16.x = f2h(acc.x * inv); o16.y = f2h(acc.y * inv); o16.z = f2h(acc.z * inv); o16.w = f2h(acc.w * inv);
+            *reinterpret_cast<ushort4 *>(orow + dt * 16 + qd * 4) = o16;
         }
     }
 }
@@ -414,6 +488,8 @@ __global__ void f16_to_f32_kernel(const f16_t *__restrict__ a, float *__restrict
 // ------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------
+static const size_t kAttnLds = (size_t)4 * 4 * 4 * 64 * 16 + 4 * 4 * 16 * 2 * 4;     // O partials + (m, l)
+
 struct VitLayer {
     const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
     f16_t *wqkv;
@@ -539,6 +615,7 @@ int vit_finalize(vlo_engine *e) {
         VIT_TRY(hipDeviceSynchronize());
     }
 #undef TK
+    VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnLds));
     e->vit = v;
     return VLO_OK;
 }
@@ -597,7 +674,7 @@ int vit_visual_embed(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_
             a.M = M; a.N = 3 * D; a.K = D; a.ldx = D; a.ldo = 2 * D; a.S = S; a.D = D; a.hd = v->hd;
             VIT_TRY(gemm_launch<EP_QKV>(a, st));
         }
-        hipLaunchKernelGGL((vit_attn_kernel<64>), dim3((S + 63) / 64, v->nh, B), dim3(256), 0, st, v->qk16, v->vT, v->att16, S, D, v->nh, scale);
+        hipLaunchKernelGGL((vit_attn_kernel<64>), dim3((S + 63) / 64, v->nh, B), dim3(256), kAttnLds, st, v->qk16, v->vT, v->att16, S, D, v->nh, scale);
         {
             GemmArgs a{};
             a.X = v->att16; a.W = Ly.wo; a.bias = Ly.bo; a.out32 = v->h;
