@@ -130,6 +130,21 @@ def gpu_synthetic_frames(num_frames, res=384, seed=1234):
     return (base + grad[:, None]).clamp_(0, 255).to(torch.uint8)
 
 
+def reduce_elapsed_max(dist, elapsed, device="cuda"):
+    """max-over-ranks wall time: the job is as slow as its slowest replica."""
+    import torch
+    if dist is None:
+        return elapsed
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def aggregate_fps(frames_per_rank, world, elapsed_max):
+    """whole-job frames/s: every rank streams ``frames_per_rank`` frames (weak scaling)."""
+    return frames_per_rank * world / elapsed_max
+
+
 def make_schedule(mode):
     if mode == "scheduled":
         return lambda i: (i % 10 == 9, 16)
@@ -296,12 +311,8 @@ def main():
     eng.profile_enable(0)
     final_len = len(li.past_key_values)
 
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    total_frames = K * world
-    fps = total_frames / elapsed
+    elapsed = reduce_elapsed_max(dist, elapsed)
+    fps = aggregate_fps(K, world, elapsed)
 
     out = None
     if rank == 0:

@@ -1,0 +1,53 @@
+"""N>1 path of bench.py on CPU: world_size-2 gloo, barrier + max-over-ranks timing, replica aggregation."""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    dist.barrier()
+    elapsed = 1.0 + rank           # rank 1 is the slow replica
+    mx = bench.reduce_elapsed_max(dist, elapsed, device="cpu")
+    dist.barrier()
+    q.put((rank, mx, bench.aggregate_fps(100, world, mx)))
+    dist.destroy_process_group()
+
+
+def test_replica_timing_reduction_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    for rank, mx, fps in res:
+        assert mx == 2.0                      # every rank sees the slowest replica's time
+        assert fps == 100 * world / 2.0       # whole-job aggregate, not per-GPU
+
+
+def test_single_process_passthrough():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.reduce_elapsed_max(None, 3.5) == 3.5
+    assert bench.aggregate_fps(1200, 1, 12.0) == 100.0
+    assert bench.usable_cores() >= 1
