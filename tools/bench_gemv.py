@@ -5,7 +5,7 @@ import torch
 from videollm_online_amd import _C
 L = _C.lib()
 torch.zeros(1, device="cuda")
-SHAPES = [("qkv", 6144, 4096, 0), ("o", 4096, 4096, 0), ("gate_up", 28672, 4096, 3), ("down", 4096, 14336, 0), ("lm_head", 128256, 4096, 1)]
+SHAPES = [("qkv", 6144, 4096, 5), ("o", 4096, 4096, 4), ("gate_up", 28672, 4096, 3), ("down", 4096, 14336, 4), ("lm_head", 128256, 4096, 1)]   # epi: 5 rope, 4 resid, 3 swiglu, 1 bf16
 tot_us = 0
 for name, N, K, epi in SHAPES:
     nbuf = max(2, int(1.2e9 // (N * K * 2)) + 1)

@@ -72,8 +72,8 @@ struct vlo_session {
     std::vector<int> pages;
     std::vector<void *> owned;
     unsigned short *h = nullptr, *x = nullptr, *act = nullptr, *attn = nullptr, *q = nullptr, *emb1 = nullptr;
-    float *partial = nullptr, *partial2 = nullptr, *part_o = nullptr, *part_ml = nullptr;
-    int partial_ld = 0;
+    float *part_o = nullptr, *part_ml = nullptr;
+    float *sq[2] = {nullptr, nullptr};          // row sum-of-squares partials handed from EPI_RESID to XSRC_NORM
     unsigned short *logits = nullptr, *last_logits = nullptr;
     int64_t *tok = nullptr;
     int64_t *host_tok = nullptr;

@@ -215,17 +215,17 @@ int vlo_engine_finalize(vlo_engine *e) {
     for (int l = 0; l < c.num_layers; ++l) {
         LayerWeights &L = e->layers[l];
         const std::string p = "model.layers." + std::to_string(l) + ".";
-        if ((rc = make_linear(e, &L.qkv, Nqkv, H, true))) return rc;
+        if ((rc = make_linear(e, &L.qkv, Nqkv, H, false))) return rc;
         if ((rc = pack_into(e, p + "self_attn.q_proj.weight", Nq, H, L.qkv.Wp, 1, 0))) return rc;
         if ((rc = pack_into(e, p + "self_attn.k_proj.weight", Nkv, H, L.qkv.Wp, 1, Nq / 16))) return rc;
         if ((rc = pack_into(e, p + "self_attn.v_proj.weight", Nkv, H, L.qkv.Wp, 1, (Nq + Nkv) / 16))) return rc;
-        if ((rc = make_linear(e, &L.o, H, Nq, true))) return rc;
+        if ((rc = make_linear(e, &L.o, H, Nq, false))) return rc;
         if ((rc = pack_into(e, p + "self_attn.o_proj.weight", H, Nq, L.o.Wp, 1, 0))) return rc;
         if ((rc = make_linear(e, &L.gate_up, 2 * I, H, false))) return rc;       // SwiGLU epilogue needs whole K
         if (I % 16) return fail(VLO_E_UNSUPPORTED, "intermediate_size must be a multiple of 16");
         if ((rc = pack_into(e, p + "mlp.gate_proj.weight", I, H, L.gate_up.Wp, 2, 0))) return rc;
         if ((rc = pack_into(e, p + "mlp.up_proj.weight", I, H, L.gate_up.Wp, 2, 1))) return rc;
-        if ((rc = make_linear(e, &L.down, H, I, true))) return rc;
+        if ((rc = make_linear(e, &L.down, H, I, false))) return rc;
         if ((rc = pack_into(e, p + "mlp.down_proj.weight", H, I, L.down.Wp, 1, 0))) return rc;
         if ((rc = take_vec(e, p + "input_layernorm.weight", H, &L.ln_in))) return rc;
         if ((rc = take_vec(e, p + "post_attention_layernorm.weight", H, &L.ln_post))) return rc;
@@ -354,13 +354,9 @@ int vlo_session_create(vlo_engine *e, int64_t max_tokens_hint, vlo_session **out
     A((void **)&s->act, (size_t)32 * I * 2);
     A((void **)&s->attn, (size_t)32 * nh * hd * 2);
     A((void **)&s->q, (size_t)16 * nh * hd * 2);
-    int ksmax = 1;
-    for (auto &L : e->layers) {
-        ksmax = std::max(ksmax, std::max(L.qkv.plan.ksplit, std::max(L.o.plan.ksplit, L.down.plan.ksplit)));
-    }
-    s->partial_ld = std::max(Nqkv, H);
-    A((void **)&s->partial, (size_t)ksmax * 16 * s->partial_ld * 4);
-    A((void **)&s->partial2, (size_t)ksmax * 16 * s->partial_ld * 4);
+    (void)Nqkv;
+    A((void **)&s->sq[0], (size_t)(512 + 16) * 16 * 4);      // row sum-of-squares partials: [gemv grid.x <= 512][16] (+ row offset slack)
+    A((void **)&s->sq[1], (size_t)(512 + 16) * 16 * 4);
     A((void **)&s->part_o, (size_t)VLO_MAX_SPLITS * nh * 16 * hd * 4);
     A((void **)&s->part_ml, (size_t)VLO_MAX_SPLITS * nh * 16 * 2 * 4);
     A((void **)&s->logits, (size_t)16 * c.vocab_size * 2);
@@ -437,25 +433,6 @@ static KvGeom kv_geom(const vlo_session *s) {
     return g;
 }
 
-static int run_gemv(const PackedLinear &pl, const unsigned short *x, int ldx, int n_rows, int epi, float *out_f32,
-                    unsigned short *out_bf16, int ldo, const void *bias, hipStream_t st) {
-    GemvArgs a;
-    a.Wp = pl.Wp;
-    a.x = x;
-    a.out_f32 = out_f32;
-    a.out_bf16 = out_bf16;
-    a.bias = (const unsigned short *)bias;
-    a.K = pl.K;
-    a.ldx = ldx;
-    a.ldo = ldo;
-    a.NT = pl.NT;
-    a.N_valid = pl.N;
-    a.n_rows = n_rows;
-    a.CT = 0;
-    HIP_TRY(gemv_launch(a, pl.plan, epi, st));
-    return VLO_OK;
-}
-
 // ---- live timing of the dominant kernel -------------------------------------------------
 static void prof_flush(vlo_engine *e) {
     for (size_t i = 0; i < e->prof_used; ++i) {
@@ -498,55 +475,82 @@ int vlo_profile_read(vlo_engine *e, int64_t *launches, double *total_ms, double 
     if (launches) *launches = e->prof_launches;
     if (total_ms) *total_ms = e->prof_ms;
     if (bytes_per_launch) {
-        // gate+up weights [2I][H] bf16 streamed once + x [n<=16][H] in + act [n][I] out (n = 11 nominal)
+        // gate+up weights [2I][H] bf16 streamed once + h [n<=16][H] in + act [n][I] out (n = 11 nominal)
         const double H = e->cfg.hidden_size, I = e->cfg.intermediate_size;
         *bytes_per_launch = 2.0 * I * H * 2.0 + 11.0 * H * 2.0 + 11.0 * I * 2.0;
     }
     return VLO_OK;
 }
 
-// one chunk of m <= 16 new tokens whose embeddings are already in s->h
-static int run_chunk(vlo_session *s, int m, bool want_last, bool want_all, hipStream_t st) {
+static GemvArgs gemv_args(const PackedLinear &pl, const unsigned short *x, int ldx, int n_rows) {
+    GemvArgs a{};
+    a.Wp = pl.Wp;
+    a.x = x;
+    a.K = pl.K;
+    a.ldx = ldx;
+    a.NT = pl.NT;
+    a.N_valid = pl.N;
+    a.n_rows = n_rows;
+    return a;
+}
+
+// one chunk of m <= 16 new tokens whose embeddings are at `src`
+//   per layer:  qkv GEMV [RMSNorm on load | RoPE + KV append epilogue] -> attention -> combine ->
+//               o GEMV [residual + sum-of-squares epilogue] -> gate/up GEMV [RMSNorm on load | SwiGLU] ->
+//               down GEMV [residual + sum-of-squares epilogue]
+static int run_chunk(vlo_session *s, const unsigned short *src, int m, bool want_last, bool want_all, hipStream_t st) {
     vlo_engine *e = s->e;
     const vlo_config &c = e->cfg;
-    const int H = c.hidden_size, I = c.intermediate_size, hd = e->head_dim, nh = c.num_heads, nkv = c.num_kv_heads;
-    const int Nqkv = (nh + 2 * nkv) * hd;
+    const int H = c.hidden_size, I = c.intermediate_size, hd = e->head_dim, nh = c.num_heads;
     int rc;
     if ((rc = ensure_pages(s, s->len + m, st))) return rc;
     const KvGeom kv = kv_geom(s);
-    const float *prev = nullptr;
-    int prev_ks = 0;
+    HIP_TRY(prep_rows_launch(src, s->h, s->sq[1], m, H, st));
+    const float *sq_in = s->sq[1];
+    int sq_parts = 1;
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerWeights &L = e->layers[l];
-        HIP_TRY(add_rmsnorm_launch(s->h, prev, prev_ks, s->partial_ld, (const unsigned short *)L.ln_in, s->x, H, H, c.rms_eps, m, st));
-        if ((rc = run_gemv(L.qkv, s->x, H, m, EPI_PARTIAL_F32, s->partial, nullptr, s->partial_ld, nullptr, st))) return rc;
-        HIP_TRY(rope_kv_append_launch(s->partial, L.qkv.plan.ksplit, s->partial_ld, s->q, (const unsigned short *)e->cos_tab,
-                                      (const unsigned short *)e->sin_tab, kv, l, nh, s->len, m, st));
+        {   // qkv
+            GemvArgs a = gemv_args(L.qkv, s->h, H, m);
+            a.norm_w = (const unsigned short *)L.ln_in; a.sq_in = sq_in; a.sq_in_parts = sq_parts; a.eps = c.rms_eps;
+            a.out_bf16 = s->q; a.cos_tab = (const unsigned short *)e->cos_tab; a.sin_tab = (const unsigned short *)e->sin_tab;
+            a.kv = kv; a.layer = l; a.num_heads = nh; a.pos0 = s->len;
+            HIP_TRY(gemv_launch(a, L.qkv.plan, XSRC_NORM, EPI_ROPE, st));
+        }
         HIP_TRY(attention_launch(s->q, kv, l, nh, s->len, m, s->part_o, s->part_ml, s->attn, st));
-        if ((rc = run_gemv(L.o, s->attn, nh * hd, m, EPI_PARTIAL_F32, s->partial, nullptr, s->partial_ld, nullptr, st))) return rc;
-        HIP_TRY(add_rmsnorm_launch(s->h, s->partial, L.o.plan.ksplit, s->partial_ld, (const unsigned short *)L.ln_post, s->x, H, H,
-                                   c.rms_eps, m, st));
-        {
+        {   // o_proj + residual
+            GemvArgs a = gemv_args(L.o, s->attn, nh * hd, m);
+            a.h = s->h; a.ldo = H; a.sq_out = s->sq[0];
+            sq_parts = gemv_grid_x(a, L.o.plan, EPI_RESID);
+            HIP_TRY(gemv_launch(a, L.o.plan, XSRC_PLAIN, EPI_RESID, st));
+            sq_in = s->sq[0];
+        }
+        {   // gate/up + SwiGLU
             hipEvent_t ev0 = nullptr, ev1 = nullptr;
             if (e->prof_stride > 0 && (e->prof_seen++ % e->prof_stride) == 0) prof_acquire(e, &ev0, &ev1);
+            GemvArgs a = gemv_args(L.gate_up, s->h, H, m);
+            a.norm_w = (const unsigned short *)L.ln_post; a.sq_in = sq_in; a.sq_in_parts = sq_parts; a.eps = c.rms_eps;
+            a.out_bf16 = s->act; a.ldo = I;
             if (ev0) hipEventRecord(ev0, st);
-            if ((rc = run_gemv(L.gate_up, s->x, H, m, EPI_SWIGLU, nullptr, s->act, I, nullptr, st))) return rc;
+            HIP_TRY(gemv_launch(a, L.gate_up.plan, XSRC_NORM, EPI_SWIGLU, st));
             if (ev1) hipEventRecord(ev1, st);
         }
-        if ((rc = run_gemv(L.down, s->act, I, m, EPI_PARTIAL_F32, s->partial2, nullptr, s->partial_ld, nullptr, st))) return rc;
-        prev = s->partial2;
-        prev_ks = L.down.plan.ksplit;
+        {   // down_proj + residual
+            GemvArgs a = gemv_args(L.down, s->act, I, m);
+            a.h = s->h; a.ldo = H; a.sq_out = s->sq[1];
+            sq_parts = gemv_grid_x(a, L.down.plan, EPI_RESID);
+            HIP_TRY(gemv_launch(a, L.down.plan, XSRC_PLAIN, EPI_RESID, st));
+            sq_in = s->sq[1];
+        }
     }
     if (want_last || want_all) {
-        HIP_TRY(add_rmsnorm_launch(s->h, prev, prev_ks, s->partial_ld, (const unsigned short *)e->norm_w, s->x, H, H, c.rms_eps, m, st));
-        if (want_all) {
-            if ((rc = run_gemv(e->lm_head, s->x, H, m, EPI_BF16, nullptr, s->logits, c.vocab_size, nullptr, st))) return rc;
-            s->last_logits = s->logits + (size_t)(m - 1) * c.vocab_size;
-        } else {
-            if ((rc = run_gemv(e->lm_head, s->x + (size_t)(m - 1) * H, H, 1, EPI_BF16, nullptr, s->logits, c.vocab_size, nullptr, st)))
-                return rc;
-            s->last_logits = s->logits;
-        }
+        // final RMSNorm fused into the lm_head operand load; only the rows that are read
+        const int r0 = want_all ? 0 : m - 1, nr = want_all ? m : 1;
+        GemvArgs a = gemv_args(e->lm_head, s->h + (size_t)r0 * H, H, nr);
+        a.norm_w = (const unsigned short *)e->norm_w; a.sq_in = sq_in + r0; a.sq_in_parts = sq_parts; a.eps = c.rms_eps;
+        a.out_bf16 = s->logits; a.ldo = c.vocab_size;
+        HIP_TRY(gemv_launch(a, e->lm_head.plan, XSRC_NORM, EPI_BF16, st));
+        s->last_logits = s->logits + (size_t)(nr - 1) * c.vocab_size;
         s->has_logits = true;
     }
     s->len += m;
@@ -563,8 +567,7 @@ int vlo_llm_step(vlo_session *s, const void *embeds_dev, int n, void *last_logit
     for (int c0 = 0; c0 < n; c0 += 16) {
         const int m = std::min(16, n - c0);
         const bool last = (c0 + m == n);
-        HIP_TRY(copy_rows_launch((const unsigned short *)embeds_dev + (size_t)c0 * H, s->h, m, H, st));
-        if ((rc = run_chunk(s, m, last, all_logits_dev != nullptr, st))) return rc;
+        if ((rc = run_chunk(s, (const unsigned short *)embeds_dev + (size_t)c0 * H, m, last, all_logits_dev != nullptr, st))) return rc;
         if (all_logits_dev)
             HIP_TRY(hipMemcpyAsync((unsigned short *)all_logits_dev + (size_t)c0 * V, s->logits, (size_t)m * V * 2,
                                    hipMemcpyDeviceToDevice, st));
@@ -638,10 +641,16 @@ int vlo_connector(vlo_engine *e, const void *feats_dev, int rows, void *out_dev,
     for (int r0 = 0; r0 < rows; r0 += 16) {
         const int m = std::min(16, rows - r0);
         HIP_TRY(copy_rows_launch((const unsigned short *)feats_dev + (size_t)r0 * Hv, (unsigned short *)e->conn_x, m, Hv, st));
-        if ((rc = run_gemv(e->conn0, (const unsigned short *)e->conn_x, Hv, m, EPI_BF16_GELU_ERF, nullptr,
-                           (unsigned short *)e->conn_mid, H, e->conn0_b, st))) return rc;
-        if ((rc = run_gemv(e->conn2, (const unsigned short *)e->conn_mid, H, m, EPI_BF16, nullptr,
-                           (unsigned short *)e->conn_out, H, e->conn2_b, st))) return rc;
+        {
+            GemvArgs a = gemv_args(e->conn0, (const unsigned short *)e->conn_x, Hv, m);
+            a.out_bf16 = (unsigned short *)e->conn_mid; a.ldo = H; a.bias = (const unsigned short *)e->conn0_b;
+            HIP_TRY(gemv_launch(a, e->conn0.plan, XSRC_PLAIN, EPI_BF16_GELU_ERF, st));
+        }
+        {
+            GemvArgs a = gemv_args(e->conn2, (const unsigned short *)e->conn_mid, H, m);
+            a.out_bf16 = (unsigned short *)e->conn_out; a.ldo = H; a.bias = (const unsigned short *)e->conn2_b;
+            HIP_TRY(gemv_launch(a, e->conn2.plan, XSRC_PLAIN, EPI_BF16, st));
+        }
         HIP_TRY(copy_rows_launch((const unsigned short *)e->conn_out, (unsigned short *)out_dev + (size_t)r0 * H, m, H, st));
     }
     return VLO_OK;
@@ -677,10 +686,10 @@ int vlo_test_gemv(const void *x_dev, const void *W_dev, float *y_dev, int n, int
     HIP_TRY(hipMemsetAsync(xp, 0, (size_t)32 * K * 2, st));
     HIP_TRY(hipMemcpyAsync(xp, x_dev, (size_t)n * K * 2, hipMemcpyDeviceToDevice, st));
     HIP_TRY(pack_weight_launch(W_dev, Wp, N, K, NT, 1, 0, st));
-    GemvArgs a;
-    a.Wp = Wp; a.x = (const unsigned short *)xp; a.out_f32 = P; a.out_bf16 = nullptr; a.bias = nullptr;
-    a.K = K; a.ldx = K; a.ldo = NT * 16; a.NT = NT; a.N_valid = N; a.n_rows = n; a.CT = 0;
-    HIP_TRY(gemv_launch(a, plan, EPI_PARTIAL_F32, st));
+    GemvArgs a{};
+    a.Wp = Wp; a.x = (const unsigned short *)xp; a.out_f32 = P;
+    a.K = K; a.ldx = K; a.ldo = NT * 16; a.NT = NT; a.N_valid = N; a.n_rows = n;
+    HIP_TRY(gemv_launch(a, plan, XSRC_PLAIN, EPI_PARTIAL_F32, st));
     // partial layout is [ksplit][16][ldo]; y is [n][N]
     {
         // sum into a padded buffer then copy rows (ldo may exceed N)
@@ -705,31 +714,58 @@ int vlo_bench_gemv(int N, int K, int n_rows, int epi, int iters, int nbuf, doubl
     const int NT = (N + 15) / 16;
     const size_t wbytes = (size_t)NT * 16 * K * 2;
     std::vector<void *> Wp(nbuf, nullptr);
-    void *x = nullptr, *o32 = nullptr, *o16 = nullptr;
+    void *x = nullptr, *o32 = nullptr, *o16 = nullptr, *hbuf = nullptr, *sq = nullptr, *nw = nullptr, *tab = nullptr, *kvp = nullptr;
+    int *pt = nullptr;
     for (int i = 0; i < nbuf; ++i) {
         HIP_TRY(hipMalloc(&Wp[i], wbytes));
         HIP_TRY(hipMemset(Wp[i], 0x3c, wbytes));      // 0x3c3c = a small finite bf16
     }
-    HIP_TRY(hipMalloc(&x, (size_t)32 * K * 2));
-    HIP_TRY(hipMemset(x, 0x3c, (size_t)32 * K * 2));
+    const size_t wide = (size_t)std::max(K, NT * 16);
+    HIP_TRY(hipMalloc(&x, 32 * wide * 2));
+    HIP_TRY(hipMemset(x, 0x3c, 32 * wide * 2));
+    HIP_TRY(hipMalloc(&hbuf, 32 * wide * 2));
+    HIP_TRY(hipMemset(hbuf, 0x3c, 32 * wide * 2));
+    HIP_TRY(hipMalloc(&nw, wide * 2));
+    HIP_TRY(hipMemset(nw, 0x3c, wide * 2));
+    HIP_TRY(hipMalloc(&sq, 1024 * 16 * 4));
+    HIP_TRY(hipMemset(sq, 0, 1024 * 16 * 4));
     HIP_TRY(hipMalloc(&o32, (size_t)plan.ksplit * 16 * NT * 16 * 4));
     HIP_TRY(hipMalloc(&o16, (size_t)16 * NT * 16 * 2));
-    GemvArgs a;
-    a.x = (const unsigned short *)x; a.out_f32 = (float *)o32; a.out_bf16 = (unsigned short *)o16; a.bias = nullptr;
-    a.K = K; a.ldx = K; a.ldo = (epi == EPI_SWIGLU) ? NT * 8 : NT * 16; a.NT = NT; a.N_valid = N; a.n_rows = n_rows; a.CT = 0;
+    HIP_TRY(hipMalloc(&tab, (size_t)VLO_PAGE_TOKENS * 64 * 2));
+    HIP_TRY(hipMemset(tab, 0x3c, (size_t)VLO_PAGE_TOKENS * 64 * 2));
+    HIP_TRY(hipMalloc(&kvp, (size_t)NT * 16 * VLO_PAGE_TOKENS * 2));
+    HIP_TRY(hipMalloc((void **)&pt, 64));
+    HIP_TRY(hipMemset(pt, 0, 64));
+    GemvArgs a{};
+    a.x = (const unsigned short *)x; a.out_f32 = (float *)o32; a.out_bf16 = (unsigned short *)o16;
+    a.K = K; a.ldx = K; a.ldo = (epi == EPI_SWIGLU) ? NT * 8 : NT * 16; a.NT = NT; a.N_valid = N; a.n_rows = n_rows;
+    int xsrc = XSRC_PLAIN;
+    if (epi == EPI_SWIGLU || epi == EPI_ROPE || epi == EPI_BF16) {
+        xsrc = XSRC_NORM;
+        a.norm_w = (const unsigned short *)nw; a.sq_in = (const float *)sq; a.sq_in_parts = 128; a.eps = 1e-5f;
+    }
+    if (epi == EPI_RESID) { a.h = (unsigned short *)hbuf; a.sq_out = (float *)sq; }
+    if (epi == EPI_ROPE) {
+        // N = (nh + 2*nkv) * 128 with nkv = nh / 4 (Llama-3 GQA); one page, positions 0..n_rows-1
+        const int heads = N / 128, nkv = heads / 6, nh = heads - 2 * nkv;
+        a.cos_tab = a.sin_tab = (const unsigned short *)tab;
+        a.kv.k_pool = a.kv.vt_pool = (unsigned short *)kvp; a.kv.page_table = pt; a.kv.layer_stride = 0;
+        a.kv.page_elems = (int64_t)nkv * VLO_PAGE_TOKENS * 128; a.kv.num_kv_heads = nkv; a.kv.head_dim = 128;
+        a.layer = 0; a.num_heads = nh; a.pos0 = 0;
+    }
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) { a.Wp = Wp[i % nbuf]; HIP_TRY(gemv_launch(a, plan, epi, 0)); }
+    for (int i = 0; i < 3; ++i) { a.Wp = Wp[i % nbuf]; HIP_TRY(gemv_launch(a, plan, xsrc, epi, 0)); }
     HIP_TRY(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i) { a.Wp = Wp[i % nbuf]; HIP_TRY(gemv_launch(a, plan, epi, 0)); }
+    for (int i = 0; i < iters; ++i) { a.Wp = Wp[i % nbuf]; HIP_TRY(gemv_launch(a, plan, xsrc, epi, 0)); }
     HIP_TRY(hipEventRecord(e1, 0));
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     *avg_us = (double)ms * 1e3 / iters;
     for (void *p : Wp) hipFree(p);
-    hipFree(x); hipFree(o32); hipFree(o16);
+    hipFree(x); hipFree(o32); hipFree(o16); hipFree(hbuf); hipFree(sq); hipFree(nw); hipFree(tab); hipFree(kvp); hipFree(pt);
     hipEventDestroy(e0); hipEventDestroy(e1);
     return VLO_OK;
 }

@@ -3,25 +3,56 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-enum { EPI_PARTIAL_F32 = 0, EPI_BF16 = 1, EPI_BF16_GELU_ERF = 2, EPI_SWIGLU = 3 };
+#include "llm_ops.h"
+
+// epilogues
+enum {
+    EPI_PARTIAL_F32 = 0,     // fp32 split-K partials [ksplit][16][ldo]            (unit tests)
+    EPI_BF16 = 1,            // bf16(acc + bias)                                     (lm_head, connector.2)
+    EPI_BF16_GELU_ERF = 2,   // HF python-GELU on bf16(acc + bias)                   (connector.0)
+    EPI_SWIGLU = 3,          // gate/up interleaved tiles -> bf16(silu(g) * u)       (gate_up)
+    EPI_RESID = 4,           // h[m][col] = bf16(h + bf16(acc)); per-row sum of squares partials (o_proj, down_proj)
+    EPI_ROPE = 5             // q/k/v split, RoPE, q buffer + paged K / V^T append   (qkv)
+};
+// activation operand source
+enum {
+    XSRC_PLAIN = 0,          // x is a bf16 [16][ldx] tile
+    XSRC_NORM = 1            // x = LlamaRMSNorm(h) computed on the fly: bf16(w[k] * bf16(h[m][k] * rs[m]))
+};
 
 struct GemvArgs {
     const void *Wp;               // packed weights (see gemv.hip)
-    const unsigned short *x;      // bf16 [16][ldx]
-    float *out_f32;               // EPI_PARTIAL_F32: [ksplit][16][ldo]
-    unsigned short *out_bf16;     // other epilogues:  [16][ldo]
-    const unsigned short *bias;   // bf16 [N] or null (EPI_BF16 / EPI_BF16_GELU_ERF)
+    const unsigned short *x;      // XSRC_PLAIN: bf16 [16][ldx];  XSRC_NORM: residual stream h, bf16 [16][ldx]
+    float *out_f32;               // EPI_PARTIAL_F32
+    unsigned short *out_bf16;     // EPI_BF16 / GELU / SWIGLU: [16][ldo];  EPI_ROPE: q buffer [16][nh*hd]
+    const unsigned short *bias;   // bf16 [N] or null
     int K, ldx, ldo;
     int NT;                       // column tiles (N padded to 16)
     int N_valid;                  // real N (multiple of 4)
     int n_rows;                   // valid token rows (<= 16)
-    int CT;                       // column tiles per block (0 = auto)
+    int CT;                       // column tiles per group (0 = default)
+    int KC;                       // K chunks walked sequentially by each wave (K = ksplit*NW*KC*KF*32)
+    // XSRC_NORM
+    const unsigned short *norm_w; // bf16 [K]
+    const float *sq_in;           // [sq_in_parts][16] per-row sum-of-squares partials of h
+    int sq_in_parts;
+    float eps;
+    // EPI_RESID
+    unsigned short *h;            // residual stream, bf16 [16][ldo], updated in place
+    float *sq_out;                // [gridDim.x][16] partials of the updated rows
+    // EPI_ROPE
+    const unsigned short *cos_tab, *sin_tab;   // bf16 [pos][hd/2]
+    KvGeom kv;
+    int layer, num_heads;
+    long long pos0;
 };
 
-struct GemvPlan { int NW, KF, ksplit; };
+struct GemvPlan { int NW, KF, KC, ksplit; };
 
 int gemv_plan(int K, bool allow_ksplit, GemvPlan *p);
-hipError_t gemv_launch(GemvArgs a, const GemvPlan &p, int epi, hipStream_t st);
+// grid.x the launch will use (= number of sq_out partial rows an EPI_RESID launch writes)
+int gemv_grid_x(const GemvArgs &a, const GemvPlan &p, int epi);
+hipError_t gemv_launch(GemvArgs a, const GemvPlan &p, int xsrc, int epi, hipStream_t st);
 // source tiles [0,NT) of row-major W[N_valid][K] -> packed tiles t*tile_stride + tile_offset of Wp
 hipError_t pack_weight_launch(const void *W, void *Wp, int N_valid, int K, int NT, int tile_stride, int tile_offset,
                               hipStream_t st);

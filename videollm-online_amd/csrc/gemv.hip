@@ -1,34 +1,45 @@
-// gemv.hip — weight-streaming skinny GEMM for the Llama step (n <= 16 rows).
+// gemv.hip — weight-streaming skinny GEMM for the Llama step (n <= 16 rows), with the neighbouring
+// elementwise work fused into its operand load and epilogue.
 //
 // y[m][n] = sum_k x[m][k] * W[n][k]      x: bf16 [16][ldx] row-major (rows >= n_rows ignored)
 //                                        W: bf16, HF nn.Linear layout [N][K]
 //
-// Replaces the hipBLASLt/cuBLAS skinny GEMMs under q/k/v/o_proj, gate/up/down_proj,
-// lm_head (HF:models/llama/modeling_llama.py:174-176,254-256,280,477-480) and the
-// connector Linears (models/live_llama/modeling_live_llama.py:18-22).
+// Replaces the hipBLASLt/cuBLAS skinny GEMMs under q/k/v/o_proj, gate/up/down_proj, lm_head
+// (HF:models/llama/modeling_llama.py:174-176,254-256,280,477-480) and the connector Linears
+// (models/live_llama/modeling_live_llama.py:18-22), plus — fused —
+//   XSRC_NORM   LlamaRMSNorm of the residual stream while building the activation fragments (:62-67)
+//   EPI_RESID   `hidden_states = residual + hidden_states` (:317, :323) and the next norm's row sum of squares
+//   EPI_ROPE    q/k/v split, apply_rotary_pos_emb (:138-160), KV append (replaces DynamicLayer.update's
+//               torch.cat of the whole cache, HF:cache_utils.py:127-151)
+//   EPI_SWIGLU  act_fn(gate) * up (:176);  EPI_BF16_GELU_ERF  the connector's python-GELU
+// so a decoder layer is 6 launches (qkv, attention, combine, o, gate_up, down) instead of 9+.
 //
-// HBM-bound (arithmetic intensity ~ n FLOP per weight byte): the design streams every
-// weight byte exactly once with 1-KiB-per-wave coalesced global_load_dwordx4 and keeps
-// the tiny activation operand in registers.
+// HBM-bound (arithmetic intensity ~ n FLOP per weight byte): every weight byte is streamed exactly
+// once with 1-KiB-per-wave coalesced global_load_dwordx4; the tiny activation operand lives in VGPRs.
 //
 // Weight image in HBM ("packed", built once at load time by pack_weight_kernel):
 //   Wp[tile][kf][lane] : 16 bytes = W[tile*16 + (lane&15)][kf*32 + (lane>>4)*8 .. +8]
-// i.e. exactly the A-operand fragment of v_mfma_f32_16x16x32_bf16, so one wave
-// instruction loads one MFMA's worth of weights from 1 KiB of contiguous HBM.
-// The MFMA computes D[nrow][m] = sum_k Wfrag[nrow][k] * xfrag[k][m]   (W as A, x as B):
+// = the A-operand fragment of v_mfma_f32_16x16x32_bf16.  The MFMA computes
+//   D[nrow][m] = sum_k Wfrag[nrow][k] * xfrag[k][m]   (W as A, x as B):
 //   lane l, reg r  ->  output column n = tile*16 + (l>>4)*4 + r, token row m = l&15.
 //
-// Work split: grid.x = groups of CT column tiles, grid.y = K splits; inside a block the
-// NW waves split the block's K range (wave w owns KF fragments), each wave keeps its x
-// fragments in VGPRs for all CT tiles, partial tiles are reduced across waves through LDS.
+// Work split: persistent blocks (grid.x ~ one per CU) stride over GROUPS of two column tiles;
+// grid.y = K slices (unit tests only; the step uses whole-K kernels so epilogues see final sums).
+// Inside a block the NW waves split K; a wave walks its K range in KC chunks of KF fragments and
+// keeps the chunk's activation fragments in VGPRs.  Weight fragment kf is re-loaded for the next
+// (chunk, tile) item right after the MFMA that consumed it (rolling prefetch): KF KiB of HBM reads
+// stay in flight per wave with a single register set.  Per group: partial tiles -> LDS
+// (double-buffered, one barrier), the first waves reduce across waves and run the epilogue.
+#include <stdlib.h>
+
 #include "common.cuh"
 #include "gemv.h"
 
 // ------------------------------------------------------------------------------------
 // packing: row-major [N][K] bf16 -> fragment order.  Rows >= N_valid are zero-filled.
-// ------------------------------------------------------------------------------------
 // Source tile t lands at destination tile t*tile_stride + tile_offset (used to concatenate q/k/v and
 // to interleave gate/up 16-row tiles for the SwiGLU epilogue).
+// ------------------------------------------------------------------------------------
 __global__ void pack_weight_kernel(const bf16_t *__restrict__ W, uint4 *__restrict__ Wp, int N_valid, int K,
                                    int NT, int KFtot, int tile_stride, int tile_offset) {
     const size_t total = (size_t)NT * KFtot * 64;
@@ -59,197 +70,324 @@ VLO_DEV float gelu_python_bf16(float x) {    // HF GELUActivation(use_gelu_pytho
     const float s = rbf(1.0f + e);
     return rbf(a * s);
 }
+VLO_DEV float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-// One (tile, lane) element of the reduced output -> epilogue.  s = sum over the block's waves.
-template <int EPI>
-VLO_DEV void gemv_epilogue(const GemvArgs &a, int tile, int l, float4 s, float4 s2, int kslice) {
-    const int m = l & 15;
-    if (m >= a.n_rows) return;
-    if (EPI == EPI_SWIGLU) {           // s = gate tile, s2 = up tile; `tile` is the pair index
-        const int col = tile * 16 + (l >> 4) * 4;
-        ushort4 o;
-        o.x = f2bf(silu_bf16(rbf(s.x)) * rbf(s2.x));
-        o.y = f2bf(silu_bf16(rbf(s.y)) * rbf(s2.y));
-        o.z = f2bf(silu_bf16(rbf(s.z)) * rbf(s2.z));
-        o.w = f2bf(silu_bf16(rbf(s.w)) * rbf(s2.w));
-        *reinterpret_cast<ushort4 *>(a.out_bf16 + (size_t)m * a.ldo + col) = o;
-        return;
-    }
-    const int col = tile * 16 + (l >> 4) * 4;
-    if (EPI == EPI_PARTIAL_F32) {
-        *reinterpret_cast<float4 *>(a.out_f32 + ((size_t)kslice * 16 + m) * a.ldo + col) = s;
-        return;
-    }
-    if (col >= a.N_valid) return;          // N padded to 16 at pack time; N_valid % 4 == 0
-    if (a.bias) {
-        const ushort4 b = *reinterpret_cast<const ushort4 *>(a.bias + col);
-        s.x += bf2f(b.x); s.y += bf2f(b.y); s.z += bf2f(b.z); s.w += bf2f(b.w);
-    }
-    ushort4 o;
-    if (EPI == EPI_BF16_GELU_ERF) {
-        o.x = f2bf(gelu_python_bf16(rbf(s.x))); o.y = f2bf(gelu_python_bf16(rbf(s.y)));
-        o.z = f2bf(gelu_python_bf16(rbf(s.z))); o.w = f2bf(gelu_python_bf16(rbf(s.w)));
-    } else {
-        o.x = f2bf(s.x); o.y = f2bf(s.y); o.z = f2bf(s.z); o.w = f2bf(s.w);
-    }
-    *reinterpret_cast<ushort4 *>(a.out_bf16 + (size_t)m * a.ldo + col) = o;
-}
-
-// Persistent, software-pipelined weight streamer.
-//   grid.y = K slices; grid.x blocks stride over groups of CTG consecutive column tiles.
-//   Wave w of a block owns KF weight fragments (K range) of every tile the block visits and keeps
-//   the matching activation fragments in VGPRs.  The loads of tile t+1 are issued before the MFMAs
-//   of tile t (two register sets), also across group boundaries, so the wave always has 16..32 KiB
-//   of HBM reads in flight.  Per group: partial tiles -> LDS (double-buffered), one barrier, the
-//   first CTG*64 threads reduce across waves and run the epilogue.
-template <int KF, int NW, int EPI>
+template <int KF, int NW, int XSRC, int EPI>
 __global__ __launch_bounds__(NW * 64) void gemv16_kernel(GemvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float4 red[];      // [2][NW][CTG][64]
+    constexpr int CTG = 2;
+    extern __shared__ __attribute__((aligned(16))) float4 red[];      // [2][NW][CTG][64] float4, then scratch
+    float *scratch = reinterpret_cast<float *>(red + 2 * NW * CTG * 64);   // rs[16] | tmp[NW*4][16]
+    float *rs_lds = scratch;
+    float *tmp_lds = scratch + 16;
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
+    const int m16 = lane & 15, qd = lane >> 4;
     const int KFtot = a.K >> 5;
-    const int kf0 = (blockIdx.y * NW + w) * KF;
-    const int CTG = a.CT;
+    const int kfw0 = (blockIdx.y * NW + w) * a.KC * KF;       // first fragment of this wave's K range
 
-    frag_ab xf[KF];
-    {
-        const bf16_t *xr = a.x + (size_t)(lane & 15) * a.ldx + (size_t)kf0 * 32 + (lane >> 4) * 8;
-#pragma unroll
-        for (int kf = 0; kf < KF; ++kf) xf[kf] = *reinterpret_cast<const frag_ab *>(xr + kf * 32);
-    }
-    const frag_ab *wbase = reinterpret_cast<const frag_ab *>(a.Wp) + (size_t)kf0 * 64 + lane;
+    // ---- group -> tiles -----------------------------------------------------------------
+    const int hd = a.kv.head_dim;
+    const int tph = (EPI == EPI_ROPE) ? hd / 16 : 2;           // tiles per head
+    const int hp = tph / 2;                                    // rotary pairs of tiles per head
+    const int ngroups = (EPI == EPI_ROPE) ? a.NT / 2 : (a.NT + 1) / 2;
+    auto tile_a = [&](int g) { return (EPI == EPI_ROPE) ? (g / hp) * tph + (g % hp) : 2 * g; };
+    auto tile_b = [&](int g) { return (EPI == EPI_ROPE) ? (g / hp) * tph + (g % hp) + hp : 2 * g + 1; };
+
+    const frag_ab *wbase = reinterpret_cast<const frag_ab *>(a.Wp) + (size_t)kfw0 * 64 + lane;
     const size_t tile_stride = (size_t)KFtot * 64;
-    const int ngroups = (a.NT + CTG - 1) / CTG;
+    auto item_ptr = [&](int tile, int c) { return wbase + (size_t)tile * tile_stride + (size_t)c * KF * 64; };
 
-    // rolling prefetch: w[kf] is re-loaded with the next tile's fragment right after the MFMA that
-    // consumed it, so KF x 1 KiB of HBM reads stay in flight per wave with one register set.
+    // ---- first weight fragments go in flight before anything else ---------------------------
     frag_ab wr[KF];
     int g = blockIdx.x;
     if (g < ngroups) {
-        const frag_ab *wp = wbase + (size_t)(g * CTG) * tile_stride;
+        const frag_ab *wp = item_ptr(tile_a(g), 0);
 #pragma unroll
         for (int kf = 0; kf < KF; ++kf) wr[kf] = __builtin_nontemporal_load(wp + kf * 64);
     }
-    int buf = 0;
-    for (; g < ngroups; g += gridDim.x) {
-        const int tile0 = g * CTG;
-        const int cnt = min(CTG, a.NT - tile0);
-        float4 *rb = red + (size_t)buf * NW * CTG * 64;
-        for (int ct = 0; ct < cnt; ++ct) {
-            // the next tile this wave will need (next in group, or first of the block's next group)
-            int nt = tile0 + ct + 1;
-            if (ct + 1 == cnt) nt = (g + gridDim.x < ngroups) ? (g + gridDim.x) * CTG : -1;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            if (nt >= 0) {
-                const frag_ab *wp = wbase + (size_t)nt * tile_stride;
-#pragma unroll
-                for (int kf = 0; kf < KF; ++kf) {
-                    acc = mfma_bf16(wr[kf], xf[kf], acc);
-                    wr[kf] = __builtin_nontemporal_load(wp + kf * 64);
-                }
-            } else {
-#pragma unroll
-                for (int kf = 0; kf < KF; ++kf) acc = mfma_bf16(wr[kf], xf[kf], acc);
-            }
-            rb[(w * CTG + ct) * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+
+    // ---- XSRC_NORM: rs[m] = rsqrt(mean(h[m]^2) + eps) from the producer's partial sums --------
+    if (XSRC == XSRC_NORM) {
+        const int t = threadIdx.x, m = t & 15, sl = t >> 4, nsl = NW * 4;
+        float s = 0.f;
+        for (int p = sl; p < a.sq_in_parts; p += nsl) s += a.sq_in[p * 16 + m];
+        tmp_lds[sl * 16 + m] = s;
+        __syncthreads();
+        if (t < 16) {
+            float tot = 0.f;
+            for (int i = 0; i < nsl; ++i) tot += tmp_lds[i * 16 + t];
+            rs_lds[t] = (t < a.n_rows) ? 1.0f / sqrtf(tot / (float)a.K + a.eps) : 0.f;
         }
         __syncthreads();
-        if (EPI == EPI_SWIGLU) {
-            const int npair = cnt >> 1;
-            for (int t = threadIdx.x; t < npair * 64; t += NW * 64) {
-                const int pr = t >> 6, l = t & 63;
-                float4 gsum = make_float4(0, 0, 0, 0), usum = make_float4(0, 0, 0, 0);
+    }
+
+    // ---- activation fragments of one K chunk (B operand): x[m = lane&15][k .. k+8] -------------
+    frag_ab xf[KF];
+    auto load_x = [&](int c) {
+        const size_t k0 = (size_t)(kfw0 + c * KF) * 32 + qd * 8;
+        const bf16_t *xr = a.x + (size_t)m16 * a.ldx + k0;
+        if (XSRC == XSRC_NORM) {
+            const float rsm = rs_lds[m16];
 #pragma unroll
-                for (int ww = 0; ww < NW; ++ww) {
-                    const float4 a0 = rb[(ww * CTG + 2 * pr) * 64 + l];
-                    const float4 a1 = rb[(ww * CTG + 2 * pr + 1) * 64 + l];
-                    gsum.x += a0.x; gsum.y += a0.y; gsum.z += a0.z; gsum.w += a0.w;
-                    usum.x += a1.x; usum.y += a1.y; usum.z += a1.z; usum.w += a1.w;
-                }
-                gemv_epilogue<EPI>(a, (tile0 >> 1) + pr, l, gsum, usum, blockIdx.y);
+            for (int kf = 0; kf < KF; ++kf) {
+                frag_ab hv = {0, 0, 0, 0, 0, 0, 0, 0}, o;
+                if (m16 < a.n_rows) hv = *reinterpret_cast<const frag_ab *>(xr + kf * 32);
+                const frag_ab wv = *reinterpret_cast<const frag_ab *>(a.norm_w + k0 + kf * 32);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)     // weight * (x * rsqrt(var + eps)).to(bf16)   (HF :66-67)
+                    o[j] = (short)f2bf(bf2f((bf16_t)wv[j]) * rbf(bf2f((bf16_t)hv[j]) * rsm));
+                xf[kf] = o;
             }
         } else {
-            for (int t = threadIdx.x; t < cnt * 64; t += NW * 64) {
-                const int ct = t >> 6, l = t & 63;
-                float4 s = make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int kf = 0; kf < KF; ++kf) {
+                frag_ab z = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (m16 < a.n_rows) z = *reinterpret_cast<const frag_ab *>(xr + kf * 32);
+                xf[kf] = z;
+            }
+        }
+    };
+    if (a.KC == 1) load_x(0);
+
+    float sq_acc = 0.f;                    // EPI_RESID: this wave's running sum of squares for row lane&15
+    int buf = 0;
+    for (; g < ngroups; g += gridDim.x) {
+        const int tA = tile_a(g), tB = tile_b(g);
+        const bool hasB = tB < a.NT;
+        const int gn = g + gridDim.x;
+        float4 *rb = red + (size_t)buf * NW * CTG * 64;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < a.KC; ++c) {
+            if (a.KC > 1) load_x(c);
+            // item (c, A); next item is (c, B) | (c+1, A) | (next group, 0, A) | none
+            {
+                const frag_ab *np = hasB ? item_ptr(tB, c)
+                                         : (c + 1 < a.KC ? item_ptr(tA, c + 1) : (gn < ngroups ? item_ptr(tile_a(gn), 0) : nullptr));
+                if (np) {
+#pragma unroll
+                    for (int kf = 0; kf < KF; ++kf) {
+                        acc0 = mfma_bf16(wr[kf], xf[kf], acc0);
+                        wr[kf] = __builtin_nontemporal_load(np + kf * 64);
+                    }
+                } else {
+#pragma unroll
+                    for (int kf = 0; kf < KF; ++kf) acc0 = mfma_bf16(wr[kf], xf[kf], acc0);
+                }
+            }
+            if (hasB) {
+                const frag_ab *np = c + 1 < a.KC ? item_ptr(tA, c + 1) : (gn < ngroups ? item_ptr(tile_a(gn), 0) : nullptr);
+                if (np) {
+#pragma unroll
+                    for (int kf = 0; kf < KF; ++kf) {
+                        acc1 = mfma_bf16(wr[kf], xf[kf], acc1);
+                        wr[kf] = __builtin_nontemporal_load(np + kf * 64);
+                    }
+                } else {
+#pragma unroll
+                    for (int kf = 0; kf < KF; ++kf) acc1 = mfma_bf16(wr[kf], xf[kf], acc1);
+                }
+            }
+        }
+        rb[(w * CTG + 0) * 64 + lane] = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+        rb[(w * CTG + 1) * 64 + lane] = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+        __syncthreads();
+
+        // ---- cross-wave reduction + epilogue ------------------------------------------------
+        if (EPI == EPI_SWIGLU || EPI == EPI_ROPE) {
+            // both tiles of the group are needed by the same lane (gate/up, rotary pair): one wave
+            if (threadIdx.x < 64) {
+                const int l = lane;
+                float4 sA = make_float4(0, 0, 0, 0), sB = make_float4(0, 0, 0, 0);
 #pragma unroll
                 for (int ww = 0; ww < NW; ++ww) {
-                    const float4 v = rb[(ww * CTG + ct) * 64 + l];
-                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                    sA = f4add(sA, rb[(ww * CTG + 0) * 64 + l]);
+                    sB = f4add(sB, rb[(ww * CTG + 1) * 64 + l]);
                 }
-                gemv_epilogue<EPI>(a, tile0 + ct, l, s, s, blockIdx.y);
+                const int m = l & 15;
+                if (m < a.n_rows) {
+                    const float va[4] = {sA.x, sA.y, sA.z, sA.w}, vb[4] = {sB.x, sB.y, sB.z, sB.w};
+                    if (EPI == EPI_SWIGLU) {
+                        const int col = g * 16 + (l >> 4) * 4;            // tiles (2g, 2g+1) = (gate, up) of columns 16g..
+                        bf16_t o[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = f2bf(silu_bf16(rbf(va[r])) * rbf(vb[r]));
+                        *reinterpret_cast<ushort4 *>(a.out_bf16 + (size_t)m * a.ldo + col) = *reinterpret_cast<const ushort4 *>(o);
+                    } else {
+                        const int half = hd >> 1, nh = a.num_heads, nkv = a.kv.num_kv_heads;
+                        const int head = g / hp, i = (g % hp) * 16 + (l >> 4) * 4;   // column inside the head, < half
+                        const long long pos = a.pos0 + m;
+                        const int page = a.kv.page_table[pos / VLO_PAGE_TOKENS];
+                        const int tok = (int)(pos % VLO_PAGE_TOKENS);
+                        if (head < nh + nkv) {
+                            bf16_t *dst = (head < nh)
+                                ? a.out_bf16 + (size_t)m * nh * hd + (size_t)head * hd
+                                : a.kv.k_pool + (size_t)a.layer * a.kv.layer_stride + (size_t)page * a.kv.page_elems +
+                                      ((size_t)(head - nh) * VLO_PAGE_TOKENS + tok) * hd;
+                            const ushort4 c4 = *reinterpret_cast<const ushort4 *>(a.cos_tab + pos * half + i);
+                            const ushort4 s4 = *reinterpret_cast<const ushort4 *>(a.sin_tab + pos * half + i);
+                            const bf16_t cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+                            bf16_t lo[4], hi[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float x1 = rbf(va[r]), x2 = rbf(vb[r]);      // projection output is bf16
+                                const float c = bf2f(cc[r]), s = bf2f(ss[r]);
+                                // q*cos + rotate_half(q)*sin, each product and the sum rounded to bf16 (:157-158)
+                                lo[r] = f2bf(rbf(x1 * c) + rbf(-x2 * s));
+                                hi[r] = f2bf(rbf(x2 * c) + rbf(x1 * s));
+                            }
+                            *reinterpret_cast<ushort4 *>(dst + i) = *reinterpret_cast<const ushort4 *>(lo);
+                            *reinterpret_cast<ushort4 *>(dst + half + i) = *reinterpret_cast<const ushort4 *>(hi);
+                        } else {
+                            bf16_t *dst = a.kv.vt_pool + (size_t)a.layer * a.kv.layer_stride + (size_t)page * a.kv.page_elems +
+                                          ((size_t)(head - nh - nkv) * hd) * VLO_PAGE_TOKENS + tok;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                dst[(size_t)(i + r) * VLO_PAGE_TOKENS] = f2bf(va[r]);
+                                dst[(size_t)(half + i + r) * VLO_PAGE_TOKENS] = f2bf(vb[r]);
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int t = threadIdx.x; t < CTG * 64; t += NW * 64) {
+                const int ct = t >> 6, l = t & 63;
+                const int tile = ct ? tB : tA;
+                float4 s = make_float4(0, 0, 0, 0);
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww) s = f4add(s, rb[(ww * CTG + ct) * 64 + l]);
+                const int m = l & 15;
+                const int col = tile * 16 + (l >> 4) * 4;
+                const bool live = (m < a.n_rows) && (tile < a.NT);
+                if (EPI == EPI_RESID) {
+                    float sq = 0.f;
+                    if (live) {
+                        bf16_t *hp4 = a.h + (size_t)m * a.ldo + col;
+                        const ushort4 hv = *reinterpret_cast<const ushort4 *>(hp4);
+                        const bf16_t hh[4] = {hv.x, hv.y, hv.z, hv.w};
+                        const float sv[4] = {s.x, s.y, s.z, s.w};
+                        bf16_t o[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {      // Linear output -> bf16, then the bf16 residual add
+                            const float hn = rbf(bf2f(hh[r]) + rbf(sv[r]));
+                            o[r] = f2bf(hn);
+                            sq += hn * hn;
+                        }
+                        *reinterpret_cast<ushort4 *>(hp4) = *reinterpret_cast<const ushort4 *>(o);
+                    }
+                    sq += __shfl_xor(sq, 16, 64);
+                    sq += __shfl_xor(sq, 32, 64);
+                    sq_acc += sq;                          // meaningful in lanes 0..15 (row = lane)
+                } else if (live) {
+                    if (EPI == EPI_PARTIAL_F32) {
+                        *reinterpret_cast<float4 *>(a.out_f32 + ((size_t)blockIdx.y * 16 + m) * a.ldo + col) = s;
+                    } else if (col < a.N_valid) {          // N padded to 16 at pack time; N_valid % 4 == 0
+                        if (a.bias) {
+                            const ushort4 b = *reinterpret_cast<const ushort4 *>(a.bias + col);
+                            s.x += bf2f(b.x); s.y += bf2f(b.y); s.z += bf2f(b.z); s.w += bf2f(b.w);
+                        }
+                        ushort4 o;
+                        if (EPI == EPI_BF16_GELU_ERF) {
+                            o.x = f2bf(gelu_python_bf16(rbf(s.x))); o.y = f2bf(gelu_python_bf16(rbf(s.y)));
+                            o.z = f2bf(gelu_python_bf16(rbf(s.z))); o.w = f2bf(gelu_python_bf16(rbf(s.w)));
+                        } else {
+                            o.x = f2bf(s.x); o.y = f2bf(s.y); o.z = f2bf(s.z); o.w = f2bf(s.w);
+                        }
+                        *reinterpret_cast<ushort4 *>(a.out_bf16 + (size_t)m * a.ldo + col) = o;
+                    }
+                }
             }
         }
         buf ^= 1;
+    }
+    if (EPI == EPI_RESID) {
+        // deterministic block total of the row sums of squares -> sq_out[blockIdx.x][16]
+        __syncthreads();
+        if (lane < 16) tmp_lds[w * 16 + lane] = sq_acc;
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            float tot = 0.f;
+            for (int ww = 0; ww < NW; ++ww) tot += tmp_lds[ww * 16 + threadIdx.x];
+            a.sq_out[(size_t)blockIdx.x * 16 + threadIdx.x] = tot;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------
 // host side: plan + launch
 // ------------------------------------------------------------------------------------
-#include <stdlib.h>
-
 static int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
     return v ? atoi(v) : dflt;
 }
 
 struct NwKf { int nw, kf; };
-// (waves per block, fragments per wave) combinations that are instantiated, in preference order
-static const NwKf kCombos[] = {{8, 16}, {8, 14}, {8, 11}, {8, 8}, {4, 16}, {4, 14}, {4, 11}, {8, 4}, {4, 8},
-                               {8, 2}, {4, 4}, {2, 11}, {8, 1}, {4, 2}, {2, 8}, {2, 4}, {4, 1}, {2, 2}, {2, 1}, {1, 1}};
+// (waves per block, fragments per wave per chunk) combinations that are instantiated, in preference order
+static const NwKf kCombos[] = {{8, 16}, {8, 14}, {8, 11}, {8, 8}, {8, 4}, {8, 2}, {8, 1}, {4, 11}, {4, 1}, {2, 11}, {1, 1}};
 
 int gemv_plan(int K, bool allow_ksplit, GemvPlan *p) {
     if (K <= 0 || (K & 31)) return -1;
     const int KFtot = K >> 5;
-    const int force_nw = env_int("VLO_GEMV_NW", 0), force_kf = env_int("VLO_GEMV_KF", 0);
+    const int force_ks = allow_ksplit ? env_int("VLO_GEMV_KSPLIT", 0) : 0;
     for (const NwKf &c : kCombos) {
-        if (force_nw && c.nw != force_nw) continue;
-        if (force_kf && c.kf != force_kf) continue;
         if (KFtot % (c.nw * c.kf)) continue;
-        const int ks = KFtot / (c.nw * c.kf);
-        if (ks > 1 && !allow_ksplit) continue;
-        if (ks > 16) continue;
-        p->NW = c.nw; p->KF = c.kf; p->ksplit = ks;
+        const int rest = KFtot / (c.nw * c.kf);       // = KC * ksplit
+        if (rest > 16) continue;
+        int ks = 1;
+        if (allow_ksplit && force_ks > 0 && rest % force_ks == 0) ks = force_ks;
+        p->NW = c.nw; p->KF = c.kf; p->ksplit = ks; p->KC = rest / ks;
         return 0;
     }
     return -1;
 }
 
-template <int KF, int NW>
-static hipError_t launch_epi(const GemvArgs &a, int epi, dim3 grid, size_t lds, hipStream_t st) {
-    dim3 block(NW * 64);
-    switch (epi) {
-    case EPI_PARTIAL_F32: hipLaunchKernelGGL((gemv16_kernel<KF, NW, EPI_PARTIAL_F32>), grid, block, lds, st, a); break;
-    case EPI_BF16: hipLaunchKernelGGL((gemv16_kernel<KF, NW, EPI_BF16>), grid, block, lds, st, a); break;
-    case EPI_BF16_GELU_ERF: hipLaunchKernelGGL((gemv16_kernel<KF, NW, EPI_BF16_GELU_ERF>), grid, block, lds, st, a); break;
-    case EPI_SWIGLU: hipLaunchKernelGGL((gemv16_kernel<KF, NW, EPI_SWIGLU>), grid, block, lds, st, a); break;
-    default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
+static int groups_of(const GemvArgs &a, int epi) { return epi == EPI_ROPE ? a.NT / 2 : (a.NT + 1) / 2; }
 
-hipError_t gemv_launch(GemvArgs a, const GemvPlan &p, int epi, hipStream_t st) {
-    static const int kCTG = env_int("VLO_GEMV_CTG", 2);
+int gemv_grid_x(const GemvArgs &a, const GemvPlan &p, int epi) {
     static const int kBPC = env_int("VLO_GEMV_BPC", 1);          // resident blocks per CU aimed at
     static const int kCUs = 256;
-    int ctg = a.CT > 0 ? a.CT : kCTG;
-    if (epi == EPI_SWIGLU) ctg = (ctg + 1) & ~1;
-    a.CT = ctg;
-    const int ngroups = (a.NT + ctg - 1) / ctg;
+    const int ngroups = groups_of(a, epi);
     int gx = (kCUs * kBPC) / p.ksplit;
     if (gx < 1) gx = 1;
     if (gx > ngroups) gx = ngroups;
-    // balance: every block should get the same number of groups where possible
-    const int per = (ngroups + gx - 1) / gx;
-    gx = (ngroups + per - 1) / per;
-    dim3 grid(gx, p.ksplit);
-    const size_t lds = (size_t)2 * p.NW * ctg * 64 * sizeof(float4);
+    const int per = (ngroups + gx - 1) / gx;        // balance: same number of groups per block where possible
+    return (ngroups + per - 1) / per;
+}
+
+template <int KF, int NW>
+static hipError_t launch_variant(const GemvArgs &a, int xsrc, int epi, dim3 grid, size_t lds, hipStream_t st) {
+    dim3 block(NW * 64);
+#define VLO_GO(XS, EP)                                                                    \
+    do {                                                                                  \
+        hipLaunchKernelGGL((gemv16_kernel<KF, NW, XS, EP>), grid, block, lds, st, a);     \
+        return hipGetLastError();                                                         \
+    } while (0)
+    if (xsrc == XSRC_NORM) {
+        if (epi == EPI_ROPE) VLO_GO(XSRC_NORM, EPI_ROPE);
+        if (epi == EPI_SWIGLU) VLO_GO(XSRC_NORM, EPI_SWIGLU);
+        if (epi == EPI_BF16) VLO_GO(XSRC_NORM, EPI_BF16);
+    } else {
+        if (epi == EPI_RESID) VLO_GO(XSRC_PLAIN, EPI_RESID);
+        if (epi == EPI_BF16) VLO_GO(XSRC_PLAIN, EPI_BF16);
+        if (epi == EPI_BF16_GELU_ERF) VLO_GO(XSRC_PLAIN, EPI_BF16_GELU_ERF);
+        if (epi == EPI_PARTIAL_F32) VLO_GO(XSRC_PLAIN, EPI_PARTIAL_F32);
+    }
+#undef VLO_GO
+    return hipErrorInvalidValue;
+}
+
+hipError_t gemv_launch(GemvArgs a, const GemvPlan &p, int xsrc, int epi, hipStream_t st) {
+    if (epi != EPI_PARTIAL_F32 && p.ksplit != 1) return hipErrorInvalidValue;
+    if (epi == EPI_ROPE && ((a.NT & 1) || (a.kv.head_dim != 64 && a.kv.head_dim != 128))) return hipErrorInvalidValue;
+    if (epi == EPI_SWIGLU && (a.NT & 1)) return hipErrorInvalidValue;
+    a.CT = 2;
+    a.KC = p.KC;
+    dim3 grid(gemv_grid_x(a, p, epi), p.ksplit);
+    const size_t lds = (size_t)2 * p.NW * 2 * 64 * sizeof(float4) + (16 + (size_t)p.NW * 4 * 16) * sizeof(float);
 #define VLO_CASE(NW_, KF_) \
-    if (p.NW == NW_ && p.KF == KF_) return launch_epi<KF_, NW_>(a, epi, grid, lds, st);
-    VLO_CASE(8, 16) VLO_CASE(8, 14) VLO_CASE(8, 11) VLO_CASE(8, 8) VLO_CASE(4, 16) VLO_CASE(4, 14) VLO_CASE(4, 11)
-    VLO_CASE(8, 4) VLO_CASE(4, 8) VLO_CASE(8, 2) VLO_CASE(4, 4) VLO_CASE(2, 11) VLO_CASE(8, 1) VLO_CASE(4, 2)
-    VLO_CASE(2, 8) VLO_CASE(2, 4) VLO_CASE(4, 1) VLO_CASE(2, 2) VLO_CASE(2, 1) VLO_CASE(1, 1)
+    if (p.NW == NW_ && p.KF == KF_) return launch_variant<KF_, NW_>(a, xsrc, epi, grid, lds, st);
+    VLO_CASE(8, 16) VLO_CASE(8, 14) VLO_CASE(8, 11) VLO_CASE(8, 8) VLO_CASE(8, 4) VLO_CASE(8, 2) VLO_CASE(8, 1)
+    VLO_CASE(4, 11) VLO_CASE(4, 1) VLO_CASE(2, 11) VLO_CASE(1, 1)
 #undef VLO_CASE
     return hipErrorInvalidValue;
 }

@@ -18,15 +18,8 @@ struct KvGeom {
     int num_kv_heads, head_dim;
 };
 
-// h[m] (+)= bf16(sum_s partial[s][m]) ; x[m] = RMSNorm(h[m]) * w     (rows m < n)
-hipError_t add_rmsnorm_launch(unsigned short *h, const float *partial, int ksplit, int partial_ld,
-                              const unsigned short *w, unsigned short *x, int H, int ldx, float eps, int n,
-                              hipStream_t st);
-
-// split [ks][16][Nqkv] f32 partials into rotary q (bf16 [16][nh*hd]) and K / V^T cache rows
-hipError_t rope_kv_append_launch(const float *qkv_partial, int ksplit, int Nqkv, unsigned short *q_out,
-                                 const unsigned short *cos_tab, const unsigned short *sin_tab,
-                                 KvGeom kv, int layer, int num_heads, int64_t pos0, int n, hipStream_t st);
+// copy `rows` embedding rows into the residual stream h and write their sums of squares to sq_out[0..rows)
+hipError_t prep_rows_launch(const unsigned short *src, unsigned short *h, float *sq_out, int rows, int H, hipStream_t st);
 
 // chunk attention (n <= 16 queries at positions pos0..pos0+n-1 against keys [0, pos0+n))
 hipError_t attention_launch(const unsigned short *q, KvGeom kv, int layer, int num_heads, int64_t pos0, int n,

@@ -1,10 +1,7 @@
 // llm_ops.hip — the non-GEMV kernels of one Llama streaming step on gfx950.
 //
-//   add_rmsnorm_kernel      residual add (+ split-K partial combine) + LlamaRMSNorm
-//                           HF:models/llama/modeling_llama.py:62-67, :317, :323
-//   rope_kv_append_kernel   q/k/v split, RoPE (half-split pairing), append to the paged KV
-//                           HF:...modeling_llama.py:138-160 ; replaces DynamicLayer.update's
-//                           torch.cat of the whole cache (HF:cache_utils.py:127-151)
+//   prep_rows_kernel        stage the step's input embeddings + their row sums of squares
+//                           (RMSNorm, residual adds, RoPE and the KV append are fused into gemv.hip)
 //   attn_chunk_kernel       n<=16 queries x growing KV, GQA, bottom-right causal mask fused,
 //                           split-KV with online softmax (replaces mask build + repeat_kv + SDPA,
 //                           HF:integrations/sdpa_attention.py:79-166, HF:masking_utils.py)
@@ -18,117 +15,27 @@
 #include "llm_ops.h"
 
 // ------------------------------------------------------------------------------------
-// residual add + RMSNorm.  One block per token row.
+// step input: copy the n new embedding rows into the residual stream and emit each row's sum of
+// squares (consumed by the first layer's norm-on-load GEMV).  One block per row.
 // ------------------------------------------------------------------------------------
-#define RMS_THREADS 512
-#define RMS_MAXCH 2   // supports H <= 8 * 512 * 2 = 8192
-
-__global__ __launch_bounds__(RMS_THREADS) void add_rmsnorm_kernel(bf16_t *__restrict__ h, const float *__restrict__ partial,
-                                                                  int ksplit, int partial_ld, const bf16_t *__restrict__ w,
-                                                                  bf16_t *__restrict__ x, int H, int ldx, float eps) {
+__global__ __launch_bounds__(256) void prep_rows_kernel(const bf16_t *__restrict__ src, bf16_t *__restrict__ h,
+                                                        float *__restrict__ sq_out, int H) {
     __shared__ float sm[16];
     const int m = blockIdx.x;
-    bf16_t *hr = h + (size_t)m * H;
-    float v[RMS_MAXCH][8];
     float ss = 0.f;
-    const int nch = H >> 3;
+    for (int ch = threadIdx.x; ch < (H >> 3); ch += blockDim.x) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(src + (size_t)m * H + ch * 8);
+        *reinterpret_cast<uint4 *>(h + (size_t)m * H + ch * 8) = raw;
+        const bf16_t *e = reinterpret_cast<const bf16_t *>(&raw);
 #pragma unroll
-    for (int c = 0; c < RMS_MAXCH; ++c) {
-        const int ch = threadIdx.x + c * RMS_THREADS;
-        if (ch < nch) {
-            const uint4 raw = *reinterpret_cast<const uint4 *>(hr + ch * 8);
-            const bf16_t *e = reinterpret_cast<const bf16_t *>(&raw);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[c][j] = bf2f(e[j]);
-            if (partial) {
-                float d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int s = 0; s < ksplit; ++s) {
-                    const float4 *pp = reinterpret_cast<const float4 *>(partial + ((size_t)s * 16 + m) * partial_ld + ch * 8);
-                    const float4 a = pp[0], b = pp[1];
-                    d[0] += a.x; d[1] += a.y; d[2] += a.z; d[3] += a.w;
-                    d[4] += b.x; d[5] += b.y; d[6] += b.z; d[7] += b.w;
-                }
-                uint4 o;
-                bf16_t *oe = reinterpret_cast<bf16_t *>(&o);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {          // linear output -> bf16, then bf16 residual add
-                    v[c][j] = rbf(v[c][j] + rbf(d[j]));
-                    oe[j] = f2bf(v[c][j]);
-                }
-                *reinterpret_cast<uint4 *>(hr + ch * 8) = o;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ss += v[c][j] * v[c][j];
-        }
+        for (int j = 0; j < 8; ++j) ss += bf2f(e[j]) * bf2f(e[j]);
     }
     ss = block_sum(ss, sm);
-    const float rs = 1.0f / sqrtf(ss / (float)H + eps);
-    bf16_t *xr = x + (size_t)m * ldx;
-#pragma unroll
-    for (int c = 0; c < RMS_MAXCH; ++c) {
-        const int ch = threadIdx.x + c * RMS_THREADS;
-        if (ch < nch) {
-            const uint4 wraw = *reinterpret_cast<const uint4 *>(w + ch * 8);
-            const bf16_t *we = reinterpret_cast<const bf16_t *>(&wraw);
-            uint4 o;
-            bf16_t *oe = reinterpret_cast<bf16_t *>(&o);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) oe[j] = f2bf(bf2f(we[j]) * rbf(v[c][j] * rs));   // weight * x.to(bf16)
-            *reinterpret_cast<uint4 *>(xr + ch * 8) = o;
-        }
-    }
+    if (threadIdx.x == 0) sq_out[m] = ss;          // sq_out[0][m]: a single partial
 }
-
-hipError_t add_rmsnorm_launch(unsigned short *h, const float *partial, int ksplit, int partial_ld, const unsigned short *w,
-                              unsigned short *x, int H, int ldx, float eps, int n, hipStream_t st) {
-    if (H > 8 * RMS_THREADS * RMS_MAXCH || (H & 7)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(add_rmsnorm_kernel, dim3(n), dim3(RMS_THREADS), 0, st, h, partial, ksplit, partial_ld, w, x, H, ldx, eps);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------
-// RoPE + KV append.  grid = (n tokens, nh + 2*nkv heads), 64 threads.
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void rope_kv_append_kernel(const float *__restrict__ P, int ksplit, int Nqkv,
-                                                            bf16_t *__restrict__ q_out, const bf16_t *__restrict__ cos_tab,
-                                                            const bf16_t *__restrict__ sin_tab, KvGeom kv, int layer,
-                                                            int nh, int64_t pos0) {
-    const int m = blockIdx.x, hh = blockIdx.y;
-    const int hd = kv.head_dim, half = hd >> 1, nkv = kv.num_kv_heads;
-    const int64_t pos = pos0 + m;
-    const int col0 = hh * hd;
-    auto val = [&](int c) {
-        float s = 0.f;
-        for (int k = 0; k < ksplit; ++k) s += P[((size_t)k * 16 + m) * Nqkv + col0 + c];
-        return rbf(s);          // projection output is a bf16 tensor in the reference
-    };
-    const int page = kv.page_table[pos / VLO_PAGE_TOKENS];
-    const int tok = (int)(pos % VLO_PAGE_TOKENS);
-    if (hh < nh + nkv) {
-        bf16_t *dst;
-        if (hh < nh) dst = q_out + (size_t)m * nh * hd + (size_t)hh * hd;
-        else dst = kv.k_pool + (size_t)layer * kv.layer_stride + (size_t)page * kv.page_elems +
-                   ((size_t)(hh - nh) * VLO_PAGE_TOKENS + tok) * hd;
-        for (int i = threadIdx.x; i < half; i += 64) {
-            const float a = val(i), b = val(i + half);
-            const float c = bf2f(cos_tab[pos * half + i]), s = bf2f(sin_tab[pos * half + i]);
-            // q*cos + rotate_half(q)*sin, each product and the sum rounded to bf16 (:157-158)
-            dst[i] = f2bf(rbf(a * c) + rbf(-b * s));
-            dst[i + half] = f2bf(rbf(b * c) + rbf(a * s));
-        }
-    } else {
-        const int kvh = hh - nh - nkv;
-        bf16_t *dst = kv.vt_pool + (size_t)layer * kv.layer_stride + (size_t)page * kv.page_elems +
-                      ((size_t)kvh * hd) * VLO_PAGE_TOKENS + tok;
-        for (int d = threadIdx.x; d < hd; d += 64) dst[(size_t)d * VLO_PAGE_TOKENS] = f2bf(val(d));
-    }
-}
-
-hipError_t rope_kv_append_launch(const float *qkv_partial, int ksplit, int Nqkv, unsigned short *q_out,
-                                 const unsigned short *cos_tab, const unsigned short *sin_tab, KvGeom kv, int layer,
-                                 int num_heads, int64_t pos0, int n, hipStream_t st) {
-    hipLaunchKernelGGL(rope_kv_append_kernel, dim3(n, num_heads + 2 * kv.num_kv_heads), dim3(64), 0, st, qkv_partial, ksplit,
-                       Nqkv, q_out, cos_tab, sin_tab, kv, layer, num_heads, pos0);
+hipError_t prep_rows_launch(const unsigned short *src, unsigned short *h, float *sq_out, int rows, int H, hipStream_t st) {
+    if (H & 7) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(prep_rows_kernel, dim3(rows), dim3(256), 0, st, src, h, sq_out, H);
     return hipGetLastError();
 }
 
