@@ -160,6 +160,11 @@ int vlo_profile_read(vlo_engine *e, int64_t *launches, double *total_ms, double 
  * packed weight images are cycled so the 256 MiB Infinity Cache cannot serve re-reads. */
 int vlo_bench_gemv(int N, int K, int n_rows, int epi, int iters, int nbuf, double *avg_us);
 
+/* debugging aid for tests: copy an internal per-session activation buffer of the LAST chunk to dst_dev.
+ * which: 0 = q [16][nh*hd] bf16, 1 = attention output [16][nh*hd] bf16, 2 = residual stream h [16][H] bf16,
+ *        3 = MLP activation [16][I] bf16, 4 = normed x [16][H] bf16 */
+int vlo_debug_read(vlo_session *s, int which, void *dst_dev, int64_t bytes, void *stream);
+
 const char *vlo_last_error(void);
 int vlo_abi_version(void);
 

@@ -5,10 +5,11 @@ import torch
 from videollm_online_amd import _C
 L = _C.lib()
 torch.zeros(1, device="cuda")
-SHAPES = [("qkv", 6144, 4096, 5), ("o", 4096, 4096, 4), ("gate_up", 28672, 4096, 3), ("down", 4096, 14336, 4), ("lm_head", 128256, 4096, 1)]   # epi: 5 rope, 4 resid, 3 swiglu, 1 bf16
+SHAPES = [("qkv+rope", 6144, 4096, 5), ("o+resid", 4096, 4096, 4), ("gate_up", 28672, 4096, 3), ("down/ks4", 4096, 14336, 0), ("lm_head", 128256, 4096, 1)]   # epi: 5 rope, 4 resid, 3 swiglu(+norm), 0 partial, 1 bf16
 tot_us = 0
+FORCE_NBUF = int(os.environ.get("NBUF", "0"))
 for name, N, K, epi in SHAPES:
-    nbuf = max(2, int(1.2e9 // (N * K * 2)) + 1)
+    nbuf = FORCE_NBUF or max(2, int(1.2e9 // (N * K * 2)) + 1)
     us = C.c_double()
     _C.check(L.vlo_bench_gemv(N, K, 11, epi, 60, nbuf, C.byref(us)))
     gb = N * K * 2 / 1e9

@@ -20,15 +20,17 @@ typedef __attribute__((ext_vector_type(4))) float  f32x4;
 
 VLO_DEV float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 
-// round-to-nearest-even float -> bf16 (what torch's .to(bfloat16) does)
-VLO_DEV bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// round-to-nearest-even float -> bf16 (what torch's .to(bfloat16) does).  clang lowers these casts to
+// gfx950's v_cvt_pk_bf16_f32 and — unlike inline asm — schedules the VALU->MFMA operand hazard itself.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+VLO_DEV unsigned pack2bf(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
+VLO_DEV bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 // value after a bf16 rounding point, kept in a float register
-VLO_DEV float rbf(float f) { return bf2f(f2bf(f)); }
+VLO_DEV float rbf(float f) { return (float)(__bf16)f; }
 
 VLO_DEV float h2f(f16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 VLO_DEV f16_t f2h(float f) { return __builtin_bit_cast(f16_t, (_Float16)f); }

@@ -72,7 +72,7 @@ struct vlo_session {
     std::vector<int> pages;
     std::vector<void *> owned;
     unsigned short *h = nullptr, *x = nullptr, *act = nullptr, *attn = nullptr, *q = nullptr, *emb1 = nullptr;
-    float *part_o = nullptr, *part_ml = nullptr;
+    float *part_o = nullptr, *part_ml = nullptr, *partial = nullptr;
     float *sq[2] = {nullptr, nullptr};          // row sum-of-squares partials handed from EPI_RESID to XSRC_NORM
     unsigned short *logits = nullptr, *last_logits = nullptr;
     int64_t *tok = nullptr;

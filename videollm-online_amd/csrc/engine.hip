@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -225,7 +226,7 @@ int vlo_engine_finalize(vlo_engine *e) {
         if (I % 16) return fail(VLO_E_UNSUPPORTED, "intermediate_size must be a multiple of 16");
         if ((rc = pack_into(e, p + "mlp.gate_proj.weight", I, H, L.gate_up.Wp, 2, 0))) return rc;
         if ((rc = pack_into(e, p + "mlp.up_proj.weight", I, H, L.gate_up.Wp, 2, 1))) return rc;
-        if ((rc = make_linear(e, &L.down, H, I, false))) return rc;
+        if ((rc = make_linear(e, &L.down, H, I, true))) return rc;
         if ((rc = pack_into(e, p + "mlp.down_proj.weight", H, I, L.down.Wp, 1, 0))) return rc;
         if ((rc = take_vec(e, p + "input_layernorm.weight", H, &L.ln_in))) return rc;
         if ((rc = take_vec(e, p + "post_attention_layernorm.weight", H, &L.ln_post))) return rc;
@@ -355,6 +356,9 @@ int vlo_session_create(vlo_engine *e, int64_t max_tokens_hint, vlo_session **out
     A((void **)&s->attn, (size_t)32 * nh * hd * 2);
     A((void **)&s->q, (size_t)16 * nh * hd * 2);
     (void)Nqkv;
+    int ksmax = 1;
+    for (auto &L : e->layers) ksmax = std::max(ksmax, L.down.plan.ksplit);
+    A((void **)&s->partial, (size_t)ksmax * 16 * H * 4);
     A((void **)&s->sq[0], (size_t)(512 + 16) * 16 * 4);      // row sum-of-squares partials: [gemv grid.x <= 512][16] (+ row offset slack)
     A((void **)&s->sq[1], (size_t)(512 + 16) * 16 * 4);
     A((void **)&s->part_o, (size_t)VLO_MAX_SPLITS * nh * 16 * hd * 4);
@@ -494,62 +498,67 @@ static GemvArgs gemv_args(const PackedLinear &pl, const unsigned short *x, int l
     return a;
 }
 
-// one chunk of m <= 16 new tokens whose embeddings are at `src`
-//   per layer:  qkv GEMV [RMSNorm on load | RoPE + KV append epilogue] -> attention -> combine ->
-//               o GEMV [residual + sum-of-squares epilogue] -> gate/up GEMV [RMSNorm on load | SwiGLU] ->
-//               down GEMV [residual + sum-of-squares epilogue]
+// one chunk of m <= 16 new tokens whose embeddings are at `src`.  Per decoder layer (7 launches):
+//   add_rmsnorm   [+ down-proj split-K combine + residual of the previous layer]      -> x
+//   qkv GEMV      [RoPE + paged KV append in the epilogue]                             -> q, K, V^T
+//   attention, combine                                                                 -> attn
+//   o GEMV        [residual add + row sum-of-squares partials in the epilogue]         -> h, sq
+//   gate/up GEMV  [post-attention RMSNorm fused into the operand load | SwiGLU]        -> act
+//   down GEMV     [K split over blocks, fp32 partials]                                 -> partial
 static int run_chunk(vlo_session *s, const unsigned short *src, int m, bool want_last, bool want_all, hipStream_t st) {
+    static const bool fuse_norm = getenv("VLO_FUSE_NORM") ? atoi(getenv("VLO_FUSE_NORM")) != 0 : true;
     vlo_engine *e = s->e;
     const vlo_config &c = e->cfg;
     const int H = c.hidden_size, I = c.intermediate_size, hd = e->head_dim, nh = c.num_heads;
     int rc;
     if ((rc = ensure_pages(s, s->len + m, st))) return rc;
     const KvGeom kv = kv_geom(s);
-    HIP_TRY(prep_rows_launch(src, s->h, s->sq[1], m, H, st));
-    const float *sq_in = s->sq[1];
-    int sq_parts = 1;
+    HIP_TRY(copy_rows_launch(src, s->h, m, H, st));
+    const float *prev = nullptr;
+    int prev_ks = 0;
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerWeights &L = e->layers[l];
+        HIP_TRY(add_rmsnorm_launch(s->h, prev, prev_ks, H, (const unsigned short *)L.ln_in, s->x, H, H, c.rms_eps, m, st));
         {   // qkv
-            GemvArgs a = gemv_args(L.qkv, s->h, H, m);
-            a.norm_w = (const unsigned short *)L.ln_in; a.sq_in = sq_in; a.sq_in_parts = sq_parts; a.eps = c.rms_eps;
+            GemvArgs a = gemv_args(L.qkv, s->x, H, m);
             a.out_bf16 = s->q; a.cos_tab = (const unsigned short *)e->cos_tab; a.sin_tab = (const unsigned short *)e->sin_tab;
             a.kv = kv; a.layer = l; a.num_heads = nh; a.pos0 = s->len;
-            HIP_TRY(gemv_launch(a, L.qkv.plan, XSRC_NORM, EPI_ROPE, st));
+            HIP_TRY(gemv_launch(a, L.qkv.plan, XSRC_PLAIN, EPI_ROPE, st));
         }
         HIP_TRY(attention_launch(s->q, kv, l, nh, s->len, m, s->part_o, s->part_ml, s->attn, st));
+        int sq_parts;
         {   // o_proj + residual
             GemvArgs a = gemv_args(L.o, s->attn, nh * hd, m);
             a.h = s->h; a.ldo = H; a.sq_out = s->sq[0];
             sq_parts = gemv_grid_x(a, L.o.plan, EPI_RESID);
             HIP_TRY(gemv_launch(a, L.o.plan, XSRC_PLAIN, EPI_RESID, st));
-            sq_in = s->sq[0];
         }
+        if (!fuse_norm)
+            HIP_TRY(add_rmsnorm_launch(s->h, nullptr, 0, H, (const unsigned short *)L.ln_post, s->x, H, H, c.rms_eps, m, st));
         {   // gate/up + SwiGLU
             hipEvent_t ev0 = nullptr, ev1 = nullptr;
             if (e->prof_stride > 0 && (e->prof_seen++ % e->prof_stride) == 0) prof_acquire(e, &ev0, &ev1);
-            GemvArgs a = gemv_args(L.gate_up, s->h, H, m);
-            a.norm_w = (const unsigned short *)L.ln_post; a.sq_in = sq_in; a.sq_in_parts = sq_parts; a.eps = c.rms_eps;
+            GemvArgs a = gemv_args(L.gate_up, fuse_norm ? s->h : s->x, H, m);
+            a.norm_w = (const unsigned short *)L.ln_post; a.sq_in = s->sq[0]; a.sq_in_parts = sq_parts; a.eps = c.rms_eps;
             a.out_bf16 = s->act; a.ldo = I;
             if (ev0) hipEventRecord(ev0, st);
-            HIP_TRY(gemv_launch(a, L.gate_up.plan, XSRC_NORM, EPI_SWIGLU, st));
+            HIP_TRY(gemv_launch(a, L.gate_up.plan, fuse_norm ? XSRC_NORM : XSRC_PLAIN, EPI_SWIGLU, st));
             if (ev1) hipEventRecord(ev1, st);
         }
-        {   // down_proj + residual
+        {   // down_proj: fp32 K-slice partials, combined by the next add_rmsnorm
             GemvArgs a = gemv_args(L.down, s->act, I, m);
-            a.h = s->h; a.ldo = H; a.sq_out = s->sq[1];
-            sq_parts = gemv_grid_x(a, L.down.plan, EPI_RESID);
-            HIP_TRY(gemv_launch(a, L.down.plan, XSRC_PLAIN, EPI_RESID, st));
-            sq_in = s->sq[1];
+            a.out_f32 = s->partial; a.ldo = H;
+            HIP_TRY(gemv_launch(a, L.down.plan, XSRC_PLAIN, EPI_PARTIAL_F32, st));
+            prev = s->partial;
+            prev_ks = L.down.plan.ksplit;
         }
     }
     if (want_last || want_all) {
-        // final RMSNorm fused into the lm_head operand load; only the rows that are read
-        const int r0 = want_all ? 0 : m - 1, nr = want_all ? m : 1;
-        GemvArgs a = gemv_args(e->lm_head, s->h + (size_t)r0 * H, H, nr);
-        a.norm_w = (const unsigned short *)e->norm_w; a.sq_in = sq_in + r0; a.sq_in_parts = sq_parts; a.eps = c.rms_eps;
+        HIP_TRY(add_rmsnorm_launch(s->h, prev, prev_ks, H, (const unsigned short *)e->norm_w, s->x, H, H, c.rms_eps, m, st));
+        const int r0 = want_all ? 0 : m - 1, nr = want_all ? m : 1;        // only the rows that are read
+        GemvArgs a = gemv_args(e->lm_head, s->x + (size_t)r0 * H, H, nr);
         a.out_bf16 = s->logits; a.ldo = c.vocab_size;
-        HIP_TRY(gemv_launch(a, e->lm_head.plan, XSRC_NORM, EPI_BF16, st));
+        HIP_TRY(gemv_launch(a, e->lm_head.plan, XSRC_PLAIN, EPI_BF16, st));
         s->last_logits = s->logits + (size_t)(nr - 1) * c.vocab_size;
         s->has_logits = true;
     }
@@ -740,7 +749,7 @@ int vlo_bench_gemv(int N, int K, int n_rows, int epi, int iters, int nbuf, doubl
     a.x = (const unsigned short *)x; a.out_f32 = (float *)o32; a.out_bf16 = (unsigned short *)o16;
     a.K = K; a.ldx = K; a.ldo = (epi == EPI_SWIGLU) ? NT * 8 : NT * 16; a.NT = NT; a.N_valid = N; a.n_rows = n_rows;
     int xsrc = XSRC_PLAIN;
-    if (epi == EPI_SWIGLU || epi == EPI_ROPE || epi == EPI_BF16) {
+    if (epi == EPI_SWIGLU && !(getenv("VLO_FUSE_NORM") && atoi(getenv("VLO_FUSE_NORM")) == 0)) {
         xsrc = XSRC_NORM;
         a.norm_w = (const unsigned short *)nw; a.sq_in = (const float *)sq; a.sq_in_parts = 128; a.eps = 1e-5f;
     }
@@ -767,5 +776,12 @@ int vlo_bench_gemv(int N, int K, int n_rows, int epi, int iters, int nbuf, doubl
     for (void *p : Wp) hipFree(p);
     hipFree(x); hipFree(o32); hipFree(o16); hipFree(hbuf); hipFree(sq); hipFree(nw); hipFree(tab); hipFree(kvp); hipFree(pt);
     hipEventDestroy(e0); hipEventDestroy(e1);
+    return VLO_OK;
+}
+
+int vlo_debug_read(vlo_session *s, int which, void *dst_dev, int64_t bytes, void *stream) {
+    if (!s || !dst_dev || bytes <= 0) return fail(VLO_E_INVALID, "bad debug_read arguments");
+    const void *src = which == 0 ? (void *)s->q : which == 1 ? (void *)s->attn : which == 2 ? (void *)s->h : which == 3 ? (void *)s->act : (void *)s->x;
+    HIP_TRY(hipMemcpyAsync(dst_dev, src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return VLO_OK;
 }

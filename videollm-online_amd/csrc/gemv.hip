@@ -133,9 +133,14 @@ __global__ __launch_bounds__(NW * 64) void gemv16_kernel(GemvArgs a) {
                 frag_ab hv = {0, 0, 0, 0, 0, 0, 0, 0}, o;
                 if (m16 < a.n_rows) hv = *reinterpret_cast<const frag_ab *>(xr + kf * 32);
                 const frag_ab wv = *reinterpret_cast<const frag_ab *>(a.norm_w + k0 + kf * 32);
+                unsigned pk[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j)     // weight * (x * rsqrt(var + eps)).to(bf16)   (HF :66-67)
-                    o[j] = (short)f2bf(bf2f((bf16_t)wv[j]) * rbf(bf2f((bf16_t)hv[j]) * rsm));
+                for (int j = 0; j < 8; j += 2) {     // weight * (x * rsqrt(var + eps)).to(bf16)   (HF :66-67)
+                    const unsigned t2 = pack2bf(bf2f((bf16_t)hv[j]) * rsm, bf2f((bf16_t)hv[j + 1]) * rsm);
+                    pk[j >> 1] = pack2bf(bf2f((bf16_t)wv[j]) * __uint_as_float(t2 << 16),
+                                         bf2f((bf16_t)wv[j + 1]) * __uint_as_float(t2 & 0xffff0000u));
+                }
+                o = __builtin_bit_cast(frag_ab, make_uint4(pk[0], pk[1], pk[2], pk[3]));
                 xf[kf] = o;
             }
         } else {
@@ -333,7 +338,7 @@ int gemv_plan(int K, bool allow_ksplit, GemvPlan *p) {
         if (KFtot % (c.nw * c.kf)) continue;
         const int rest = KFtot / (c.nw * c.kf);       // = KC * ksplit
         if (rest > 16) continue;
-        int ks = 1;
+        int ks = allow_ksplit ? rest : 1;            // K slices across blocks (fp32 partial outputs) vs chunks inside a wave
         if (allow_ksplit && force_ks > 0 && rest % force_ks == 0) ks = force_ks;
         p->NW = c.nw; p->KF = c.kf; p->ksplit = ks; p->KC = rest / ks;
         return 0;
@@ -363,10 +368,10 @@ static hipError_t launch_variant(const GemvArgs &a, int xsrc, int epi, dim3 grid
         return hipGetLastError();                                                         \
     } while (0)
     if (xsrc == XSRC_NORM) {
-        if (epi == EPI_ROPE) VLO_GO(XSRC_NORM, EPI_ROPE);
         if (epi == EPI_SWIGLU) VLO_GO(XSRC_NORM, EPI_SWIGLU);
-        if (epi == EPI_BF16) VLO_GO(XSRC_NORM, EPI_BF16);
     } else {
+        if (epi == EPI_ROPE) VLO_GO(XSRC_PLAIN, EPI_ROPE);
+        if (epi == EPI_SWIGLU) VLO_GO(XSRC_PLAIN, EPI_SWIGLU);
         if (epi == EPI_RESID) VLO_GO(XSRC_PLAIN, EPI_RESID);
         if (epi == EPI_BF16) VLO_GO(XSRC_PLAIN, EPI_BF16);
         if (epi == EPI_BF16_GELU_ERF) VLO_GO(XSRC_PLAIN, EPI_BF16_GELU_ERF);

@@ -18,6 +18,11 @@ struct KvGeom {
     int num_kv_heads, head_dim;
 };
 
+// h[m] (+)= bf16(sum_s partial[s][m]) ; x[m] = RMSNorm(h[m]) * w     (rows m < n)
+hipError_t add_rmsnorm_launch(unsigned short *h, const float *partial, int ksplit, int partial_ld,
+                              const unsigned short *w, unsigned short *x, int H, int ldx, float eps, int n,
+                              hipStream_t st);
+
 // copy `rows` embedding rows into the residual stream h and write their sums of squares to sq_out[0..rows)
 hipError_t prep_rows_launch(const unsigned short *src, unsigned short *h, float *sq_out, int rows, int H, hipStream_t st);
 

@@ -11,8 +11,79 @@
 //
 // Rounding points mirror the reference's bf16 CPU/sdpa path (activations are bf16
 // between ops, accumulation is fp32), see DESIGN.md "Numerics".
+#include <stdlib.h>
+
 #include "common.cuh"
 #include "llm_ops.h"
+
+// ------------------------------------------------------------------------------------
+// residual add + RMSNorm.  One block per token row.
+// ------------------------------------------------------------------------------------
+#define RMS_THREADS 512
+#define RMS_MAXCH 2   // supports H <= 8 * 512 * 2 = 8192
+
+__global__ __launch_bounds__(RMS_THREADS) void add_rmsnorm_kernel(bf16_t *__restrict__ h, const float *__restrict__ partial,
+                                                                  int ksplit, int partial_ld, const bf16_t *__restrict__ w,
+                                                                  bf16_t *__restrict__ x, int H, int ldx, float eps) {
+    __shared__ float sm[16];
+    const int m = blockIdx.x;
+    bf16_t *hr = h + (size_t)m * H;
+    float v[RMS_MAXCH][8];
+    float ss = 0.f;
+    const int nch = H >> 3;
+#pragma unroll
+    for (int c = 0; c < RMS_MAXCH; ++c) {
+        const int ch = threadIdx.x + c * RMS_THREADS;
+        if (ch < nch) {
+            const uint4 raw = *reinterpret_cast<const uint4 *>(hr + ch * 8);
+            const bf16_t *e = reinterpret_cast<const bf16_t *>(&raw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[c][j] = bf2f(e[j]);
+            if (partial) {
+                float d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int s = 0; s < ksplit; ++s) {
+                    const float4 *pp = reinterpret_cast<const float4 *>(partial + ((size_t)s * 16 + m) * partial_ld + ch * 8);
+                    const float4 a = pp[0], b = pp[1];
+                    d[0] += a.x; d[1] += a.y; d[2] += a.z; d[3] += a.w;
+                    d[4] += b.x; d[5] += b.y; d[6] += b.z; d[7] += b.w;
+                }
+                uint4 o;
+                bf16_t *oe = reinterpret_cast<bf16_t *>(&o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {          // linear output -> bf16, then bf16 residual add
+                    v[c][j] = rbf(v[c][j] + rbf(d[j]));
+                    oe[j] = f2bf(v[c][j]);
+                }
+                *reinterpret_cast<uint4 *>(hr + ch * 8) = o;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += v[c][j] * v[c][j];
+        }
+    }
+    ss = block_sum(ss, sm);
+    const float rs = 1.0f / sqrtf(ss / (float)H + eps);
+    bf16_t *xr = x + (size_t)m * ldx;
+#pragma unroll
+    for (int c = 0; c < RMS_MAXCH; ++c) {
+        const int ch = threadIdx.x + c * RMS_THREADS;
+        if (ch < nch) {
+            const uint4 wraw = *reinterpret_cast<const uint4 *>(w + ch * 8);
+            const bf16_t *we = reinterpret_cast<const bf16_t *>(&wraw);
+            uint4 o;
+            bf16_t *oe = reinterpret_cast<bf16_t *>(&o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) oe[j] = f2bf(bf2f(we[j]) * rbf(v[c][j] * rs));   // weight * x.to(bf16)
+            *reinterpret_cast<uint4 *>(xr + ch * 8) = o;
+        }
+    }
+}
+
+hipError_t add_rmsnorm_launch(unsigned short *h, const float *partial, int ksplit, int partial_ld, const unsigned short *w,
+                              unsigned short *x, int H, int ldx, float eps, int n, hipStream_t st) {
+    if (H > 8 * RMS_THREADS * RMS_MAXCH || (H & 7)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(add_rmsnorm_kernel, dim3(n), dim3(RMS_THREADS), 0, st, h, partial, ksplit, partial_ld, w, x, H, ldx, eps);
+    return hipGetLastError();
+}
 
 // ------------------------------------------------------------------------------------
 // step input: copy the n new embedding rows into the residual stream and emit each row's sum of
@@ -40,22 +111,31 @@ hipError_t prep_rows_launch(const unsigned short *src, unsigned short *h, float 
 }
 
 // ------------------------------------------------------------------------------------
-// chunk attention.  grid = (nsplit, nkv); block = (G / HPW) waves; wave w owns q heads
-// kvh*G + w*HPW .. +HPW and walks the block's key chunk in 32-key steps:
-//   S^T[key][qrow] = K[key][:] . Q[qrow][:]          (K tile as MFMA A operand, from HBM)
+// chunk attention.  grid = (nsplit, nkv); block = NHG x KS waves:
+//   NHG = G / HPW head groups (wave hg owns q heads kvh*G + hg*HPW .. +HPW),
+//   KS  = in-block key sub-splits (wave ks walks every KS-th 32-key block of the block's chunk),
+// so a CU holds 8 waves streaming different K/V pages while only one partial per (split, head)
+// leaves the block: the KS partial (m, l, O) states are merged through LDS (flash-decoding inside
+// the block), the block's result goes to the split-KV partial buffers, attn_combine_kernel merges
+// the splits.  Per 32 keys:
+//   S^T[key][qrow] = K[key][:] . Q[qrow][:]          (K page rows = MFMA A operand, from HBM)
 //   online softmax per (head, qrow = lane&15); P^T stays in the lanes that produced it
-//   O^T[d][qrow]  += V^T[d][key] . P^T[key][qrow]    (V^T page rows as MFMA A operand)
+//   O^T[d][qrow]  += V^T[d][key] . P^T[key][qrow]    (V^T page rows = MFMA A operand)
 // ------------------------------------------------------------------------------------
 template <int HD, int HPW>
-__global__ __launch_bounds__(256) void attn_chunk_kernel(const bf16_t *__restrict__ q, KvGeom kv, int layer, int nh, int G,
+__global__ __launch_bounds__(512) void attn_chunk_kernel(const bf16_t *__restrict__ q, KvGeom kv, int layer, int nh, int G, int KS,
                                                          int64_t pos0, int n, int chunk, float scale,
                                                          float *__restrict__ part_o, float *__restrict__ part_ml) {
     constexpr int NKK = HD / 32, NDT = HD / 16;
+    extern __shared__ __attribute__((aligned(16))) float4 lds_o[];        // [(KS-1)*NHG][HPW][NDT][64] float4, then m/l
+    const int NHG = G / HPW;
+    float *lds_ml = reinterpret_cast<float *>(lds_o + (size_t)(KS - 1) * NHG * HPW * NDT * 64);   // [(KS-1)*NHG][HPW][16][2]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int hg = w % NHG, ks = w / NHG;
     const int split = blockIdx.x, kvh = blockIdx.y;
     const int L = (int)(pos0 + n);
     const int c0 = split * chunk, c1 = min(L, c0 + chunk);
-    const int head0 = kvh * G + w * HPW;
+    const int head0 = kvh * G + hg * HPW;
     const int qrow = lane & 15, qd = lane >> 4;
 
     frag_ab qf[HPW][NKK];
@@ -80,7 +160,7 @@ __global__ __launch_bounds__(256) void attn_chunk_kernel(const bf16_t *__restric
     const bf16_t *kbase = kv.k_pool + (size_t)layer * kv.layer_stride;
     const bf16_t *vbase = kv.vt_pool + (size_t)layer * kv.layer_stride;
 
-    for (int kt0 = c0; kt0 < c1; kt0 += 32) {
+    for (int kt0 = c0 + ks * 32; kt0 < c1; kt0 += KS * 32) {
         const int page = kv.page_table[kt0 / VLO_PAGE_TOKENS];
         const int tok0 = kt0 % VLO_PAGE_TOKENS;
         const bf16_t *kp = kbase + (size_t)page * kv.page_elems + ((size_t)kvh * VLO_PAGE_TOKENS + tok0) * HD;
@@ -97,8 +177,7 @@ __global__ __launch_bounds__(256) void attn_chunk_kernel(const bf16_t *__restric
             const bf16_t *vr = vp + (size_t)(dt * 16 + qrow) * VLO_PAGE_TOKENS + qd * 4;
             const uint2 lo = *reinterpret_cast<const uint2 *>(vr);
             const uint2 hi = *reinterpret_cast<const uint2 *>(vr + 16);
-            const uint4 pk = make_uint4(lo.x, lo.y, hi.x, hi.y);
-            vf[dt] = __builtin_bit_cast(frag_ab, pk);
+            vf[dt] = __builtin_bit_cast(frag_ab, make_uint4(lo.x, lo.y, hi.x, hi.y));
         }
         const int kb = kt0 + qd * 4;
 #pragma unroll
@@ -125,13 +204,14 @@ __global__ __launch_bounds__(256) void attn_chunk_kernel(const bf16_t *__restric
             const float alpha = __expf(mrun[h] - m_safe);
             mrun[h] = m_new;
             float psum = 0.f;
-            frag_ab pb;
+            float p[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float p = __expf(v[j] - m_safe);
-                psum += p;
-                pb[j] = (short)f2bf(p);
+                p[j] = __expf(v[j] - m_safe);
+                psum += p[j];
             }
+            const uint4 pk = make_uint4(pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7]));
+            const frag_ab pb = __builtin_bit_cast(frag_ab, pk);
             lrun[h] = lrun[h] * alpha + psum;
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
@@ -143,13 +223,58 @@ __global__ __launch_bounds__(256) void attn_chunk_kernel(const bf16_t *__restric
     }
 #pragma unroll
     for (int h = 0; h < HPW; ++h) {
-        float l = lrun[h];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        lrun[h] += __shfl_xor(lrun[h], 16, 64);
+        lrun[h] += __shfl_xor(lrun[h], 32, 64);
+    }
+    // ---- merge the KS key sub-splits through LDS; waves with ks == 0 keep their state in registers
+    if (KS > 1) {
+        if (ks > 0) {
+            const int slot = (ks - 1) * NHG + hg;
+#pragma unroll
+            for (int h = 0; h < HPW; ++h) {
+                if (qd == 0) {
+                    lds_ml[((slot * HPW + h) * 16 + qrow) * 2] = mrun[h];
+                    lds_ml[((slot * HPW + h) * 16 + qrow) * 2 + 1] = lrun[h];
+                }
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const f32x4 o = O[h][dt];
+                    lds_o[((size_t)(slot * HPW + h) * NDT + dt) * 64 + lane] = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+        __syncthreads();
+        if (ks > 0) return;
+#pragma unroll
+        for (int h = 0; h < HPW; ++h) {
+            float M = mrun[h];
+            for (int k2 = 1; k2 < KS; ++k2) M = fmaxf(M, lds_ml[((((k2 - 1) * NHG + hg) * HPW + h) * 16 + qrow) * 2]);
+            const float Ms = (M == -INFINITY) ? 0.f : M;
+            const float w0 = __expf(mrun[h] - Ms);             // -inf -> 0
+            float l = lrun[h] * w0;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) { O[h][dt][0] *= w0; O[h][dt][1] *= w0; O[h][dt][2] *= w0; O[h][dt][3] *= w0; }
+            for (int k2 = 1; k2 < KS; ++k2) {
+                const int slot = (k2 - 1) * NHG + hg;
+                const float mk = lds_ml[((slot * HPW + h) * 16 + qrow) * 2];
+                const float wk = __expf(mk - Ms);
+                l += lds_ml[((slot * HPW + h) * 16 + qrow) * 2 + 1] * wk;
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const float4 o = lds_o[((size_t)(slot * HPW + h) * NDT + dt) * 64 + lane];
+                    O[h][dt][0] += o.x * wk; O[h][dt][1] += o.y * wk; O[h][dt][2] += o.z * wk; O[h][dt][3] += o.w * wk;
+                }
+            }
+            mrun[h] = M;
+            lrun[h] = l;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < HPW; ++h) {
         const size_t row = ((size_t)split * nh + head0 + h) * 16 + qrow;
         if (qd == 0) {
             part_ml[row * 2] = mrun[h];
-            part_ml[row * 2 + 1] = l;
+            part_ml[row * 2 + 1] = lrun[h];
         }
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
@@ -159,29 +284,54 @@ __global__ __launch_bounds__(256) void attn_chunk_kernel(const bf16_t *__restric
     }
 }
 
-// grid = (nh, n); block = HD threads
-__global__ void attn_combine_kernel(const float *__restrict__ part_o, const float *__restrict__ part_ml, int nsplit, int nh,
-                                    int HD, bf16_t *__restrict__ out) {
-    const int head = blockIdx.x, qrow = blockIdx.y, d = threadIdx.x;
-    float M = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, part_ml[(((size_t)s * nh + head) * 16 + qrow) * 2]);
-    float Lsum = 0.f, acc = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        const size_t row = ((size_t)s * nh + head) * 16 + qrow;
-        const float ms = part_ml[row * 2];
-        const float wgt = (ms == -INFINITY) ? 0.f : __expf(ms - M);
-        Lsum += part_ml[row * 2 + 1] * wgt;
-        acc += part_o[row * HD + d] * wgt;
+// grid = (nh, n); block = 256 threads = (256 / HD) split-lanes x HD columns
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restrict__ part_o, const float *__restrict__ part_ml,
+                                                           int nsplit, int nh, int HD, bf16_t *__restrict__ out) {
+    __shared__ float wgt[VLO_MAX_SPLITS];
+    __shared__ float red[256];
+    __shared__ float Ltot;
+    const int head = blockIdx.x, qrow = blockIdx.y, t = threadIdx.x;
+    if (t < 64) {                                  // one wave: softmax weights of the splits
+        float ms = -INFINITY, ls = 0.f;
+        if (t < nsplit) {
+            const size_t row = ((size_t)t * nh + head) * 16 + qrow;
+            ms = part_ml[row * 2];
+            ls = part_ml[row * 2 + 1];
+        }
+        const float M = wave_max(ms);
+        const float wv = (ms == -INFINITY) ? 0.f : __expf(ms - M);
+        const float Ls = wave_sum(ls * wv);
+        if (t < nsplit) wgt[t] = wv;
+        if (t == 0) Ltot = Ls;
     }
-    out[(size_t)qrow * nh * HD + (size_t)head * HD + d] = f2bf(acc / Lsum);
+    __syncthreads();
+    const int d = t % HD, ql = t / HD, nql = 256 / HD;
+    float acc = 0.f;
+    for (int s = ql; s < nsplit; s += nql) acc += part_o[(((size_t)s * nh + head) * 16 + qrow) * HD + d] * wgt[s];
+    red[t] = acc;
+    __syncthreads();
+    if (ql == 0) {
+        for (int k2 = 1; k2 < nql; ++k2) acc += red[k2 * HD + d];
+        out[(size_t)qrow * nh * HD + (size_t)head * HD + d] = f2bf(acc / Ltot);
+    }
 }
 
 hipError_t attention_launch(const unsigned short *q, KvGeom kv, int layer, int num_heads, int64_t pos0, int n,
                             float *part_o, float *part_ml, unsigned short *out, hipStream_t st) {
     const int nkv = kv.num_kv_heads, hd = kv.head_dim, G = num_heads / nkv;
     const int L = (int)(pos0 + n);
-    int target = (L + 127) / 128;
-    const int want = (256 + nkv - 1) / nkv;           // ~one block per CU
+    const int hpw = (G % 2 == 0) ? 2 : 1;
+    const int nhg = G / hpw;
+    if (nhg > 8) return hipErrorInvalidValue;
+    int KS = 8 / nhg;                                   // 8 waves per block
+    if (KS > 4) KS = 4;
+    {
+        static const int force = getenv("VLO_ATTN_KS") ? atoi(getenv("VLO_ATTN_KS")) : 0;
+        if (force > 0) KS = force;
+    }
+    // splits: ~one block per CU at long context; every wave should see at least one 32-key block
+    int target = (L + KS * 32 - 1) / (KS * 32);
+    const int want = (256 + nkv - 1) / nkv;
     if (target > want) target = want;
     if (target > VLO_MAX_SPLITS) target = VLO_MAX_SPLITS;
     if (target < 1) target = 1;
@@ -189,11 +339,18 @@ hipError_t attention_launch(const unsigned short *q, KvGeom kv, int layer, int n
     chunk = (chunk + 31) & ~31;
     const int nsplit = (L + chunk - 1) / chunk;
     const float scale = 1.0f / sqrtf((float)hd);
-    int hpw = (G % 2 == 0) ? 2 : 1;
-    if (G / hpw > 4) return hipErrorInvalidValue;     // block = (G/HPW) waves, launch bound 256 threads
-    dim3 grid(nsplit, nkv), block((G / hpw) * 64);
+    dim3 grid(nsplit, nkv), block(nhg * KS * 64);
+    const size_t lds = (size_t)(KS - 1) * nhg * hpw * ((size_t)(hd / 16) * 64 * 16 + 16 * 2 * 4);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void *)attn_chunk_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void *)attn_chunk_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void *)attn_chunk_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void *)attn_chunk_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
 #define VLO_ATTN(HD_, HPW_) \
-    hipLaunchKernelGGL((attn_chunk_kernel<HD_, HPW_>), grid, block, 0, st, q, kv, layer, num_heads, G, pos0, n, chunk, scale, part_o, part_ml)
+    hipLaunchKernelGGL((attn_chunk_kernel<HD_, HPW_>), grid, block, lds, st, q, kv, layer, num_heads, G, KS, pos0, n, chunk, scale, part_o, part_ml)
     if (hd == 128 && hpw == 2) VLO_ATTN(128, 2);
     else if (hd == 128 && hpw == 1) VLO_ATTN(128, 1);
     else if (hd == 64 && hpw == 2) VLO_ATTN(64, 2);
@@ -202,7 +359,7 @@ hipError_t attention_launch(const unsigned short *q, KvGeom kv, int layer, int n
 #undef VLO_ATTN
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(attn_combine_kernel, dim3(num_heads, n), dim3(hd), 0, st, part_o, part_ml, nsplit, num_heads, hd, out);
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(num_heads, n), dim3(256), 0, st, part_o, part_ml, nsplit, num_heads, hd, out);
     return hipGetLastError();
 }
 
