@@ -57,6 +57,24 @@ def test_visual_embed_parity(llm, vit, B):
     eng.close()
 
 
+def test_graph_replay_matches_eager():
+    """The captured hipGraph encode (side stream) must reproduce the eager launch sequence bit for bit,
+    also when batch sizes alternate and the workspace is re-allocated."""
+    spec, vspec = O.LLM_SPECS["toy128"], O.VIT_SPECS["toy"]
+    w, vw = O.init_llm_weights(spec, seed=3), O.init_vit_weights(vspec, seed=1)
+    eng = _engine(spec, vspec, w, vw)
+    frames = O.synthetic_frames(4, vspec.image_size, seed=7).cuda()
+    eager = {B: eng.visual_embed(frames[:B]).clone() for B in (1, 3)}       # default stream -> eager path
+    side = torch.cuda.Stream()
+    for B in (1, 3, 1, 4, 3):
+        with torch.cuda.stream(side):
+            out = eng.visual_embed(frames[:B], stream=side)
+        side.synchronize()
+        if B in eager:
+            assert torch.equal(out, eager[B]), B
+    eng.close()
+
+
 def test_visual_embed_matches_reference_fixture(golden_dir):
     """frame_embeds in the fixture were produced by the reference's LiveMixin.visual_embed."""
     g = np.load(os.path.join(golden_dir, "llm_toy128_bf16.npz"))

@@ -35,6 +35,8 @@ if __name__ == "__main__":
     random_llm_weights_to_engine(eng, cfg)
     load_random_vit(eng)
     eng.finalize()
+    st = torch.cuda.Stream()
+    torch.cuda.set_stream(st)
     for B in (1, 2, 4, 8):
         frames = torch.randint(0, 256, (B, 3, 384, 384), dtype=torch.uint8, device="cuda")
         for _ in range(3): eng.visual_embed(frames)

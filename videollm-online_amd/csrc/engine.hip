@@ -630,6 +630,22 @@ int vlo_greedy_generate(vlo_session *s, const void *embeds_dev, int m, int eos_t
     return VLO_OK;
 }
 
+// connector scratch (allocated outside any stream capture)
+int vlo_connector_reserve(vlo_engine *e) {
+    if (e->conn_x) return VLO_OK;
+    const int H = e->cfg.hidden_size, Hv = e->cfg.vision_hidden_size;
+    int rc;
+    if ((rc = dev_alloc(&e->conn_x, (size_t)32 * Hv * 2))) return rc;
+    if ((rc = dev_alloc(&e->conn_mid, (size_t)32 * H * 2))) return rc;
+    if ((rc = dev_alloc(&e->conn_out, (size_t)32 * H * 2))) return rc;
+    e->owned.push_back(e->conn_x);
+    e->owned.push_back(e->conn_mid);
+    e->owned.push_back(e->conn_out);
+    HIP_TRY(hipMemset(e->conn_x, 0, (size_t)32 * Hv * 2));
+    HIP_TRY(hipMemset(e->conn_mid, 0, (size_t)32 * H * 2));
+    return VLO_OK;
+}
+
 int vlo_connector(vlo_engine *e, const void *feats_dev, int rows, void *out_dev, void *stream) {
     if (!e || !feats_dev || !out_dev || rows <= 0) return fail(VLO_E_INVALID, "bad connector arguments");
     if (!e->finalized || !e->has_connector) return fail(VLO_E_STATE, "connector weights not loaded");
@@ -637,16 +653,7 @@ int vlo_connector(vlo_engine *e, const void *feats_dev, int rows, void *out_dev,
     hipStream_t st = (hipStream_t)stream;
     const int H = e->cfg.hidden_size, Hv = e->cfg.vision_hidden_size;
     int rc;
-    if (!e->conn_x) {
-        if ((rc = dev_alloc(&e->conn_x, (size_t)32 * Hv * 2))) return rc;
-        if ((rc = dev_alloc(&e->conn_mid, (size_t)32 * H * 2))) return rc;
-        if ((rc = dev_alloc(&e->conn_out, (size_t)32 * H * 2))) return rc;
-        e->owned.push_back(e->conn_x);
-        e->owned.push_back(e->conn_mid);
-        e->owned.push_back(e->conn_out);
-        HIP_TRY(hipMemset(e->conn_x, 0, (size_t)32 * Hv * 2));
-        HIP_TRY(hipMemset(e->conn_mid, 0, (size_t)32 * H * 2));
-    }
+    if ((rc = vlo_connector_reserve(e))) return rc;
     for (int r0 = 0; r0 < rows; r0 += 16) {
         const int m = std::min(16, rows - r0);
         HIP_TRY(copy_rows_launch((const unsigned short *)feats_dev + (size_t)r0 * Hv, (unsigned short *)e->conn_x, m, Hv, st));

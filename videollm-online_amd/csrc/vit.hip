@@ -13,9 +13,11 @@
 // GEMM: out[m][n] = sum_k X[m][k] * W[n][k]; both operands K-contiguous.  v_mfma_f32_16x16x32_f16 with the
 // WEIGHT tile as the A operand and the ACTIVATION tile as the B operand, so a lane ends up holding 4
 // consecutive output columns of one token row (8-byte row-major stores).
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 
 #include "common.cuh"
 #include "vit.h"
@@ -424,7 +426,13 @@ __global__ __launch_bounds__(256) void map_attn_kernel(const f16_t *__restrict__
     float mx = -INFINITY;
     for (int t = threadIdx.x; t < S; t += blockDim.x) {
         float s = 0.f;
-        for (int d = 0; d < hd; ++d) s += h2f(qp[head * hd + d]) * h2f(kb[(size_t)t * 2 * D + d]);
+        for (int d0 = 0; d0 < hd; d0 += 8) {       // 16-byte loads; hd % 8 == 0
+            const uint4 qv = *reinterpret_cast<const uint4 *>(qp + head * hd + d0);
+            const uint4 kv4 = *reinterpret_cast<const uint4 *>(kb + (size_t)t * 2 * D + d0);
+            const f16_t *qe = reinterpret_cast<const f16_t *>(&qv), *ke = reinterpret_cast<const f16_t *>(&kv4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += h2f(qe[j]) * h2f(ke[j]);
+        }
         s *= scale;
         prob[t] = s;
         mx = fmaxf(mx, s);
@@ -454,25 +462,28 @@ __global__ __launch_bounds__(256) void map_attn_kernel(const f16_t *__restrict__
 }
 
 // CLS + pooled tokens -> bf16 [B][1 + ph*pw][D]   (adaptive_avg_pool2d with exact G/ph blocks; vision_live.py:16-30)
-__global__ void pool_concat_kernel(const float *__restrict__ last, const float *__restrict__ cls, bf16_t *__restrict__ out, int G,
-                                   int D, int ph, int pw) {
+__global__ __launch_bounds__(256) void pool_concat_kernel(const float *__restrict__ last, const float *__restrict__ cls,
+                                                          bf16_t *__restrict__ out, int G, int D, int ph, int pw) {
     const int b = blockIdx.y, tok = blockIdx.x, T = 1 + ph * pw, S = G * G;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) {
-        float v;
-        if (tok == 0) {
-            v = cls[(size_t)b * D + d];
-        } else {
-            const int py = (tok - 1) / pw, px = (tok - 1) % pw;
-            // adaptive pooling windows: [floor(i*G/p), ceil((i+1)*G/p))
-            const int y0 = (py * G) / ph, y1 = ((py + 1) * G + ph - 1) / ph;
-            const int x0 = (px * G) / pw, x1 = ((px + 1) * G + pw - 1) / pw;
-            float s = 0.f;
-            for (int y = y0; y < y1; ++y)
-                for (int x = x0; x < x1; ++x) s += last[((size_t)b * S + y * G + x) * D + d];
-            v = s / (float)((y1 - y0) * (x1 - x0));
+    const int d = blockIdx.z * 256 + threadIdx.x;
+    if (d >= D) return;
+    float v;
+    if (tok == 0) {
+        v = cls[(size_t)b * D + d];
+    } else {
+        const int py = (tok - 1) / pw, px = (tok - 1) % pw;
+        // adaptive pooling windows: [floor(i*G/p), ceil((i+1)*G/p))
+        const int y0 = (py * G) / ph, y1 = ((py + 1) * G + ph - 1) / ph;
+        const int x0 = (px * G) / pw, x1 = ((px + 1) * G + pw - 1) / pw;
+        float s = 0.f;
+        for (int y = y0; y < y1; ++y) {
+            const float *row = last + ((size_t)b * S + (size_t)y * G) * D + d;
+#pragma unroll 8
+            for (int x = x0; x < x1; ++x) s += row[(size_t)x * D];
         }
-        out[((size_t)b * T + tok) * D + d] = f2bf(v);       // frames.to(self.dtype)  (modeling_live.py:25)
+        v = s / (float)((y1 - y0) * (x1 - x0));
     }
+    out[((size_t)b * T + tok) * D + d] = f2bf(v);       // frames.to(self.dtype)  (modeling_live.py:25)
 }
 
 // residual for the MAP head: out32[b][d] = a16[b][d] + (acc16 computed by EP_F32 gemm) — done inline via EP_F32 + add
@@ -516,6 +527,9 @@ struct VitState {
     f16_t *x16 = nullptr, *qk16 = nullptr, *vT = nullptr, *att16 = nullptr, *mid16 = nullptr, *kv16 = nullptr;
     f16_t *hx16 = nullptr, *hmid16 = nullptr, *hatt16 = nullptr, *ho16 = nullptr;
     bf16_t *tokens = nullptr;
+    uint8_t *frames_in = nullptr;        // graph-stable staging of the input frames
+    bf16_t *out_stage = nullptr;         // graph-stable staging of the output embeddings
+    std::map<int, hipGraphExec_t> graphs;     // batch size -> captured encode
     std::vector<void *> ws;
 };
 
@@ -623,6 +637,8 @@ int vit_finalize(vlo_engine *e) {
 static int vit_reserve(vlo_engine *e, VitState *v, int B) {
     if (B <= v->Bcap) return VLO_OK;
     hipDeviceSynchronize();
+    for (auto &g : v->graphs) hipGraphExecDestroy(g.second);     // captured pointers die with the workspace
+    v->graphs.clear();
     for (void *p : v->ws) hipFree(p);
     v->ws.clear();
     const size_t M = (size_t)B * v->S, D = v->D, I = v->I;
@@ -647,16 +663,19 @@ static int vit_reserve(vlo_engine *e, VitState *v, int B) {
     A((void **)&v->cls32, (size_t)B * D * 4);
     A((void **)&v->tmp32, (size_t)B * D * 4);
     A((void **)&v->tokens, (size_t)B * (1 + v->ph * v->pw) * D * 2);
+    A((void **)&v->frames_in, (size_t)B * 3 * v->R * v->R);
+    A((void **)&v->out_stage, (size_t)B * (1 + v->ph * v->pw) * e->cfg.hidden_size * 2);
     if (rc) return rc;
     v->Bcap = B;
     (void)e;
     return VLO_OK;
 }
 
-int vit_visual_embed(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_dev, hipStream_t st) {
+int vlo_connector_reserve(vlo_engine *e);      // engine.hip
+
+// the ~180-launch encode of B frames: frames (uint8, device) -> out (bf16 [B*T][H], device)
+static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_dev, hipStream_t st) {
     VitState *v = e->vit;
-    int rc;
-    if ((rc = vit_reserve(e, v, B))) return rc;
     const int D = v->D, I = v->I, S = v->S, M = B * S;
     const float scale = 1.0f / sqrtf((float)v->hd);
     {   // patch embed + pos  -> residual stream h (fp32)
@@ -724,14 +743,47 @@ int vit_visual_embed(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_
         a.M = B; a.N = D; a.K = I; a.ldx = I;
         VIT_TRY(gemm_launch<EP_RESID>(a, st));
     }
-    hipLaunchKernelGGL(pool_concat_kernel, dim3(1 + v->ph * v->pw, B), dim3(256), 0, st, v->last, v->tmp32, v->tokens, v->G, D, v->ph, v->pw);
+    hipLaunchKernelGGL(pool_concat_kernel, dim3(1 + v->ph * v->pw, B, (D + 255) / 256), dim3(256), 0, st, v->last, v->tmp32, v->tokens, v->G, D, v->ph, v->pw);
     VIT_TRY(hipGetLastError());
     // connector (bf16 skinny GEMMs, gemv.hip)
     return vlo_connector(e, v->tokens, B * (1 + v->ph * v->pw), out_dev, st);
 }
 
+// Entry point.  The launch sequence is static for a given B, so it is captured once into a hipGraph and
+// replayed (one host call instead of ~180; the host thread also feeds the Llama stream).  Frames are
+// staged into a fixed input buffer and the embeddings leave through a fixed output buffer so the
+// captured kernel arguments stay valid.  VLO_VIT_GRAPH=0 disables the graph.
+int vit_visual_embed(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_dev, hipStream_t st) {
+    static const bool use_graph = getenv("VLO_VIT_GRAPH") ? atoi(getenv("VLO_VIT_GRAPH")) != 0 : true;
+    VitState *v = e->vit;
+    int rc;
+    if ((rc = vit_reserve(e, v, B))) return rc;
+    if ((rc = vlo_connector_reserve(e))) return rc;
+    if (!use_graph || st == nullptr) return vit_run(e, frames_dev, B, out_dev, st);    // the null stream cannot be captured
+    const size_t in_bytes = (size_t)B * 3 * v->R * v->R;
+    const size_t out_bytes = (size_t)B * (1 + v->ph * v->pw) * e->cfg.hidden_size * 2;
+    VIT_TRY(hipMemcpyAsync(v->frames_in, frames_dev, in_bytes, hipMemcpyDeviceToDevice, st));
+    auto it = v->graphs.find(B);
+    if (it == v->graphs.end()) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        VIT_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+        rc = vit_run(e, v->frames_in, B, v->out_stage, st);
+        hipError_t ce = hipStreamEndCapture(st, &graph);
+        if (rc) return rc;
+        VIT_TRY(ce);
+        VIT_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        hipGraphDestroy(graph);
+        it = v->graphs.emplace(B, exec).first;
+    }
+    VIT_TRY(hipGraphLaunch(it->second, st));
+    VIT_TRY(hipMemcpyAsync(out_dev, v->out_stage, out_bytes, hipMemcpyDeviceToDevice, st));
+    return VLO_OK;
+}
+
 void vit_destroy(vlo_engine *e) {
     if (!e->vit) return;
+    for (auto &g : e->vit->graphs) hipGraphExecDestroy(g.second);
     for (void *p : e->vit->ws) hipFree(p);
     delete e->vit;
     e->vit = nullptr;

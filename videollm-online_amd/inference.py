@@ -105,6 +105,8 @@ class LiveInfer:
             from torchvision.io import read_video
             video = read_video(video, pts_unit="sec", output_format="TCHW")[0]
         self.video_tensor = video.to(self.model.device)
+        self._video_ready = torch.cuda.Event()
+        self._video_ready.record(self._main)
         self.num_video_frames = self.video_tensor.size(0)
         self.video_duration = self.video_tensor.size(0) / self.frame_fps
 
@@ -120,7 +122,7 @@ class LiveInfer:
         if not todo:
             return
         lo2, hi2 = todo[0], todo[-1] + 1
-        self._enc.wait_stream(self._main)      # video_tensor upload / earlier writes
+        self._enc.wait_event(self._video_ready)      # the video upload; NOT the main stream's Llama work
         with torch.cuda.stream(self._enc):
             emb = self.model.engine.visual_embed(self.video_tensor[lo2:hi2], stream=self._enc)
             emb.record_stream(self._main)
@@ -136,8 +138,6 @@ class LiveInfer:
             self._encode_async(ranger.start, ranger.stop)
             for r in ranger:
                 self.frame_embeds_queue.append((r / self.frame_fps, self._encoded.pop(r)))
-            if self.prefetch:                  # frame t+1 encodes while the LLM step of frame t runs
-                self._encode_async(frame_idx + 1, frame_idx + 2)
         self.last_frame_idx = frame_idx
         self.video_time = video_time
 
@@ -191,6 +191,10 @@ class LiveInfer:
             self.step_log.append((len(self.past_key_values), inputs_embeds.shape[0]))
             eng.llm_step(self.past_key_values, inputs_embeds, want_last=False)
             self._frames_done += 1
+            if self.prefetch and not self.frame_embeds_queue:
+                # frame t+1 is encoded on the encode stream while this Llama step runs; its ~180 launches are
+                # enqueued here, AFTER the step's own launches, so the host never delays the step
+                self._encode_async(self.last_frame_idx + 1, self.last_frame_idx + 2)
             # 2. if the same time, response after frame at that time
             if self.query_queue and video_time >= self.query_queue[0][0]:
                 video_time, query = self.query_queue.popleft()
