@@ -241,6 +241,7 @@ def main():
     ap.add_argument("--mode", default="scheduled", choices=["scheduled", "silent", "free"])
     ap.add_argument("--fps", type=float, default=2.0)
     ap.add_argument("--no-prefetch", action="store_true")
+    ap.add_argument("--prefetch-frames", type=int, default=4, help="frames encoded ahead per batched ViT call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=12)
     ap.add_argument("--prof-stride", type=int, default=8)
@@ -277,7 +278,8 @@ def main():
     toks = stream_tokens(cfg.vocab_size)
     model = LiveModel(eng, eos_token_id=toks.eos_token_id, frame_token_interval_id=toks.interval_id)
     frames = gpu_synthetic_frames(n_frames, seed=1234 + rank)
-    li = LiveInfer(model, tokens=toks, frame_fps=args.fps, prefetch=not args.no_prefetch, schedule=make_schedule(args.mode))
+    li = LiveInfer(model, tokens=toks, frame_fps=args.fps, prefetch=not args.no_prefetch, prefetch_frames=args.prefetch_frames,
+                   schedule=make_schedule(args.mode))
 
     def run(nsteps, timed):
         li.reset()
@@ -335,7 +337,7 @@ def main():
             "config": {"workload": f"{args.model} + siglip-l16-384, {K} frames @ {args.fps:g} FPS 384x384 uint8, "
                                    f"TP=1, one stream per GPU ({world} replica(s)), mode={args.mode} "
                                    f"(16-token response every 10th frame + t=0 query), random-init weights at true shapes",
-                       "frames": K, "final_kv_tokens": final_len, "llm_steps": llm_steps, "prefetch_encode": not args.no_prefetch,
+                       "frames": K, "final_kv_tokens": final_len, "llm_steps": llm_steps, "prefetch_encode": not args.no_prefetch, "prefetch_frames": args.prefetch_frames,
                        "parallelism": f"replicas{world}"},
             "stream_hbm_roofline": {"algorithmic_llm_bytes": alg_bytes, "frac_of_hbm_peak": round(alg_bytes / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
             "roofline": {"bound": "hbm", "kernel": "gemv16_kernel<KF,EPI_SWIGLU> (gate/up projection + SwiGLU)",

@@ -57,58 +57,59 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs a) {
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int r16 = lane & 15, qd = lane >> 4;
     constexpr int XCH = BM * 8 / 256, WCH = BN * 8 / 256;   // 16-byte chunks per thread per tile
-    uint4 rx[XCH], rw[WCH];
+    constexpr int DEPTH = 4;                                // K tiles in flight (register ring)
+    uint4 rx[DEPTH][XCH], rw[DEPTH][WCH];
 
-    auto load_tile = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < XCH; ++i) {
-            const int id = tid + i * 256, row = id >> 3, c = id & 7;
-            const int m = m0 + row;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (m < a.M) {
-                if (EP == EP_PATCH) {
-                    // im2col on the fly: k = ch*P*P + py*P + px ; 8 consecutive px -> 8 consecutive bytes
-                    const int k = k0 + c * 8;
-                    const int ch = k / (a.P * a.P), rem = k % (a.P * a.P), py = rem / a.P, px = rem % a.P;
-                    const int b = m / a.S, t = m % a.S, gy = t / a.G, gx = t % a.G;
-                    const uint8_t *src = a.frames + (((size_t)b * 3 + ch) * a.R + gy * a.P + py) * a.R + gx * a.P + px;
-                    const uint2 raw = *reinterpret_cast<const uint2 *>(src);
-                    const uint8_t *e = reinterpret_cast<const uint8_t *>(&raw);
-                    f16_t o[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        // frames * rescale_factor, then (x - 0.5) / 0.5 in fp32, cast fp16 (vision_live.py:12)
-                        const float x = (float)e[j] * 0.00392156862745098f;
-                        o[j] = f2h((x - 0.5f) / 0.5f);
-                    }
-                    v = *reinterpret_cast<const uint4 *>(o);
-                } else {
-                    v = *reinterpret_cast<const uint4 *>(a.X + (size_t)m * a.ldx + k0 + c * 8);
-                }
-            }
-            rx[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) {
-            const int id = tid + i * 256, row = id >> 3, c = id & 7;
-            const int n = n0 + row;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (n < a.N) v = *reinterpret_cast<const uint4 *>(a.W + (size_t)n * a.K + k0 + c * 8);
-            rw[i] = v;
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < XCH; ++i) {
-            const int id = tid + i * 256, row = id >> 3, c = id & 7;
-            *reinterpret_cast<uint4 *>(&sX[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]) = rx[i];
-        }
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) {
-            const int id = tid + i * 256, row = id >> 3, c = id & 7;
-            *reinterpret_cast<uint4 *>(&sW[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]) = rw[i];
-        }
-    };
+    // global -> registers for K tile starting at k0, into ring slot `slot` (compile-time after unrolling)
+#define LOAD_TILE(slot, k0_)                                                                                          \
+    do {                                                                                                              \
+        const int k0 = (k0_);                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < XCH; ++i) {                                                             \
+            const int id = tid + i * 256, row = id >> 3, c = id & 7;                                                  \
+            const int m = m0 + row;                                                                                   \
+            uint4 v = make_uint4(0, 0, 0, 0);                                                                         \
+            if (m < a.M) {                                                                                            \
+                if (EP == EP_PATCH) {                                                                                 \
+                    /* im2col on the fly: k = ch*P*P + py*P + px ; 8 consecutive px -> 8 consecutive bytes */        \
+                    const int k = k0 + c * 8;                                                                         \
+                    const int ch = k / (a.P * a.P), rem = k % (a.P * a.P), py = rem / a.P, px = rem % a.P;            \
+                    const int b = m / a.S, t = m % a.S, gy = t / a.G, gx = t % a.G;                                   \
+                    const uint8_t *src = a.frames + (((size_t)b * 3 + ch) * a.R + gy * a.P + py) * a.R + gx * a.P + px; \
+                    const uint2 raw = *reinterpret_cast<const uint2 *>(src);                                          \
+                    const uint8_t *e = reinterpret_cast<const uint8_t *>(&raw);                                       \
+                    f16_t o[8];                                                                                       \
+                    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                   \
+                        /* frames * rescale_factor, then (x - 0.5) / 0.5 in fp32, cast fp16 (vision_live.py:12) */    \
+                        const float x = (float)e[j] * 0.00392156862745098f;                                           \
+                        o[j] = f2h((x - 0.5f) / 0.5f);                                                                \
+                    }                                                                                                 \
+                    v = *reinterpret_cast<const uint4 *>(o);                                                          \
+                } else {                                                                                              \
+                    v = *reinterpret_cast<const uint4 *>(a.X + (size_t)m * a.ldx + k0 + c * 8);                       \
+                }                                                                                                     \
+            }                                                                                                         \
+            rx[slot][i] = v;                                                                                          \
+        }                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < WCH; ++i) {                                                             \
+            const int id = tid + i * 256, row = id >> 3, c = id & 7;                                                  \
+            const int n = n0 + row;                                                                                   \
+            uint4 v = make_uint4(0, 0, 0, 0);                                                                         \
+            if (n < a.N) v = *reinterpret_cast<const uint4 *>(a.W + (size_t)n * a.K + k0 + c * 8);                    \
+            rw[slot][i] = v;                                                                                          \
+        }                                                                                                             \
+    } while (0)
+    // registers (ring slot) -> XOR-swizzled LDS buffer
+#define STORE_TILE(slot, buf)                                                                                         \
+    do {                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < XCH; ++i) {                                                             \
+            const int id = tid + i * 256, row = id >> 3, c = id & 7;                                                  \
+            *reinterpret_cast<uint4 *>(&sX[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]) = rx[slot][i];               \
+        }                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < WCH; ++i) {                                                             \
+            const int id = tid + i * 256, row = id >> 3, c = id & 7;                                                  \
+            *reinterpret_cast<uint4 *>(&sW[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]) = rw[slot][i];               \
+        }                                                                                                             \
+    } while (0)
 
     f32x4 acc[MI][NI];
 #pragma unroll
@@ -119,34 +120,47 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs a) {
     const int nk_all = a.K / GEMM_BK;
     const int nk = (EP == EP_RESID && a.ksplit > 1) ? nk_all / a.ksplit : nk_all;
     const int kbeg = (EP == EP_RESID && a.ksplit > 1) ? blockIdx.z * nk * GEMM_BK : 0;
-    load_tile(kbeg);
-    store_tile(0);
+    // prologue: DEPTH tiles in flight; the first one lands in LDS buffer 0
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j)
+        if (j < nk) LOAD_TILE(j, kbeg + j * GEMM_BK);
+    STORE_TILE(0, 0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kbeg + (kt + 1) * GEMM_BK);
+    // K loop: one global->LDS latency is hidden behind DEPTH-1 iterations of MFMA work.  Ring slot j holds
+    // tile kt (already copied to LDS) on entry of iteration kt = kt0 + j, so it is re-loaded with tile kt+DEPTH.
+    for (int kt0 = 0; kt0 < nk; kt0 += DEPTH) {
 #pragma unroll
-        for (int kk = 0; kk < GEMM_BK / 32; ++kk) {
-            frag_ab fx[MI], fw[NI];
-            const int c = kk * 4 + qd;
+        for (int j = 0; j < DEPTH; ++j) {
+            const int kt = kt0 + j;
+            if (kt < nk) {
+                const int buf = kt & 1;
+                if (kt + DEPTH < nk) LOAD_TILE(j, kbeg + (kt + DEPTH) * GEMM_BK);
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int row = wm * (BM / 2) + i * 16 + r16;
-                fx[i] = *reinterpret_cast<const frag_ab *>(&sX[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]);
+                for (int kk = 0; kk < GEMM_BK / 32; ++kk) {
+                    frag_ab fx[MI], fw[NI];
+                    const int c = kk * 4 + qd;
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        const int row = wm * (BM / 2) + i * 16 + r16;
+                        fx[i] = *reinterpret_cast<const frag_ab *>(&sX[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]);
+                    }
+#pragma unroll
+                    for (int jn = 0; jn < NI; ++jn) {
+                        const int row = wn * (BN / 2) + jn * 16 + r16;
+                        fw[jn] = *reinterpret_cast<const frag_ab *>(&sW[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int jn = 0; jn < NI; ++jn) acc[i][jn] = mfma_f16(fw[jn], fx[i], acc[i][jn]);
+                }
+                if (kt + 1 < nk) STORE_TILE((j + 1) % DEPTH, buf ^ 1);
+                __syncthreads();
             }
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int row = wn * (BN / 2) + j * 16 + r16;
-                fw[j] = *reinterpret_cast<const frag_ab *>(&sW[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]);
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] = mfma_f16(fw[j], fx[i], acc[i][j]);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
-        __syncthreads();
     }
+#undef LOAD_TILE
+#undef STORE_TILE
 
     // epilogue: lane holds out[m][n .. n+3], m = tile row (lane&15), n = tile col (lane>>4)*4
 #pragma unroll

@@ -31,7 +31,8 @@ class StreamTokens:
 
 class LiveInfer:
     def __init__(self, model: LiveModel, tokens: StreamTokens | None = None, tokenizer=None, frame_fps: float = 2,
-                 system_prompt: str = "", prefetch: bool = True, schedule=None, max_new_tokens: int = 100):
+                 system_prompt: str = "", prefetch: bool = True, prefetch_frames: int = 2, schedule=None,
+                 max_new_tokens: int = 100):
         self.model = model
         self.engine = model.engine
         self.tokenizer = tokenizer
@@ -64,6 +65,8 @@ class LiveInfer:
         self._added_stream_generation_ids = list(tokens.stream_generation_ids)
         # device plumbing
         self.prefetch = prefetch
+        self.prefetch_frames = max(1, prefetch_frames)   # frames encoded ahead in ONE batched ViT call (the reference
+        # batches all pending frames the same way, demo/inference.py:105-106); the video is fully loaded up front
         self.schedule = schedule           # frame_idx -> None | (speak: bool, num_tokens: int)  (throughput runs)
         self._main = torch.cuda.current_stream(dev)
         self._enc = torch.cuda.Stream(dev)
@@ -191,10 +194,11 @@ class LiveInfer:
             self.step_log.append((len(self.past_key_values), inputs_embeds.shape[0]))
             eng.llm_step(self.past_key_values, inputs_embeds, want_last=False)
             self._frames_done += 1
-            if self.prefetch and not self.frame_embeds_queue:
-                # frame t+1 is encoded on the encode stream while this Llama step runs; its ~180 launches are
+            nxt = self.last_frame_idx + 1
+            if self.prefetch and not self.frame_embeds_queue and nxt not in self._encoded:
+                # the next frame(s) are encoded on the encode stream while this Llama step runs; the encode is
                 # enqueued here, AFTER the step's own launches, so the host never delays the step
-                self._encode_async(self.last_frame_idx + 1, self.last_frame_idx + 2)
+                self._encode_async(nxt, nxt + self.prefetch_frames)
             # 2. if the same time, response after frame at that time
             if self.query_queue and video_time >= self.query_queue[0][0]:
                 video_time, query = self.query_queue.popleft()
