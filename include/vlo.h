@@ -155,6 +155,9 @@ int vlo_test_gemv(const void *x_dev, const void *W_dev, float *y_dev, int n, int
  * launches, their total milliseconds and the algorithmic bytes of ONE launch. */
 int vlo_profile_enable(vlo_engine *e, int stride);     /* stride <= 0 disables and clears */
 int vlo_profile_read(vlo_engine *e, int64_t *launches, double *total_ms, double *bytes_per_launch);
+/* average elapsed time of an EMPTY event bracket (two hipEventRecord back to back) on `stream`, in microseconds:
+ * the fixed cost every bracket above includes on top of the kernel's own duration */
+int vlo_profile_calibrate(vlo_engine *e, void *stream, double *empty_bracket_us);
 
 /* micro-benchmark of the weight-streaming GEMV on synthetic data (tools/bench_gemv.py): `nbuf` distinct
  * packed weight images are cycled so the 256 MiB Infinity Cache cannot serve re-reads. */

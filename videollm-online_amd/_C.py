@@ -33,7 +33,7 @@ EXPORTS = [
     "vlo_engine_destroy", "vlo_engine_weight_bytes", "vlo_session_create", "vlo_session_reset", "vlo_session_len",
     "vlo_session_destroy", "vlo_visual_embed", "vlo_connector", "vlo_embed", "vlo_llm_step", "vlo_stream_sample",
     "vlo_greedy_generate", "vlo_session_read_kv", "vlo_step_algorithmic_bytes", "vlo_test_gemv",
-    "vlo_profile_enable", "vlo_profile_read", "vlo_bench_gemv", "vlo_debug_read",
+    "vlo_profile_enable", "vlo_profile_read", "vlo_bench_gemv", "vlo_debug_read", "vlo_profile_calibrate",
 ]
 
 
@@ -73,6 +73,7 @@ def lib():
     L.vlo_test_gemv.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.vlo_bench_gemv.argtypes = [i32, i32, i32, i32, i32, i32, C.POINTER(C.c_double)]
     L.vlo_debug_read.argtypes = [vp, i32, vp, i64, vp]
+    L.vlo_profile_calibrate.argtypes = [vp, vp, C.POINTER(C.c_double)]
     L.vlo_profile_enable.argtypes = [vp, i32]
     L.vlo_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     if L.vlo_abi_version() != VLO_ABI_VERSION:

@@ -486,6 +486,34 @@ int vlo_profile_read(vlo_engine *e, int64_t *launches, double *total_ms, double 
     return VLO_OK;
 }
 
+int vlo_profile_calibrate(vlo_engine *e, void *stream, double *empty_bracket_us) {
+    if (!e || !empty_bracket_us) return fail(VLO_E_INVALID, "bad profile_calibrate arguments");
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int N = 64;
+    hipEvent_t a[N], b[N];
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int i = 0; i < N; ++i) {
+        HIP_TRY(hipEventCreate(&a[i]));
+        HIP_TRY(hipEventCreate(&b[i]));
+    }
+    for (int i = 0; i < N; ++i) {
+        HIP_TRY(hipEventRecord(a[i], st));
+        HIP_TRY(hipEventRecord(b[i], st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    double tot = 0.0;
+    for (int i = 0; i < N; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, a[i], b[i]));
+        tot += ms;
+        hipEventDestroy(a[i]);
+        hipEventDestroy(b[i]);
+    }
+    *empty_bracket_us = tot * 1e3 / N;
+    return VLO_OK;
+}
+
 static GemvArgs gemv_args(const PackedLinear &pl, const unsigned short *x, int ldx, int n_rows) {
     GemvArgs a{};
     a.Wp = pl.Wp;

@@ -89,9 +89,11 @@ __global__ __launch_bounds__(NW * 64) void gemv16_kernel(GemvArgs a) {
     const int hd = a.kv.head_dim;
     const int tph = (EPI == EPI_ROPE) ? hd / 16 : 2;           // tiles per head
     const int hp = tph / 2;                                    // rotary pairs of tiles per head
-    const int ngroups = (EPI == EPI_ROPE) ? a.NT / 2 : (a.NT + 1) / 2;
-    auto tile_a = [&](int g) { return (EPI == EPI_ROPE) ? (g / hp) * tph + (g % hp) : 2 * g; };
-    auto tile_b = [&](int g) { return (EPI == EPI_ROPE) ? (g / hp) * tph + (g % hp) + hp : 2 * g + 1; };
+    // a.CT == 1: one tile per group (narrow outputs such as o_proj: NT = 256 tiles -> 256 blocks instead of 128)
+    const bool single = (EPI != EPI_ROPE && EPI != EPI_SWIGLU && a.CT == 1);
+    const int ngroups = (EPI == EPI_ROPE) ? a.NT / 2 : (single ? a.NT : (a.NT + 1) / 2);
+    auto tile_a = [&](int g) { return (EPI == EPI_ROPE) ? (g / hp) * tph + (g % hp) : (single ? g : 2 * g); };
+    auto tile_b = [&](int g) { return (EPI == EPI_ROPE) ? (g / hp) * tph + (g % hp) + hp : (single ? a.NT : 2 * g + 1); };
 
     const frag_ab *wbase = reinterpret_cast<const frag_ab *>(a.Wp) + (size_t)kfw0 * 64 + lane;
     const size_t tile_stride = (size_t)KFtot * 64;
@@ -346,12 +348,21 @@ int gemv_plan(int K, bool allow_ksplit, GemvPlan *p) {
     return -1;
 }
 
-static int groups_of(const GemvArgs &a, int epi) { return epi == EPI_ROPE ? a.NT / 2 : (a.NT + 1) / 2; }
+// groups of two column tiles, or single tiles when pairs would leave CUs idle (pairing is mandatory for the
+// rotary and gate/up epilogues)
+static bool single_tile_groups(const GemvArgs &a, const GemvPlan &p, int epi) {
+    if (epi == EPI_ROPE || epi == EPI_SWIGLU) return false;
+    return ((a.NT + 1) / 2) * p.ksplit < 256;
+}
+static int groups_of(const GemvArgs &a, const GemvPlan &p, int epi) {
+    if (epi == EPI_ROPE) return a.NT / 2;
+    return single_tile_groups(a, p, epi) ? a.NT : (a.NT + 1) / 2;
+}
 
 int gemv_grid_x(const GemvArgs &a, const GemvPlan &p, int epi) {
     static const int kBPC = env_int("VLO_GEMV_BPC", 1);          // resident blocks per CU aimed at
     static const int kCUs = 256;
-    const int ngroups = groups_of(a, epi);
+    const int ngroups = groups_of(a, p, epi);
     int gx = (kCUs * kBPC) / p.ksplit;
     if (gx < 1) gx = 1;
     if (gx > ngroups) gx = ngroups;
@@ -385,7 +396,7 @@ hipError_t gemv_launch(GemvArgs a, const GemvPlan &p, int xsrc, int epi, hipStre
     if (epi != EPI_PARTIAL_F32 && p.ksplit != 1) return hipErrorInvalidValue;
     if (epi == EPI_ROPE && ((a.NT & 1) || (a.kv.head_dim != 64 && a.kv.head_dim != 128))) return hipErrorInvalidValue;
     if (epi == EPI_SWIGLU && (a.NT & 1)) return hipErrorInvalidValue;
-    a.CT = 2;
+    a.CT = single_tile_groups(a, p, epi) ? 1 : 2;
     a.KC = p.KC;
     dim3 grid(gemv_grid_x(a, p, epi), p.ksplit);
     const size_t lds = (size_t)2 * p.NW * 2 * 64 * sizeof(float4) + (16 + (size_t)p.NW * 4 * 16) * sizeof(float);

@@ -142,6 +142,12 @@ class Engine:
         _C.check(_C.lib().vlo_profile_read(self._h, C.byref(n), C.byref(ms), C.byref(b)))
         return n.value, ms.value, b.value
 
+    def profile_calibrate(self, stream=None) -> float:
+        """microseconds an empty HIP-event bracket reads on this stream"""
+        us = C.c_double(0)
+        _C.check(_C.lib().vlo_profile_calibrate(self._h, _stream_handle(stream), C.byref(us)))
+        return us.value
+
     def new_session(self, max_tokens_hint: int = 0) -> Session:
         return Session(self, max_tokens_hint)
 
