@@ -260,3 +260,50 @@ def test_long_context_paging_and_split_kv(name, seed):
             if layer == 0:
                 assert (k == rc.k[0][hh]).float().mean().item() > 0.98
     sess.close(); eng.close()
+
+
+def test_engine_from_checkpoint_with_lora_merge(tmp_path):
+    """Real-checkpoint path: sharded base safetensors + PEFT adapter -> merged on the GPU -> engine; logits match the
+    fp32 oracle run on the merged weights at the usual 3-way tolerance."""
+    import json
+    from safetensors.torch import save_file
+    from videollm_online_amd import checkpoint as CK
+    from videollm_online_amd.engine import Engine, EngineConfig
+    spec = O.LLM_SPECS["toy128"]
+    w = O.init_llm_weights(spec, seed=3)
+    base = {k: v.contiguous() for k, v in w.items() if not k.startswith("connector.")}
+    bdir = tmp_path / "base"; bdir.mkdir()
+    save_file(base, str(bdir / "model.safetensors"))
+    g = torch.Generator().manual_seed(4)
+    ad = {}
+    for k, v in base.items():
+        mod = k[:-len(".weight")]
+        if CK.LORA_TARGETS.search(mod) and v.dim() == 2 and "embed" not in k and "norm" not in k:
+            ad[f"base_model.model.{mod}.lora_A.weight"] = (torch.randn(8, v.shape[1], generator=g) * 0.05).bfloat16()
+            ad[f"base_model.model.{mod}.lora_B.weight"] = (torch.randn(v.shape[0], 8, generator=g) * 0.05).bfloat16()
+    for k, v in w.items():
+        if k.startswith("connector."):
+            ad[f"base_model.model.{k}"] = v.contiguous()
+    adir = tmp_path / "adapter"; adir.mkdir()
+    save_file(ad, str(adir / "adapter_model.safetensors"))
+    json.dump({"r": 8, "lora_alpha": 16}, open(adir / "adapter_config.json", "w"))
+    cfg = EngineConfig(hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size, num_hidden_layers=spec.num_layers,
+                       num_attention_heads=spec.num_heads, num_key_value_heads=spec.num_kv_heads, vocab_size=spec.vocab_size,
+                       rope_theta=spec.rope_theta, rms_norm_eps=spec.rms_eps, vision_hidden_size=spec.vision_hidden_size,
+                       kv_pool_tokens=1024)
+    eng = Engine(cfg)
+    CK.load_engine_weights(eng, str(bdir), str(adir))
+    eng.load_weight("rope.inv_freq", O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+    eng.finalize()
+    merged = dict(CK.iter_llm_weights(str(bdir), str(adir)))
+    assert not torch.equal(merged["lm_head.weight"], w["lm_head.weight"])       # the adapter really changed the weights
+    ref, gold = O.LlamaOracle(spec, merged, torch.bfloat16), O.LlamaOracle(spec, merged, torch.float32)
+    sess = eng.new_session()
+    x = torch.randn(11, spec.hidden_size, generator=g).bfloat16()
+    rl, _ = ref.forward(x, None)
+    gl, _ = gold.forward(x, None)
+    _, allr = eng.llm_step(sess, x.cuda(), want_all=True)
+    torch.cuda.synchronize()
+    e, r, scale = _three_way(allr.cpu(), rl, gl)
+    assert e <= 1.5 * r + 1e-3 * scale, (e, r)
+    sess.close(); eng.close()
