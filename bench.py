@@ -36,6 +36,8 @@ LLM_SHAPES = {
 }
 VIT_SHAPE = dict(hidden_size=1024, intermediate_size=4096, num_layers=24, num_heads=16, image_size=384, patch_size=16)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0       # dense bf16/fp16 MFMA peak (same guide)
+VIT_GFLOP_PER_FRAME = 384.4     # ViT 384 + connector 0.42
 
 
 _T0 = time.time()
@@ -312,6 +314,21 @@ def main():
     n_launch, prof_ms, bytes_per_launch = eng.profile_read()
     eng.profile_enable(0)
     empty_us = eng.profile_calibrate()
+    # encode stage in isolation (HIP events on its own stream): ms/frame and fraction of the dense fp16 MFMA peak
+    vit_ms = None
+    if rank == 0:
+        B = max(1, args.prefetch_frames)
+        enc = torch.cuda.Stream()
+        with torch.cuda.stream(enc):
+            for _ in range(2):
+                eng.visual_embed(frames[:B], stream=enc)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(enc)
+            for _ in range(8):
+                eng.visual_embed(frames[:B], stream=enc)
+            e1.record(enc)
+        enc.synchronize()
+        vit_ms = e0.elapsed_time(e1) / 8 / B
     final_len = len(li.past_key_values)
 
     elapsed = reduce_elapsed_max(dist, elapsed)
@@ -343,6 +360,10 @@ def main():
                                    f"(16-token response every 10th frame + t=0 query), random-init weights at true shapes",
                        "frames": K, "final_kv_tokens": final_len, "llm_steps": llm_steps, "prefetch_encode": not args.no_prefetch, "prefetch_frames": args.prefetch_frames,
                        "parallelism": f"replicas{world}"},
+            "encode_stage": {"batch": max(1, args.prefetch_frames), "ms_per_frame": round(vit_ms, 4),
+                             "tflops": round(VIT_GFLOP_PER_FRAME / vit_ms, 1), "mfma_peak_tflops": MFMA_PEAK_TFLOPS,
+                             "frac_of_mfma_peak": round(VIT_GFLOP_PER_FRAME / vit_ms / MFMA_PEAK_TFLOPS, 4),
+                             "note": "SigLIP-L/16-384 + connector, 384.4 GFLOP/frame (SURVEY.md §8d), fp16 MFMA, measured alone"},
             "stream_hbm_roofline": {"algorithmic_llm_bytes": alg_bytes, "frac_of_hbm_peak": round(alg_bytes / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
             "roofline": {"bound": "hbm", "kernel": "gemv16_kernel<KF,EPI_SWIGLU> (gate/up projection + SwiGLU)",
                          "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

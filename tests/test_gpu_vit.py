@@ -31,7 +31,8 @@ def _engine(spec, vspec, w, vw):
     return e.finalize()
 
 
-@pytest.mark.parametrize("llm,vit,B", [("toy128", "toy", 3), ("toy128", "toy", 1), ("tinyllama-2l", "siglip-l16-384-2l", 2)])
+@pytest.mark.parametrize("llm,vit,B", [("toy128", "toy", 3), ("toy128", "toy", 1), ("tinyllama-2l", "siglip-l16-384-2l", 2),
+                                       ("tinyllama-2l", "siglip-l16-384-2l", 4)])     # B=4 takes the 128x128-tile GEMM path
 def test_visual_embed_parity(llm, vit, B):
     spec, vspec = O.LLM_SPECS[llm], O.VIT_SPECS[vit]
     w = O.init_llm_weights(spec, seed=3)

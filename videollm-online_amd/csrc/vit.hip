@@ -47,7 +47,7 @@ VLO_DEV float rh(float x) { return h2f(f2h(x)); }     // fp16 rounding point
 
 #define GEMM_BK 64
 
-template <int BM, int BN, int EP>
+template <int BM, int BN, int EP, int DEPTH>
 __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs a) {
     constexpr int MI = BM / 32, NI = BN / 32;          // 16x16 tiles per wave along m / n (2x2 waves)
     __shared__ __attribute__((aligned(16))) f16_t sX[2][BM * GEMM_BK];
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs a) {
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int r16 = lane & 15, qd = lane >> 4;
     constexpr int XCH = BM * 8 / 256, WCH = BN * 8 / 256;   // 16-byte chunks per thread per tile
-    constexpr int DEPTH = 4;                                // K tiles in flight (register ring)
+    // DEPTH = K tiles in flight (register ring)
     uint4 rx[DEPTH][XCH], rw[DEPTH][WCH];
 
     // global -> registers for K tile starting at k0, into ring slot `slot` (compile-time after unrolling)
@@ -221,20 +221,16 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs a) {
 template <int EP>
 static hipError_t gemm_launch(GemmArgs a, hipStream_t st) {
     if (a.K % GEMM_BK || (a.N & 3)) return hipErrorInvalidValue;
-    int ks = 1;
-    if (EP == EP_RESID) {
-        // few (M/64 x N/64) tiles at one frame: slice K until ~2 blocks per CU exist
-        const int tiles = ((a.N + 63) / 64) * ((a.M + 63) / 64);
-        const int nk = a.K / GEMM_BK;
-        while (ks < 8 && tiles * ks < 512 && nk % (ks * 2) == 0 && nk / (ks * 2) >= 4) ks *= 2;
-    }
-    a.ksplit = ks;
+    // No split-K: slicing K with fp32 atomics into the residual stream measured no faster at one frame (3.50 vs
+    // 3.57 ms) and makes results depend on the atomic order; 128x128 tiles (4x4 MFMA tiles per wave, 64 KB LDS,
+    // ~200 VGPRs -> one block per CU) measured 1.5-1.9x SLOWER than 64x64 at B = 4..8.  Both stay out.
+    a.ksplit = 1;
     if (a.M <= 32) {
-        dim3 grid((a.N + 63) / 64, (a.M + 31) / 32, ks);
-        hipLaunchKernelGGL((vit_gemm_kernel<32, 64, EP>), grid, dim3(256), 0, st, a);
+        dim3 grid((a.N + 63) / 64, (a.M + 31) / 32, 1);
+        hipLaunchKernelGGL((vit_gemm_kernel<32, 64, EP, 4>), grid, dim3(256), 0, st, a);
     } else {
-        dim3 grid((a.N + 63) / 64, (a.M + 63) / 64, ks);
-        hipLaunchKernelGGL((vit_gemm_kernel<64, 64, EP>), grid, dim3(256), 0, st, a);
+        dim3 grid((a.N + 63) / 64, (a.M + 63) / 64, 1);
+        hipLaunchKernelGGL((vit_gemm_kernel<64, 64, EP, 4>), grid, dim3(256), 0, st, a);
     }
     return hipGetLastError();
 }
