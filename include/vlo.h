@@ -78,7 +78,7 @@ typedef struct vlo_config {
     int32_t pool_h, pool_w;       /* frame_token_pooled */
     /* KV pool: total tokens the paged pool can hold across all sessions */
     int64_t kv_pool_tokens;
-    /* tensor parallel (rank/size of this engine inside a TP group; 0/1 = none) */
+    /* tensor parallel: this engine holds rank tp_rank's shard of a tp_size-way group (0/1 = none); see vlo_tp_* */
     int32_t tp_rank, tp_size;
 } vlo_config;
 
@@ -148,6 +148,29 @@ double vlo_step_algorithmic_bytes(const vlo_engine *e, int64_t Lc, int n);
 /* raw skinny-GEMM entry used by unit tests: y[n,N] (f32) = x[n,K](bf16) @ W[N,K]^T (bf16), n<=16.
  * W_dev is an ordinary row-major device tensor; packs on every call (tests only). */
 int vlo_test_gemv(const void *x_dev, const void *W_dev, float *y_dev, int n, int N, int K, void *stream);
+
+/* ---- tensor parallelism (north_star; new capability — the reference has none) -------------------
+ * Engines created with vlo_config.tp_size = T > 1 / tp_rank = r hold rank r's shard (load_weight still takes the FULL
+ * tensors and slices them).  They are stepped through a group:
+ *   - one process per GPU (torchrun): n_local = 1, `rccl_unique_id` = the 128 bytes produced by vlo_tp_unique_id() on
+ *     rank 0 and broadcast by the host; exchanges are RCCL all-reduce / all-gather on the caller's stream;
+ *   - single process: n_local = T engines on ONE device (logical ranks; validates the sharding without a multi-GPU box),
+ *     `rccl_unique_id` = NULL; exchanges are device kernels.
+ * The tp_* calls mirror vlo_session_* / vlo_llm_step / vlo_stream_sample / vlo_greedy_generate; embeddings and the
+ * vision tower are replicated (use vlo_embed / vlo_visual_embed on any local engine). */
+typedef struct vlo_tp_group vlo_tp_group;
+typedef struct vlo_tp_session vlo_tp_session;
+int  vlo_tp_unique_id(void *out128);
+int  vlo_tp_group_create(vlo_engine **engines, int n_local, const void *rccl_unique_id, vlo_tp_group **out);
+void vlo_tp_group_destroy(vlo_tp_group *g);
+int  vlo_tp_session_create(vlo_tp_group *g, int64_t max_tokens_hint, vlo_tp_session **out);
+int  vlo_tp_session_reset(vlo_tp_session *t);
+int64_t vlo_tp_session_len(const vlo_tp_session *t);
+void vlo_tp_session_destroy(vlo_tp_session *t);
+int  vlo_tp_llm_step(vlo_tp_session *t, const void *embeds_dev, int n, void *last_logits_dev, void *all_logits_dev, void *stream);
+int  vlo_tp_stream_sample(vlo_tp_session *t, float threshold, int interval_id, int64_t *tok_dev, float *p_interval_dev, void *stream);
+int  vlo_tp_greedy_generate(vlo_tp_session *t, const void *embeds_dev, int m, int eos_token_id, int64_t *out_ids_dev, int max_new,
+                            int force_len, int *n_written, void *stream);
 
 /* live kernel timing for bench.py's roofline: when enabled, every `stride`-th launch of the dominant
  * kernel (the gate/up weight-streaming GEMV, gemv16_kernel<KF,SWIGLU>) is bracketed by HIP events on the

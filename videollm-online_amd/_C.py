@@ -34,6 +34,8 @@ EXPORTS = [
     "vlo_session_destroy", "vlo_visual_embed", "vlo_connector", "vlo_embed", "vlo_llm_step", "vlo_stream_sample",
     "vlo_greedy_generate", "vlo_session_read_kv", "vlo_step_algorithmic_bytes", "vlo_test_gemv",
     "vlo_profile_enable", "vlo_profile_read", "vlo_bench_gemv", "vlo_debug_read", "vlo_profile_calibrate",
+    "vlo_tp_unique_id", "vlo_tp_group_create", "vlo_tp_group_destroy", "vlo_tp_session_create", "vlo_tp_session_reset",
+    "vlo_tp_session_len", "vlo_tp_session_destroy", "vlo_tp_llm_step", "vlo_tp_stream_sample", "vlo_tp_greedy_generate",
 ]
 
 
@@ -74,6 +76,19 @@ def lib():
     L.vlo_bench_gemv.argtypes = [i32, i32, i32, i32, i32, i32, C.POINTER(C.c_double)]
     L.vlo_debug_read.argtypes = [vp, i32, vp, i64, vp]
     L.vlo_profile_calibrate.argtypes = [vp, vp, C.POINTER(C.c_double)]
+    L.vlo_tp_unique_id.argtypes = [vp]
+    L.vlo_tp_group_create.argtypes = [C.POINTER(vp), i32, vp, C.POINTER(vp)]
+    L.vlo_tp_group_destroy.argtypes = [vp]
+    L.vlo_tp_group_destroy.restype = None
+    L.vlo_tp_session_create.argtypes = [vp, i64, C.POINTER(vp)]
+    L.vlo_tp_session_reset.argtypes = [vp]
+    L.vlo_tp_session_len.argtypes = [vp]
+    L.vlo_tp_session_len.restype = i64
+    L.vlo_tp_session_destroy.argtypes = [vp]
+    L.vlo_tp_session_destroy.restype = None
+    L.vlo_tp_llm_step.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.vlo_tp_stream_sample.argtypes = [vp, C.c_float, i32, vp, vp, vp]
+    L.vlo_tp_greedy_generate.argtypes = [vp, vp, i32, i32, vp, i32, i32, C.POINTER(i32), vp]
     L.vlo_profile_enable.argtypes = [vp, i32]
     L.vlo_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     if L.vlo_abi_version() != VLO_ABI_VERSION:

@@ -9,7 +9,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvlo.so")
-SOURCES = ["gemv.hip", "llm_ops.hip", "vit.hip", "engine.hip"]
+SOURCES = ["gemv.hip", "llm_ops.hip", "vit.hip", "engine.hip", "tp.hip"]
 HEADERS = ["common.cuh", "gemv.h", "llm_ops.h", "vit.h", "engine.h", os.path.join("..", "..", "include", "vlo.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
@@ -48,7 +48,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {s}:\n{out}")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", LIB]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")

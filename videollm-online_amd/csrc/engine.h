@@ -34,6 +34,10 @@ struct vlo_engine {
     vlo_config cfg{};
     int device = 0;
     int head_dim = 0;
+    // tensor-parallel shard of this engine (== the global dims when tp_size == 1): q heads, kv heads, MLP columns,
+    // vocabulary rows owned by this rank (HF tp plan: q/k/v/gate/up column-wise, o/down row-wise, lm_head column-wise)
+    int tp_rank = 0, tp_size = 1;
+    int nh_l = 0, nkv_l = 0, I_l = 0, V_l = 0;
     bool finalized = false;
     bool has_connector = false;
     std::map<std::string, RawTensor> raw;      // row-major weights staged on the device until finalize
@@ -75,10 +79,17 @@ struct vlo_session {
     float *part_o = nullptr, *part_ml = nullptr, *partial = nullptr;
     float *sq[2] = {nullptr, nullptr};          // row sum-of-squares partials handed from EPI_RESID to XSRC_NORM
     unsigned short *logits = nullptr, *last_logits = nullptr;
+    unsigned short *logits_local = nullptr;      // TP: this rank's vocabulary shard [16][V_l]
+    float *partial_o = nullptr;                  // TP: o_proj partial sums [16][H] awaiting the all-reduce
     int64_t *tok = nullptr;
     int64_t *host_tok = nullptr;
     int *page_table = nullptr, *host_pt = nullptr;
 };
 
 int dev_alloc(void **p, size_t bytes);
+// helpers shared with tp.hip
+struct KvGeom;
+int ensure_pages(vlo_session *s, int64_t new_len, hipStream_t st);
+GemvArgs gemv_args(const PackedLinear &pl, const unsigned short *x, int ldx, int n_rows);
+KvGeom kv_geom(const vlo_session *s);
 int vlo_fail(int code, const std::string &msg);   // sets the thread-local error string, returns code

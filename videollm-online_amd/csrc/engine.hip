@@ -87,12 +87,24 @@ int vlo_engine_create(const vlo_config *cfg, int device, vlo_engine **out) {
     if (hd != 64 && hd != 128) return fail(VLO_E_UNSUPPORTED, "head_dim must be 64 or 128");
     if ((cfg->hidden_size & 31) || (cfg->intermediate_size & 31) || (cfg->vocab_size & 3))
         return fail(VLO_E_UNSUPPORTED, "hidden/intermediate must be multiples of 32, vocab of 4");
-    if (cfg->tp_size > 1) return fail(VLO_E_UNSUPPORTED, "tensor parallel engines are not built in this round");
+    const int T = cfg->tp_size > 1 ? cfg->tp_size : 1;
+    if (T > 1) {
+        if (cfg->tp_rank < 0 || cfg->tp_rank >= T) return fail(VLO_E_INVALID, "tp_rank out of range");
+        if (cfg->num_kv_heads % T || cfg->num_heads % T || cfg->intermediate_size % (T * 32) || cfg->vocab_size % (T * 16))
+            return fail(VLO_E_UNSUPPORTED, "tp_size must divide kv heads, heads, intermediate_size/32 and vocab_size/16");
+        if (T > 8) return fail(VLO_E_UNSUPPORTED, "tp_size > 8");
+    }
     HIP_TRY(hipSetDevice(device));
     vlo_engine *e = new vlo_engine();
     e->cfg = *cfg;
     e->device = device;
     e->head_dim = hd;
+    e->tp_size = T;
+    e->tp_rank = T > 1 ? cfg->tp_rank : 0;
+    e->nh_l = cfg->num_heads / T;
+    e->nkv_l = cfg->num_kv_heads / T;
+    e->I_l = cfg->intermediate_size / T;
+    e->V_l = cfg->vocab_size / T;
     if (e->cfg.kv_pool_tokens <= 0) e->cfg.kv_pool_tokens = 16384;
     *out = e;
     return VLO_OK;
@@ -162,13 +174,16 @@ static int take(vlo_engine *e, const std::string &name, std::vector<int64_t> sha
     return VLO_OK;
 }
 
-// pack a [N][K] bf16 linear into dst tiles (see gemv.hip)
-static int pack_into(vlo_engine *e, const std::string &name, int N, int K, void *dst, int tile_stride, int tile_offset) {
+// pack rows [row0, row0+N) x columns [col0, col0+K) of the full bf16 linear `name` [Nfull][Kfull] into dst tiles
+// (see gemv.hip); the slice is this rank's tensor-parallel shard (the whole matrix when tp_size == 1)
+static int pack_into(vlo_engine *e, const std::string &name, int Nfull, int Kfull, int row0, int N, int col0, int K, void *dst,
+                     int tile_stride, int tile_offset) {
     RawTensor t;
-    int rc = take(e, name, {N, K}, &t);
+    int rc = take(e, name, {Nfull, Kfull}, &t);
     if (rc) return rc;
     const int NT = (N + 15) / 16;
-    HIP_TRY(pack_weight_launch(t.ptr, dst, N, K, NT, tile_stride, tile_offset, 0));
+    const unsigned short *src = (const unsigned short *)t.ptr + (size_t)row0 * Kfull + col0;
+    HIP_TRY(pack_weight_launch(src, dst, N, K, Kfull, NT, tile_stride, tile_offset, 0));
     return VLO_OK;
 }
 
@@ -209,49 +224,52 @@ int vlo_engine_finalize(vlo_engine *e) {
     if (e->finalized) return VLO_OK;
     HIP_TRY(hipSetDevice(e->device));
     const vlo_config &c = e->cfg;
-    const int H = c.hidden_size, I = c.intermediate_size, hd = e->head_dim, nh = c.num_heads, nkv = c.num_kv_heads;
-    const int Nq = nh * hd, Nkv = nkv * hd, Nqkv = Nq + 2 * Nkv;
+    const int H = c.hidden_size, hd = e->head_dim;
+    const int r = e->tp_rank;
+    const int Ifull = c.intermediate_size, I = e->I_l;                 // this rank's MLP columns
+    const int NqF = c.num_heads * hd, NkvF = c.num_kv_heads * hd;       // full projection widths
+    const int Nq = e->nh_l * hd, Nkv = e->nkv_l * hd, Nqkv = Nq + 2 * Nkv;   // this rank's heads
     int rc;
     e->layers.resize(c.num_layers);
     for (int l = 0; l < c.num_layers; ++l) {
         LayerWeights &L = e->layers[l];
         const std::string p = "model.layers." + std::to_string(l) + ".";
         if ((rc = make_linear(e, &L.qkv, Nqkv, H, false))) return rc;
-        if ((rc = pack_into(e, p + "self_attn.q_proj.weight", Nq, H, L.qkv.Wp, 1, 0))) return rc;
-        if ((rc = pack_into(e, p + "self_attn.k_proj.weight", Nkv, H, L.qkv.Wp, 1, Nq / 16))) return rc;
-        if ((rc = pack_into(e, p + "self_attn.v_proj.weight", Nkv, H, L.qkv.Wp, 1, (Nq + Nkv) / 16))) return rc;
-        if ((rc = make_linear(e, &L.o, H, Nq, false))) return rc;
-        if ((rc = pack_into(e, p + "self_attn.o_proj.weight", H, Nq, L.o.Wp, 1, 0))) return rc;
+        if ((rc = pack_into(e, p + "self_attn.q_proj.weight", NqF, H, r * Nq, Nq, 0, H, L.qkv.Wp, 1, 0))) return rc;
+        if ((rc = pack_into(e, p + "self_attn.k_proj.weight", NkvF, H, r * Nkv, Nkv, 0, H, L.qkv.Wp, 1, Nq / 16))) return rc;
+        if ((rc = pack_into(e, p + "self_attn.v_proj.weight", NkvF, H, r * Nkv, Nkv, 0, H, L.qkv.Wp, 1, (Nq + Nkv) / 16))) return rc;
+        if ((rc = make_linear(e, &L.o, H, Nq, e->tp_size > 1))) return rc;          // TP: fp32 partial sums, all-reduced
+        if ((rc = pack_into(e, p + "self_attn.o_proj.weight", H, NqF, 0, H, r * Nq, Nq, L.o.Wp, 1, 0))) return rc;
         if ((rc = make_linear(e, &L.gate_up, 2 * I, H, false))) return rc;       // SwiGLU epilogue needs whole K
-        if (I % 16) return fail(VLO_E_UNSUPPORTED, "intermediate_size must be a multiple of 16");
-        if ((rc = pack_into(e, p + "mlp.gate_proj.weight", I, H, L.gate_up.Wp, 2, 0))) return rc;
-        if ((rc = pack_into(e, p + "mlp.up_proj.weight", I, H, L.gate_up.Wp, 2, 1))) return rc;
+        if (I % 16) return fail(VLO_E_UNSUPPORTED, "intermediate_size (per rank) must be a multiple of 16");
+        if ((rc = pack_into(e, p + "mlp.gate_proj.weight", Ifull, H, r * I, I, 0, H, L.gate_up.Wp, 2, 0))) return rc;
+        if ((rc = pack_into(e, p + "mlp.up_proj.weight", Ifull, H, r * I, I, 0, H, L.gate_up.Wp, 2, 1))) return rc;
         if ((rc = make_linear(e, &L.down, H, I, true))) return rc;
-        if ((rc = pack_into(e, p + "mlp.down_proj.weight", H, I, L.down.Wp, 1, 0))) return rc;
+        if ((rc = pack_into(e, p + "mlp.down_proj.weight", H, Ifull, 0, H, r * I, I, L.down.Wp, 1, 0))) return rc;
         if ((rc = take_vec(e, p + "input_layernorm.weight", H, &L.ln_in))) return rc;
         if ((rc = take_vec(e, p + "post_attention_layernorm.weight", H, &L.ln_post))) return rc;
         HIP_TRY(hipDeviceSynchronize());
-        for (const char *s : {"self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
-                              "self_attn.o_proj.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight"})
-            drop_raw(e, p + s);
+        for (const char *sfx : {"self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
+                                "self_attn.o_proj.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight"})
+            drop_raw(e, p + sfx);
     }
     if ((rc = take_vec(e, "model.norm.weight", H, &e->norm_w))) return rc;
-    if ((rc = make_linear(e, &e->lm_head, c.vocab_size, H, false))) return rc;
-    if ((rc = pack_into(e, "lm_head.weight", c.vocab_size, H, e->lm_head.Wp, 1, 0))) return rc;
-    {   // embedding table stays row-major (gather)
+    if ((rc = make_linear(e, &e->lm_head, e->V_l, H, false))) return rc;
+    if ((rc = pack_into(e, "lm_head.weight", c.vocab_size, H, r * e->V_l, e->V_l, 0, H, e->lm_head.Wp, 1, 0))) return rc;
+    {   // embedding table stays row-major (gather), replicated on every rank
         RawTensor t;
         if ((rc = take(e, "model.embed_tokens.weight", {c.vocab_size, H}, &t))) return rc;
         e->embed = t.ptr;
         e->owned.push_back(t.ptr);
         e->raw.erase("model.embed_tokens.weight");
     }
-    // connector (optional: an LLM-only engine may omit it)
+    // connector (optional: an LLM-only engine may omit it); replicated
     if (e->raw.count("connector.0.weight")) {
         const int Hv = c.vision_hidden_size;
         if ((rc = make_linear(e, &e->conn0, H, Hv, false))) return rc;
-        if ((rc = pack_into(e, "connector.0.weight", H, Hv, e->conn0.Wp, 1, 0))) return rc;
+        if ((rc = pack_into(e, "connector.0.weight", H, Hv, 0, H, 0, Hv, e->conn0.Wp, 1, 0))) return rc;
         if ((rc = make_linear(e, &e->conn2, H, H, false))) return rc;
-        if ((rc = pack_into(e, "connector.2.weight", H, H, e->conn2.Wp, 1, 0))) return rc;
+        if ((rc = pack_into(e, "connector.2.weight", H, H, 0, H, 0, H, e->conn2.Wp, 1, 0))) return rc;
         if ((rc = take_vec(e, "connector.0.bias", H, &e->conn0_b))) return rc;
         if ((rc = take_vec(e, "connector.2.bias", H, &e->conn2_b))) return rc;
         e->has_connector = true;
@@ -297,7 +315,7 @@ int vlo_engine_finalize(vlo_engine *e) {
     }
     // KV pool
     {
-        e->page_elems = (int64_t)nkv * VLO_PAGE_TOKENS * hd;
+        e->page_elems = (int64_t)e->nkv_l * VLO_PAGE_TOKENS * hd;
         e->layer_stride = e->page_elems * e->pool_pages;
         const size_t bytes = (size_t)e->layer_stride * c.num_layers * 2;
         if ((rc = dev_alloc(&e->k_pool, bytes))) return rc;
@@ -337,7 +355,7 @@ int vlo_session_create(vlo_engine *e, int64_t max_tokens_hint, vlo_session **out
     HIP_TRY(hipSetDevice(e->device));
     (void)max_tokens_hint;
     const vlo_config &c = e->cfg;
-    const int H = c.hidden_size, I = c.intermediate_size, hd = e->head_dim, nh = c.num_heads, nkv = c.num_kv_heads;
+    const int H = c.hidden_size, I = e->I_l, hd = e->head_dim, nh = e->nh_l, nkv = e->nkv_l;
     const int Nqkv = (nh + 2 * nkv) * hd;
     vlo_session *s = new vlo_session();
     s->e = e;
@@ -364,6 +382,12 @@ int vlo_session_create(vlo_engine *e, int64_t max_tokens_hint, vlo_session **out
     A((void **)&s->part_o, (size_t)VLO_MAX_SPLITS * nh * 16 * hd * 4);
     A((void **)&s->part_ml, (size_t)VLO_MAX_SPLITS * nh * 16 * 2 * 4);
     A((void **)&s->logits, (size_t)16 * c.vocab_size * 2);
+    if (e->tp_size > 1) {
+        int ks_o = 1;
+        for (auto &L : e->layers) ks_o = std::max(ks_o, L.o.plan.ksplit);
+        A((void **)&s->logits_local, (size_t)16 * e->V_l * 2);
+        A((void **)&s->partial_o, (size_t)ks_o * 16 * H * 4);
+    }
     A((void **)&s->tok, 64);
     A((void **)&s->emb1, (size_t)32 * H * 2);
     A((void **)&s->page_table, (size_t)e->pool_pages * 4);
@@ -404,7 +428,7 @@ void vlo_session_destroy(vlo_session *s) {
     delete s;
 }
 
-static int ensure_pages(vlo_session *s, int64_t new_len, hipStream_t st) {
+int ensure_pages(vlo_session *s, int64_t new_len, hipStream_t st) {
     vlo_engine *e = s->e;
     if (new_len > e->max_positions) return fail(VLO_E_NOMEM, "sequence exceeds kv_pool_tokens");
     const int need = (int)((new_len + VLO_PAGE_TOKENS - 1) / VLO_PAGE_TOKENS);
@@ -424,7 +448,7 @@ static int ensure_pages(vlo_session *s, int64_t new_len, hipStream_t st) {
     return VLO_OK;
 }
 
-static KvGeom kv_geom(const vlo_session *s) {
+KvGeom kv_geom(const vlo_session *s) {
     const vlo_engine *e = s->e;
     KvGeom g;
     g.k_pool = (unsigned short *)e->k_pool;
@@ -432,7 +456,7 @@ static KvGeom kv_geom(const vlo_session *s) {
     g.page_table = s->page_table;
     g.layer_stride = e->layer_stride;
     g.page_elems = e->page_elems;
-    g.num_kv_heads = e->cfg.num_kv_heads;
+    g.num_kv_heads = e->nkv_l;
     g.head_dim = e->head_dim;
     return g;
 }
@@ -514,7 +538,7 @@ int vlo_profile_calibrate(vlo_engine *e, void *stream, double *empty_bracket_us)
     return VLO_OK;
 }
 
-static GemvArgs gemv_args(const PackedLinear &pl, const unsigned short *x, int ldx, int n_rows) {
+GemvArgs gemv_args(const PackedLinear &pl, const unsigned short *x, int ldx, int n_rows) {
     GemvArgs a{};
     a.Wp = pl.Wp;
     a.x = x;
@@ -597,6 +621,7 @@ static int run_chunk(vlo_session *s, const unsigned short *src, int m, bool want
 int vlo_llm_step(vlo_session *s, const void *embeds_dev, int n, void *last_logits_dev, void *all_logits_dev, void *stream) {
     if (!s || !embeds_dev || n <= 0) return fail(VLO_E_INVALID, "bad llm_step arguments");
     vlo_engine *e = s->e;
+    if (e->tp_size > 1) return fail(VLO_E_STATE, "tensor-parallel engine: step it through vlo_tp_llm_step");
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t st = (hipStream_t)stream;
     const int H = e->cfg.hidden_size, V = e->cfg.vocab_size;
@@ -708,7 +733,7 @@ int vlo_visual_embed(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_
 }
 
 int vlo_session_read_kv(vlo_session *s, int layer, int which, int kv_head, int64_t t0, int64_t t1, void *dst_dev, void *stream) {
-    if (!s || !dst_dev || layer < 0 || layer >= s->e->cfg.num_layers || kv_head < 0 || kv_head >= s->e->cfg.num_kv_heads ||
+    if (!s || !dst_dev || layer < 0 || layer >= s->e->cfg.num_layers || kv_head < 0 || kv_head >= s->e->nkv_l ||
         t0 < 0 || t1 > s->len || t1 < t0)
         return fail(VLO_E_INVALID, "bad read_kv arguments");
     HIP_TRY(hipSetDevice(s->e->device));
@@ -729,7 +754,7 @@ int vlo_test_gemv(const void *x_dev, const void *W_dev, float *y_dev, int n, int
     HIP_TRY(hipMalloc((void **)&P, (size_t)plan.ksplit * 16 * NT * 16 * 4));
     HIP_TRY(hipMemsetAsync(xp, 0, (size_t)32 * K * 2, st));
     HIP_TRY(hipMemcpyAsync(xp, x_dev, (size_t)n * K * 2, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(pack_weight_launch(W_dev, Wp, N, K, NT, 1, 0, st));
+    HIP_TRY(pack_weight_launch(W_dev, Wp, N, K, K, NT, 1, 0, st));
     GemvArgs a{};
     a.Wp = Wp; a.x = (const unsigned short *)xp; a.out_f32 = P;
     a.K = K; a.ldx = K; a.ldo = NT * 16; a.NT = NT; a.N_valid = N; a.n_rows = n;

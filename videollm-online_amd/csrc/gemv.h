@@ -53,6 +53,6 @@ int gemv_plan(int K, bool allow_ksplit, GemvPlan *p);
 // grid.x the launch will use (= number of sq_out partial rows an EPI_RESID launch writes)
 int gemv_grid_x(const GemvArgs &a, const GemvPlan &p, int epi);
 hipError_t gemv_launch(GemvArgs a, const GemvPlan &p, int xsrc, int epi, hipStream_t st);
-// source tiles [0,NT) of row-major W[N_valid][K] -> packed tiles t*tile_stride + tile_offset of Wp
-hipError_t pack_weight_launch(const void *W, void *Wp, int N_valid, int K, int NT, int tile_stride, int tile_offset,
+// source tiles [0,NT) of row-major W[N_valid][K] (row stride ldw elements) -> packed tiles t*tile_stride + tile_offset of Wp
+hipError_t pack_weight_launch(const void *W, void *Wp, int N_valid, int K, int ldw, int NT, int tile_stride, int tile_offset,
                               hipStream_t st);

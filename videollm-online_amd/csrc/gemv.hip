@@ -40,7 +40,8 @@
 // Source tile t lands at destination tile t*tile_stride + tile_offset (used to concatenate q/k/v and
 // to interleave gate/up 16-row tiles for the SwiGLU epilogue).
 // ------------------------------------------------------------------------------------
-__global__ void pack_weight_kernel(const bf16_t *__restrict__ W, uint4 *__restrict__ Wp, int N_valid, int K,
+// `ldw` = source row stride in elements (>= K): lets a tensor-parallel rank pack a column slice of W.
+__global__ void pack_weight_kernel(const bf16_t *__restrict__ W, uint4 *__restrict__ Wp, int N_valid, int K, int ldw,
                                    int NT, int KFtot, int tile_stride, int tile_offset) {
     const size_t total = (size_t)NT * KFtot * 64;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -51,7 +52,7 @@ __global__ void pack_weight_kernel(const bf16_t *__restrict__ W, uint4 *__restri
         const int n = tile * 16 + (lane & 15);
         const int k = kf * 32 + (lane >> 4) * 8;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (n < N_valid) v = *reinterpret_cast<const uint4 *>(W + (size_t)n * K + k);
+        if (n < N_valid) v = *reinterpret_cast<const uint4 *>(W + (size_t)n * ldw + k);
         Wp[((size_t)(tile * tile_stride + tile_offset) * KFtot + kf) * 64 + lane] = v;
     }
 }
@@ -330,7 +331,7 @@ static int env_int(const char *name, int dflt) {
 
 struct NwKf { int nw, kf; };
 // (waves per block, fragments per wave per chunk) combinations that are instantiated, in preference order
-static const NwKf kCombos[] = {{8, 16}, {8, 14}, {8, 11}, {8, 8}, {8, 4}, {8, 2}, {8, 1}, {4, 11}, {4, 1}, {2, 11}, {1, 1}};
+static const NwKf kCombos[] = {{8, 16}, {8, 14}, {8, 11}, {8, 8}, {8, 4}, {8, 2}, {8, 1}, {4, 14}, {4, 11}, {4, 1}, {2, 11}, {1, 1}};
 
 int gemv_plan(int K, bool allow_ksplit, GemvPlan *p) {
     if (K <= 0 || (K & 31)) return -1;
@@ -403,18 +404,18 @@ hipError_t gemv_launch(GemvArgs a, const GemvPlan &p, int xsrc, int epi, hipStre
 #define VLO_CASE(NW_, KF_) \
     if (p.NW == NW_ && p.KF == KF_) return launch_variant<KF_, NW_>(a, xsrc, epi, grid, lds, st);
     VLO_CASE(8, 16) VLO_CASE(8, 14) VLO_CASE(8, 11) VLO_CASE(8, 8) VLO_CASE(8, 4) VLO_CASE(8, 2) VLO_CASE(8, 1)
-    VLO_CASE(4, 11) VLO_CASE(4, 1) VLO_CASE(2, 11) VLO_CASE(1, 1)
+    VLO_CASE(4, 14) VLO_CASE(4, 11) VLO_CASE(4, 1) VLO_CASE(2, 11) VLO_CASE(1, 1)
 #undef VLO_CASE
     return hipErrorInvalidValue;
 }
 
-hipError_t pack_weight_launch(const void *W, void *Wp, int N_valid, int K, int NT, int tile_stride, int tile_offset,
+hipError_t pack_weight_launch(const void *W, void *Wp, int N_valid, int K, int ldw, int NT, int tile_stride, int tile_offset,
                               hipStream_t st) {
     const int KFtot = K >> 5;
     const size_t total = (size_t)NT * KFtot * 64;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 65535) blocks = 65535;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, st, (const bf16_t *)W, (uint4 *)Wp, N_valid, K, NT,
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, st, (const bf16_t *)W, (uint4 *)Wp, N_valid, K, ldw, NT,
                        KFtot, tile_stride, tile_offset);
     return hipGetLastError();
 }

@@ -1,0 +1,333 @@
+// tp.hip — tensor-parallel Llama step (north_star: shard the attention / MLP projections across the GPUs of a
+// node, all-reduce over xGMI).  New capability: the reference has no TP and no collectives.
+//
+// Sharding (HF's plan, HF:models/llama/configuration_llama.py:49-57): q/k/v and gate/up column-wise (a rank owns
+// nh/T query heads, nkv/T kv heads and I/T MLP columns, and ONLY its kv heads' pages of the KV cache), o_proj and
+// down_proj row-wise (fp32 partial sums of [n, H]), lm_head column-wise (a vocabulary shard).  Per decoder layer
+// there are exactly two exchanges — all-reduce(sum) of the o_proj and of the down_proj partials, 16*H*4 B = 256 KiB
+// fp32 at most (n*H*4 when the projection is not K-split) — plus one all-gather of the last-row logits shard per step.
+// RMSNorm, residual stream, embeddings, ViT + connector and the samplers are replicated.
+//
+// A "group" owns this process's local ranks: all T of them in single-process mode (several logical ranks driven in
+// lock-step by one host thread; on ONE device this is how the sharding arithmetic is validated without a multi-GPU
+// box — exchanges are a sum / copy kernel), or exactly one in the one-process-per-GPU mode (exchanges are RCCL
+// ncclAllReduce / ncclAllGather on the step's stream, communicator bootstrapped from a unique id that the host
+// broadcasts with torch.distributed).  librccl is dlopen'ed so libvlo.so has no link-time dependency on it.
+#include <dlfcn.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/vlo.h"
+#include "common.cuh"
+#include "engine.h"
+#include "gemv.h"
+#include "llm_ops.h"
+
+#define TP_TRY(expr)                                                                                        \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess) return vlo_fail(VLO_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+// ---- RCCL, resolved at run time -----------------------------------------------------------------------------
+struct NcclUid { char internal[128]; };
+typedef int (*fn_ncclGetUniqueId)(NcclUid *);
+typedef int (*fn_ncclCommInitRank)(void **, int, NcclUid, int);
+typedef int (*fn_ncclAllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef int (*fn_ncclAllGather)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef int (*fn_ncclCommDestroy)(void *);
+enum { kNcclInt8 = 0, kNcclFloat32 = 7, kNcclSum = 0 };
+
+struct Rccl {
+    void *dl = nullptr;
+    fn_ncclGetUniqueId GetUniqueId = nullptr;
+    fn_ncclCommInitRank CommInitRank = nullptr;
+    fn_ncclAllReduce AllReduce = nullptr;
+    fn_ncclAllGather AllGather = nullptr;
+    fn_ncclCommDestroy CommDestroy = nullptr;
+};
+static Rccl g_rccl;
+
+static int rccl_load() {
+    if (g_rccl.dl) return VLO_OK;
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void *dl = nullptr;
+    for (const char *n : names)
+        if ((dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!dl) return vlo_fail(VLO_E_UNSUPPORTED, std::string("cannot dlopen librccl: ") + dlerror());
+    g_rccl.GetUniqueId = (fn_ncclGetUniqueId)dlsym(dl, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (fn_ncclCommInitRank)dlsym(dl, "ncclCommInitRank");
+    g_rccl.AllReduce = (fn_ncclAllReduce)dlsym(dl, "ncclAllReduce");
+    g_rccl.AllGather = (fn_ncclAllGather)dlsym(dl, "ncclAllGather");
+    g_rccl.CommDestroy = (fn_ncclCommDestroy)dlsym(dl, "ncclCommDestroy");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather || !g_rccl.CommDestroy)
+        return vlo_fail(VLO_E_UNSUPPORTED, "librccl lacks an expected symbol");
+    g_rccl.dl = dl;
+    return VLO_OK;
+}
+
+// ---- group / session ----------------------------------------------------------------------------------------
+struct vlo_tp_group {
+    std::vector<vlo_engine *> eng;     // local ranks, consecutive tp_rank values
+    int tp_size = 1;
+    void *comm = nullptr;              // RCCL communicator (one-process-per-GPU mode)
+};
+struct vlo_tp_session {
+    vlo_tp_group *g = nullptr;
+    std::vector<vlo_session *> ss;     // one KV shard per local rank
+    unsigned short *gather_tmp = nullptr;   // [T][16][V_l] receive buffer of the logits all-gather
+};
+
+struct PtrList { float *p[8]; int n; };
+__global__ void tp_sum_kernel(PtrList L, size_t count) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int r = 0; r < L.n; ++r) s += L.p[r][i];
+        for (int r = 0; r < L.n; ++r) L.p[r][i] = s;
+    }
+}
+
+int vlo_tp_unique_id(void *out128) {
+    if (!out128) return vlo_fail(VLO_E_INVALID, "null unique id buffer");
+    int rc = rccl_load();
+    if (rc) return rc;
+    NcclUid id;
+    if (g_rccl.GetUniqueId(&id) != 0) return vlo_fail(VLO_E_HIP, "ncclGetUniqueId failed");
+    memcpy(out128, &id, sizeof(id));
+    return VLO_OK;
+}
+
+int vlo_tp_group_create(vlo_engine **engines, int n_local, const void *rccl_unique_id, vlo_tp_group **out) {
+    if (!engines || n_local <= 0 || !out) return vlo_fail(VLO_E_INVALID, "bad tp_group_create arguments");
+    const int T = engines[0]->tp_size;
+    for (int i = 0; i < n_local; ++i) {
+        if (!engines[i] || !engines[i]->finalized) return vlo_fail(VLO_E_STATE, "tp engines must be finalized");
+        if (engines[i]->tp_size != T || engines[i]->tp_rank != engines[0]->tp_rank + i)
+            return vlo_fail(VLO_E_INVALID, "local engines must carry consecutive tp_rank values of one tp_size");
+    }
+    if (n_local != T && n_local != 1) return vlo_fail(VLO_E_INVALID, "a process drives either all ranks or exactly one");
+    if (n_local == T)
+        for (int i = 1; i < T; ++i)
+            if (engines[i]->device != engines[0]->device)
+                return vlo_fail(VLO_E_UNSUPPORTED, "single-process groups exchange through device kernels and must share one device; "
+                                                   "use one process per GPU (RCCL) across devices");
+    vlo_tp_group *g = new vlo_tp_group();
+    g->eng.assign(engines, engines + n_local);
+    g->tp_size = T;
+    if (n_local == 1 && T > 1) {
+        if (!rccl_unique_id) { delete g; return vlo_fail(VLO_E_INVALID, "one-process-per-GPU groups need the RCCL unique id"); }
+        int rc = rccl_load();
+        if (rc) { delete g; return rc; }
+        NcclUid id;
+        memcpy(&id, rccl_unique_id, sizeof(id));
+        if (hipSetDevice(engines[0]->device) != hipSuccess || g_rccl.CommInitRank(&g->comm, T, id, engines[0]->tp_rank) != 0) {
+            delete g;
+            return vlo_fail(VLO_E_HIP, "ncclCommInitRank failed");
+        }
+    }
+    *out = g;
+    return VLO_OK;
+}
+
+void vlo_tp_group_destroy(vlo_tp_group *g) {
+    if (!g) return;
+    if (g->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(g->comm);
+    delete g;
+}
+
+int vlo_tp_session_create(vlo_tp_group *g, int64_t max_tokens_hint, vlo_tp_session **out) {
+    if (!g || !out) return vlo_fail(VLO_E_INVALID, "bad tp_session_create arguments");
+    vlo_tp_session *t = new vlo_tp_session();
+    t->g = g;
+    for (vlo_engine *e : g->eng) {
+        vlo_session *s = nullptr;
+        int rc = vlo_session_create(e, max_tokens_hint, &s);
+        if (rc) { vlo_tp_session_destroy(t); return rc; }
+        t->ss.push_back(s);
+    }
+    vlo_engine *e0 = g->eng[0];
+    if (dev_alloc((void **)&t->gather_tmp, (size_t)g->tp_size * 16 * e0->V_l * 2)) { vlo_tp_session_destroy(t); return VLO_E_HIP; }
+    *out = t;
+    return VLO_OK;
+}
+void vlo_tp_session_destroy(vlo_tp_session *t) {
+    if (!t) return;
+    for (vlo_session *s : t->ss) vlo_session_destroy(s);
+    if (t->gather_tmp) hipFree(t->gather_tmp);
+    delete t;
+}
+int vlo_tp_session_reset(vlo_tp_session *t) {
+    if (!t) return vlo_fail(VLO_E_INVALID, "null tp session");
+    for (vlo_session *s : t->ss) vlo_session_reset(s);
+    return VLO_OK;
+}
+int64_t vlo_tp_session_len(const vlo_tp_session *t) { return t && !t->ss.empty() ? t->ss[0]->len : -1; }
+
+// ---- exchanges -------------------------------------------------------------------------------------------------
+static int tp_allreduce(vlo_tp_session *t, float *(vlo_session::*buf), size_t count, hipStream_t st) {
+    vlo_tp_group *g = t->g;
+    if (g->tp_size == 1) return VLO_OK;
+    if (g->comm) {
+        float *b = t->ss[0]->*buf;
+        if (g_rccl.AllReduce(b, b, count, kNcclFloat32, kNcclSum, g->comm, st) != 0) return vlo_fail(VLO_E_HIP, "ncclAllReduce failed");
+        return VLO_OK;
+    }
+    PtrList L;
+    L.n = (int)t->ss.size();
+    for (int r = 0; r < L.n; ++r) L.p[r] = t->ss[r]->*buf;
+    int blocks = (int)((count + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(tp_sum_kernel, dim3(blocks), dim3(256), 0, st, L, count);
+    TP_TRY(hipGetLastError());
+    return VLO_OK;
+}
+
+// logits_local [nr][V_l] of every rank -> logits [nr][V] on every local rank
+static int tp_gather_logits(vlo_tp_session *t, int nr, hipStream_t st) {
+    vlo_tp_group *g = t->g;
+    const int T = g->tp_size, V = g->eng[0]->cfg.vocab_size, Vl = g->eng[0]->V_l;
+    if (g->comm) {
+        vlo_session *s = t->ss[0];
+        if (g_rccl.AllGather(s->logits_local, t->gather_tmp, (size_t)nr * Vl * 2, kNcclInt8, g->comm, st) != 0)
+            return vlo_fail(VLO_E_HIP, "ncclAllGather failed");
+        for (int r = 0; r < T; ++r)       // [T][nr][Vl] -> [nr][V]
+            TP_TRY(hipMemcpy2DAsync(s->logits + (size_t)r * Vl, (size_t)V * 2, t->gather_tmp + (size_t)r * nr * Vl, (size_t)Vl * 2,
+                                    (size_t)Vl * 2, nr, hipMemcpyDeviceToDevice, st));
+        return VLO_OK;
+    }
+    for (size_t d = 0; d < t->ss.size(); ++d)
+        for (int r = 0; r < T; ++r)
+            TP_TRY(hipMemcpy2DAsync(t->ss[d]->logits + (size_t)r * Vl, (size_t)V * 2, t->ss[r]->logits_local, (size_t)Vl * 2,
+                                    (size_t)Vl * 2, nr, hipMemcpyDeviceToDevice, st));
+    return VLO_OK;
+}
+
+// ---- one chunk of m <= 16 new tokens on every local rank, lock-step ------------------------------------------------
+static int tp_chunk(vlo_tp_session *t, const unsigned short *src, int m, bool want_last, bool want_all, hipStream_t st) {
+    vlo_tp_group *g = t->g;
+    const int R = (int)t->ss.size();
+    const vlo_config &c = g->eng[0]->cfg;
+    const int H = c.hidden_size, hd = g->eng[0]->head_dim;
+    int rc;
+    for (int r = 0; r < R; ++r) {
+        vlo_session *s = t->ss[r];
+        if ((rc = ensure_pages(s, s->len + m, st))) return rc;
+        TP_TRY(copy_rows_launch(src, s->h, m, H, st));
+    }
+    bool have_prev = false;
+    int prev_ks = 0;
+    for (int l = 0; l < c.num_layers; ++l) {
+        int ks_o = 1, ks_d = 1;
+        for (int r = 0; r < R; ++r) {           // attention half: everything up to the o_proj partial sums
+            vlo_session *s = t->ss[r];
+            vlo_engine *e = s->e;
+            const LayerWeights &L = e->layers[l];
+            const KvGeom kv = kv_geom(s);
+            TP_TRY(add_rmsnorm_launch(s->h, have_prev ? s->partial : nullptr, prev_ks, H, (const unsigned short *)L.ln_in, s->x, H, H,
+                                      c.rms_eps, m, st));
+            GemvArgs a = gemv_args(L.qkv, s->x, H, m);
+            a.out_bf16 = s->q; a.cos_tab = (const unsigned short *)e->cos_tab; a.sin_tab = (const unsigned short *)e->sin_tab;
+            a.kv = kv; a.layer = l; a.num_heads = e->nh_l; a.pos0 = s->len;
+            TP_TRY(gemv_launch(a, L.qkv.plan, XSRC_PLAIN, EPI_ROPE, st));
+            TP_TRY(attention_launch(s->q, kv, l, e->nh_l, s->len, m, s->part_o, s->part_ml, s->attn, st));
+            GemvArgs o = gemv_args(L.o, s->attn, e->nh_l * hd, m);
+            o.out_f32 = s->partial_o; o.ldo = H;
+            TP_TRY(gemv_launch(o, L.o.plan, XSRC_PLAIN, EPI_PARTIAL_F32, st));
+            ks_o = L.o.plan.ksplit;
+        }
+        if ((rc = tp_allreduce(t, &vlo_session::partial_o, ks_o == 1 ? (size_t)m * H : (size_t)ks_o * 16 * H, st))) return rc;
+        for (int r = 0; r < R; ++r) {           // MLP half
+            vlo_session *s = t->ss[r];
+            vlo_engine *e = s->e;
+            const LayerWeights &L = e->layers[l];
+            TP_TRY(add_rmsnorm_launch(s->h, s->partial_o, ks_o, H, (const unsigned short *)L.ln_post, s->x, H, H, c.rms_eps, m, st));
+            GemvArgs a = gemv_args(L.gate_up, s->x, H, m);
+            a.out_bf16 = s->act; a.ldo = e->I_l;
+            TP_TRY(gemv_launch(a, L.gate_up.plan, XSRC_PLAIN, EPI_SWIGLU, st));
+            GemvArgs d = gemv_args(L.down, s->act, e->I_l, m);
+            d.out_f32 = s->partial; d.ldo = H;
+            TP_TRY(gemv_launch(d, L.down.plan, XSRC_PLAIN, EPI_PARTIAL_F32, st));
+            ks_d = L.down.plan.ksplit;
+        }
+        if ((rc = tp_allreduce(t, &vlo_session::partial, ks_d == 1 ? (size_t)m * H : (size_t)ks_d * 16 * H, st))) return rc;
+        have_prev = true;
+        prev_ks = ks_d;
+    }
+    if (want_last || want_all) {
+        const int r0 = want_all ? 0 : m - 1, nr = want_all ? m : 1;
+        for (int r = 0; r < R; ++r) {
+            vlo_session *s = t->ss[r];
+            vlo_engine *e = s->e;
+            TP_TRY(add_rmsnorm_launch(s->h, s->partial, prev_ks, H, (const unsigned short *)e->norm_w, s->x, H, H, c.rms_eps, m, st));
+            GemvArgs a = gemv_args(e->lm_head, s->x + (size_t)r0 * H, H, nr);
+            a.out_bf16 = s->logits_local; a.ldo = e->V_l;
+            TP_TRY(gemv_launch(a, e->lm_head.plan, XSRC_PLAIN, EPI_BF16, st));
+        }
+        if ((rc = tp_gather_logits(t, nr, st))) return rc;
+        for (int r = 0; r < R; ++r) {
+            t->ss[r]->last_logits = t->ss[r]->logits + (size_t)(nr - 1) * c.vocab_size;
+            t->ss[r]->has_logits = true;
+        }
+    }
+    for (int r = 0; r < R; ++r) t->ss[r]->len += m;
+    return VLO_OK;
+}
+
+int vlo_tp_llm_step(vlo_tp_session *t, const void *embeds_dev, int n, void *last_logits_dev, void *all_logits_dev, void *stream) {
+    if (!t || !embeds_dev || n <= 0) return vlo_fail(VLO_E_INVALID, "bad tp_llm_step arguments");
+    vlo_engine *e0 = t->g->eng[0];
+    TP_TRY(hipSetDevice(e0->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int H = e0->cfg.hidden_size, V = e0->cfg.vocab_size;
+    int rc;
+    for (int c0 = 0; c0 < n; c0 += 16) {
+        const int m = std::min(16, n - c0);
+        const bool last = (c0 + m == n);
+        if ((rc = tp_chunk(t, (const unsigned short *)embeds_dev + (size_t)c0 * H, m, last, all_logits_dev != nullptr, st))) return rc;
+        if (all_logits_dev)
+            TP_TRY(hipMemcpyAsync((unsigned short *)all_logits_dev + (size_t)c0 * V, t->ss[0]->logits, (size_t)m * V * 2,
+                                  hipMemcpyDeviceToDevice, st));
+    }
+    if (last_logits_dev) TP_TRY(hipMemcpyAsync(last_logits_dev, t->ss[0]->last_logits, (size_t)V * 2, hipMemcpyDeviceToDevice, st));
+    return VLO_OK;
+}
+
+int vlo_tp_stream_sample(vlo_tp_session *t, float threshold, int interval_id, int64_t *tok_dev, float *p_interval_dev, void *stream) {
+    if (!t || !tok_dev) return vlo_fail(VLO_E_INVALID, "bad tp_stream_sample arguments");
+    vlo_session *s = t->ss[0];
+    if (!s->has_logits) return vlo_fail(VLO_E_STATE, "no logits: call vlo_tp_llm_step first");
+    TP_TRY(hipSetDevice(s->e->device));
+    TP_TRY(stream_sample_launch(s->last_logits, s->e->cfg.vocab_size, threshold, interval_id, tok_dev, p_interval_dev, (hipStream_t)stream));
+    return VLO_OK;
+}
+
+int vlo_tp_greedy_generate(vlo_tp_session *t, const void *embeds_dev, int m, int eos_token_id, int64_t *out_ids_dev, int max_new,
+                           int force_len, int *n_written, void *stream) {
+    if (!t || !embeds_dev || !out_ids_dev || m <= 0 || max_new <= 0) return vlo_fail(VLO_E_INVALID, "bad tp_greedy_generate arguments");
+    vlo_session *s = t->ss[0];
+    vlo_engine *e = s->e;
+    TP_TRY(hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int V = e->cfg.vocab_size;
+    if (force_len > max_new) force_len = max_new;
+    int rc = vlo_tp_llm_step(t, embeds_dev, m, nullptr, nullptr, stream);
+    if (rc) return rc;
+    int i = 0;
+    for (;; ++i) {
+        int mode = 0;
+        if (force_len > 0) mode = (i == force_len - 1) ? 2 : 1;
+        TP_TRY(greedy_sample_launch(s->last_logits, V, out_ids_dev + i, eos_token_id, mode, st));
+        TP_TRY(hipMemcpyAsync(s->host_tok, out_ids_dev + i, 8, hipMemcpyDeviceToHost, st));
+        TP_TRY(hipStreamSynchronize(st));
+        if (*s->host_tok == eos_token_id) break;
+        if (i == max_new - 1) break;
+        TP_TRY(embed_gather_launch((const unsigned short *)e->embed, out_ids_dev + i, 1, e->cfg.hidden_size, V, s->emb1, st));
+        if ((rc = vlo_tp_llm_step(t, s->emb1, 1, nullptr, nullptr, stream))) return rc;
+    }
+    if (n_written) *n_written = i + 1;
+    return VLO_OK;
+}

@@ -28,6 +28,9 @@ class EngineConfig:
     # vision tower (None = LLM-only engine)
     vit: dict | None = None
     kv_pool_tokens: int = 16384
+    # tensor parallel shard held by this engine (see TpGroup)
+    tp_rank: int = 0
+    tp_size: int = 1
 
     def to_c(self) -> _C.VloConfig:
         c = _C.VloConfig()
@@ -38,7 +41,7 @@ class EngineConfig:
         c.vision_hidden_size, c.frame_num_tokens = self.vision_hidden_size, self.frame_num_tokens
         c.pool_h, c.pool_w = self.frame_token_pooled
         c.kv_pool_tokens = self.kv_pool_tokens
-        c.tp_rank, c.tp_size = 0, 1
+        c.tp_rank, c.tp_size = self.tp_rank, self.tp_size
         if self.vit:
             v = self.vit
             c.has_vit = 1
@@ -211,3 +214,140 @@ def test_gemv(x: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
     y = torch.empty(x.shape[0], W.shape[0], dtype=torch.float32, device=x.device)
     _C.check(_C.lib().vlo_test_gemv(_ptr(x), _ptr(W), _ptr(y), x.shape[0], W.shape[0], W.shape[1], _stream_handle()))
     return y
+
+
+class TpSession:
+    """KV handle of a tensor-parallel group: one KV shard (this rank's kv heads) per local rank."""
+
+    def __init__(self, group: "TpGroup", max_tokens_hint: int = 0):
+        self.group = group
+        h = C.c_void_p()
+        _C.check(_C.lib().vlo_tp_session_create(group._g, max_tokens_hint, C.byref(h)))
+        self._h = h
+
+    def __bool__(self):
+        return True
+
+    def get_seq_length(self) -> int:
+        return int(_C.lib().vlo_tp_session_len(self._h))
+
+    __len__ = get_seq_length
+
+    def reset(self):
+        _C.check(_C.lib().vlo_tp_session_reset(self._h))
+
+    def close(self):
+        if self._h:
+            _C.lib().vlo_tp_session_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TpGroup:
+    """Tensor-parallel Llama (north_star TP; include/vlo.h `vlo_tp_*`) behind the same surface as Engine, so
+    LiveModel / LiveInfer run on it unchanged.
+
+    * ``TpGroup(cfg, tp_size, device=0)``: single process, ``tp_size`` logical ranks on one device (exchanges are
+      device kernels) — validates the sharding arithmetic without a multi-GPU box.
+    * ``TpGroup(cfg, tp_size, device=local_rank, rank=r, unique_id=bytes)``: one process per GPU; exchanges are RCCL
+      all-reduce / all-gather.  ``unique_id`` comes from ``TpGroup.unique_id()`` on rank 0, broadcast by the caller
+      (e.g. ``torch.distributed.broadcast_object_list``).
+    Weights are given in FULL; every rank slices its shard.  ViT, connector and embeddings are replicated."""
+
+    def __init__(self, cfg: EngineConfig, tp_size: int, device: int = 0, rank: int | None = None, unique_id: bytes | None = None):
+        from dataclasses import replace
+        self.cfg = cfg
+        self.tp_size = tp_size
+        ranks = list(range(tp_size)) if rank is None else [rank]
+        self._uid = unique_id
+        if rank is not None and tp_size > 1 and unique_id is None:
+            raise ValueError("one-process-per-GPU TP needs the RCCL unique id")
+        self.engines = [Engine(replace(cfg, tp_rank=r, tp_size=tp_size, vit=cfg.vit if i == 0 else None), device)
+                        for i, r in enumerate(ranks)]
+        self.device = self.engines[0].device
+        self.head_dim = self.engines[0].head_dim
+        self._g = None
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _C.check(_C.lib().vlo_tp_unique_id(buf))
+        return buf.raw
+
+    def load_weight(self, name: str, t: torch.Tensor):
+        for i, e in enumerate(self.engines):
+            if name.startswith("vision.") and i > 0:
+                continue                      # the vision tower lives on the first local engine only
+            e.load_weight(name, t)
+
+    def load_weights(self, weights: dict):
+        for k, v in weights.items():
+            self.load_weight(k, v)
+
+    def finalize(self):
+        for e in self.engines:
+            e.finalize()
+        arr = (C.c_void_p * len(self.engines))(*[e._h for e in self.engines])
+        g = C.c_void_p()
+        uid = C.create_string_buffer(self._uid, 128) if self._uid is not None else None
+        _C.check(_C.lib().vlo_tp_group_create(arr, len(self.engines), uid, C.byref(g)))
+        self._g = g
+        return self
+
+    @property
+    def weight_bytes(self) -> int:
+        return sum(e.weight_bytes for e in self.engines)
+
+    def step_algorithmic_bytes(self, Lc: int, n: int) -> float:
+        return self.engines[0].step_algorithmic_bytes(Lc, n)
+
+    def profile_enable(self, stride: int = 1):
+        pass
+
+    def new_session(self, max_tokens_hint: int = 0) -> TpSession:
+        return TpSession(self, max_tokens_hint)
+
+    def embed(self, ids, stream=None):
+        return self.engines[0].embed(ids, stream)
+
+    def connector(self, feats, stream=None):
+        return self.engines[0].connector(feats, stream)
+
+    def visual_embed(self, frames_u8, stream=None, out=None):
+        return self.engines[0].visual_embed(frames_u8, stream, out)
+
+    def llm_step(self, session: TpSession, embeds: torch.Tensor, want_last=True, want_all=False, stream=None):
+        embeds = embeds.to(device=self.device, dtype=torch.bfloat16).contiguous().view(-1, self.cfg.hidden_size)
+        n = embeds.shape[0]
+        last = torch.empty(self.cfg.vocab_size, dtype=torch.bfloat16, device=self.device) if want_last else None
+        allr = torch.empty(n, self.cfg.vocab_size, dtype=torch.bfloat16, device=self.device) if want_all else None
+        _C.check(_C.lib().vlo_tp_llm_step(session._h, _ptr(embeds), n, _ptr(last) if want_last else None,
+                                          _ptr(allr) if want_all else None, _stream_handle(stream)))
+        return last, allr
+
+    def stream_sample(self, session: TpSession, threshold: float, interval_id: int, stream=None, tok_out=None, p_out=None):
+        tok = tok_out if tok_out is not None else torch.empty(1, dtype=torch.long, device=self.device)
+        p = p_out if p_out is not None else torch.empty(1, dtype=torch.float32, device=self.device)
+        _C.check(_C.lib().vlo_tp_stream_sample(session._h, threshold, interval_id, _ptr(tok), _ptr(p), _stream_handle(stream)))
+        return tok, p
+
+    def greedy_generate(self, session: TpSession, embeds: torch.Tensor, eos_token_id: int, inplace_output_ids: torch.Tensor,
+                        force_len: int = 0, stream=None) -> int:
+        embeds = embeds.to(device=self.device, dtype=torch.bfloat16).contiguous().view(-1, self.cfg.hidden_size)
+        n = C.c_int(0)
+        _C.check(_C.lib().vlo_tp_greedy_generate(session._h, _ptr(embeds), embeds.shape[0], eos_token_id,
+                                                 _ptr(inplace_output_ids), inplace_output_ids.numel(), force_len,
+                                                 C.byref(n), _stream_handle(stream)))
+        return n.value
+
+    def close(self):
+        if self._g:
+            _C.lib().vlo_tp_group_destroy(self._g)
+            self._g = None
+        for e in self.engines:
+            e.close()
