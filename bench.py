@@ -247,6 +247,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=12)
     ap.add_argument("--prof-stride", type=int, default=8)
+    ap.add_argument("--tp", action="store_true",
+                    help="N > 1: ONE stream, Llama tensor-parallel over the N GPUs (RCCL all-reduce), strong scaling; "
+                         "default is one independent stream per GPU (replicas, weak scaling)")
     args = ap.parse_args()
 
     import torch
@@ -261,7 +264,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    from videollm_online_amd.engine import Engine, EngineConfig
+    from videollm_online_amd.engine import Engine, EngineConfig, TpGroup
     from videollm_online_amd.inference import LiveInfer
     from videollm_online_amd.modeling_live import LiveModel
 
@@ -272,14 +275,23 @@ def main():
     kv_tokens = 64 + 11 * n_frames + (n_frames // 10 + 2) * 24 + 4096
     cfg = EngineConfig(**shape, vision_hidden_size=1024, vit=VIT_SHAPE, kv_pool_tokens=kv_tokens)
     log(f"building engine ({args.model} + siglip-l16-384), kv pool {kv_tokens} tokens")
-    eng = Engine(cfg, local)
-    gpu_random_weights(eng, cfg, seed=rank)
+    tp = args.tp and world > 1
+    if tp:
+        # every rank builds the SAME full random weights (same seed) and keeps its shard; the RCCL communicator is
+        # bootstrapped from rank 0's unique id
+        uid = [TpGroup.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        eng = TpGroup(cfg, world, device=local, rank=rank, unique_id=uid[0])
+        gpu_random_weights(eng, cfg, seed=0)
+    else:
+        eng = Engine(cfg, local)
+        gpu_random_weights(eng, cfg, seed=rank)
     eng.finalize()
     torch.cuda.synchronize()
     log(f"engine ready, {eng.weight_bytes / 1e9:.2f} GB packed weights")
     toks = stream_tokens(cfg.vocab_size)
     model = LiveModel(eng, eos_token_id=toks.eos_token_id, frame_token_interval_id=toks.interval_id)
-    frames = gpu_synthetic_frames(n_frames, seed=1234 + rank)
+    frames = gpu_synthetic_frames(n_frames, seed=1234 + (0 if tp else rank))
     li = LiveInfer(model, tokens=toks, frame_fps=args.fps, prefetch=not args.no_prefetch, prefetch_frames=args.prefetch_frames,
                    schedule=make_schedule(args.mode))
 
@@ -311,9 +323,10 @@ def main():
     eng.profile_enable(args.prof_stride)
     elapsed, costs, alg_bytes, llm_steps = run(K, True)
     log(f"timed region done: {elapsed:.3f}s -> {K / elapsed:.1f} frames/s on this rank")
-    n_launch, prof_ms, bytes_per_launch = eng.profile_read()
+    prof_eng = eng.engines[0] if tp else eng
+    n_launch, prof_ms, bytes_per_launch = prof_eng.profile_read()
     eng.profile_enable(0)
-    empty_us = eng.profile_calibrate()
+    empty_us = prof_eng.profile_calibrate()
     # encode stage in isolation (HIP events on its own stream): ms/frame and fraction of the dense fp16 MFMA peak
     vit_ms = None
     if rank == 0:
@@ -332,7 +345,7 @@ def main():
     final_len = len(li.past_key_values)
 
     elapsed = reduce_elapsed_max(dist, elapsed)
-    fps = aggregate_fps(K, world, elapsed)
+    fps = aggregate_fps(K, 1 if tp else world, elapsed)        # TP: the ranks share ONE stream of K frames
 
     out = None
     if rank == 0:
@@ -351,15 +364,17 @@ def main():
         out = {
             "metric": "streaming FPS + p50 per-frame latency, Llama-3-8B+SigLIP-L, 10 min @ 2 FPS, 1/2/4/8 GPU",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "strong" if tp else "weak",
+            "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "p50_frame_latency_ms": round(statistics.median(costs) * 1e3, 4),
             "p95_frame_latency_ms": round(sorted(costs)[int(0.95 * (len(costs) - 1))] * 1e3, 4),
             "config": {"workload": f"{args.model} + siglip-l16-384, {K} frames @ {args.fps:g} FPS 384x384 uint8, "
-                                   f"TP=1, one stream per GPU ({world} replica(s)), mode={args.mode} "
+                                   + (f"ONE stream, Llama TP={world} (RCCL all-reduce x2/layer), ViT replicated, "
+                                      if tp else f"TP=1, one stream per GPU ({world} replica(s)), ") + f"mode={args.mode} "
                                    f"(16-token response every 10th frame + t=0 query), random-init weights at true shapes",
                        "frames": K, "final_kv_tokens": final_len, "llm_steps": llm_steps, "prefetch_encode": not args.no_prefetch, "prefetch_frames": args.prefetch_frames,
-                       "parallelism": f"replicas{world}"},
+                       "parallelism": f"tp{world}" if tp else f"replicas{world}"},
             "encode_stage": {"batch": max(1, args.prefetch_frames), "ms_per_frame": round(vit_ms, 4),
                              "tflops": round(VIT_GFLOP_PER_FRAME / vit_ms, 1), "mfma_peak_tflops": MFMA_PEAK_TFLOPS,
                              "frac_of_mfma_peak": round(VIT_GFLOP_PER_FRAME / vit_ms / MFMA_PEAK_TFLOPS, 4),
