@@ -82,6 +82,7 @@ struct vlo_session {
     unsigned short *logits_local = nullptr;      // TP: this rank's vocabulary shard [16][V_l]
     float *partial_o = nullptr;                  // TP: o_proj partial sums [16][H] awaiting the all-reduce
     int64_t *tok = nullptr;
+    float *sample_scratch = nullptr;
     int64_t *host_tok = nullptr;
     int *page_table = nullptr, *host_pt = nullptr;
 };

@@ -389,6 +389,7 @@ int vlo_session_create(vlo_engine *e, int64_t max_tokens_hint, vlo_session **out
         A((void **)&s->partial_o, (size_t)ks_o * 16 * H * 4);
     }
     A((void **)&s->tok, 64);
+    A((void **)&s->sample_scratch, VLO_SAMPLE_SCRATCH_FLOATS * 4);
     A((void **)&s->emb1, (size_t)32 * H * 2);
     A((void **)&s->page_table, (size_t)e->pool_pages * 4);
     if (rc) {
@@ -643,7 +644,7 @@ int vlo_stream_sample(vlo_session *s, float threshold, int interval_id, int64_t 
     if (!s->has_logits) return fail(VLO_E_STATE, "no logits: call vlo_llm_step first");
     HIP_TRY(hipSetDevice(s->e->device));
     HIP_TRY(stream_sample_launch(s->last_logits, s->e->cfg.vocab_size, threshold, interval_id, tok_dev, p_interval_dev,
-                                 (hipStream_t)stream));
+                                 s->sample_scratch, (hipStream_t)stream));
     return VLO_OK;
 }
 
@@ -670,7 +671,7 @@ int vlo_greedy_generate(vlo_session *s, const void *embeds_dev, int m, int eos_t
     for (;; ++i) {
         int mode = 0;
         if (force_len > 0) mode = (i == force_len - 1) ? 2 : 1;
-        HIP_TRY(greedy_sample_launch(s->last_logits, V, out_ids_dev + i, eos_token_id, mode, st));
+        HIP_TRY(greedy_sample_launch(s->last_logits, V, out_ids_dev + i, eos_token_id, mode, s->sample_scratch, st));
         // the reference reads the token on the host every step (`if new_token_id == eos_token_id`, :179)
         HIP_TRY(hipMemcpyAsync(s->host_tok, out_ids_dev + i, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));

@@ -34,10 +34,12 @@ hipError_t embed_gather_launch(const unsigned short *table, const int64_t *ids, 
                                unsigned short *out, hipStream_t st);
 
 // samplers on bf16 logits [V]
+#define VLO_SAMPLE_SCRATCH_FLOATS 512     // >= 6 * SAMPLE_BLOCKS + 1
+// `scratch`: VLO_SAMPLE_SCRATCH_FLOATS floats of device memory owned by the session
 hipError_t greedy_sample_launch(const unsigned short *logits, int V, int64_t *tok_out, int eos, int force_mode,
-                                hipStream_t st);
+                                float *scratch, hipStream_t st);
 hipError_t stream_sample_launch(const unsigned short *logits, int V, float threshold, int interval_id,
-                                int64_t *tok_out, float *p_interval_out, hipStream_t st);
+                                int64_t *tok_out, float *p_interval_out, float *scratch, hipStream_t st);
 
 hipError_t copy_rows_launch(const unsigned short *src, unsigned short *dst, int rows, int H, hipStream_t st);
 hipError_t read_kv_launch(KvGeom kv, int layer, int which, int kv_head, int64_t t0, int64_t t1, unsigned short *dst,

@@ -413,14 +413,18 @@ hipError_t read_kv_launch(KvGeom kv, int layer, int which, int kv_head, int64_t 
 }
 
 // ------------------------------------------------------------------------------------
-// samplers — one 1024-thread block over the L2-resident bf16 logits [V]
+// samplers over the L2-resident bf16 logits [V]: SAMPLE_BLOCKS blocks scan a slice each, a one-wave
+// kernel merges the partials (3 short launches instead of one ~90 us single-block scan).
 // ------------------------------------------------------------------------------------
+#define SAMPLE_BLOCKS 64
+#define SAMPLE_THREADS 256
+
 struct ArgBest { float v; int i; };
 VLO_DEV ArgBest better(ArgBest a, ArgBest b) {      // larger value wins; ties -> smaller index (torch argmax)
     if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
     return a;
 }
-VLO_DEV ArgBest block_argbest(ArgBest x, float *smv, int *smi) {
+VLO_DEV ArgBest wave_argbest(ArgBest x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         ArgBest y;
@@ -428,6 +432,10 @@ VLO_DEV ArgBest block_argbest(ArgBest x, float *smv, int *smi) {
         y.i = __shfl_xor(x.i, o, 64);
         x = better(x, y);
     }
+    return x;
+}
+VLO_DEV ArgBest block_argbest(ArgBest x, float *smv, int *smi) {
+    x = wave_argbest(x);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     __syncthreads();
     if (lane == 0) { smv[w] = x.v; smi[w] = x.i; }
@@ -437,18 +445,41 @@ VLO_DEV ArgBest block_argbest(ArgBest x, float *smv, int *smi) {
     return r;
 }
 
-// force_mode: 0 = plain argmax; 1 = argmax but never eos (scheduled mode, mid-response);
-//             2 = argmax computed, eos written (scheduled mode, last token)
-__global__ __launch_bounds__(1024) void greedy_sample_kernel(const bf16_t *__restrict__ logits, int V, int64_t *tok_out, int eos,
-                                                             int force_mode) {
+// scratch layout (floats): [0, NB) block max | [NB, 2NB) block sum of exp(x - block max) | [2NB, 3NB) best value |
+//                          [3NB, 4NB) best index (int bits)
+__global__ __launch_bounds__(SAMPLE_THREADS) void sample_stats_kernel(const bf16_t *__restrict__ logits, int V, float *__restrict__ scr) {
+    __shared__ float sm[16];
     __shared__ float smv[16];
     __shared__ int smi[16];
+    const int per = (V + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = min(V, lo + per);
+    float mx = -INFINITY;
     ArgBest b = {-INFINITY, 0x7fffffff};
-    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const float v = bf2f(logits[i]);
+        mx = fmaxf(mx, v);
         if (v > b.v) { b.v = v; b.i = i; }
     }
+    mx = block_max(mx, sm);
+    float s = 0.f;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) s += expf(bf2f(logits[i]) - mx);
+    s = block_sum(s, sm);
     b = block_argbest(b, smv, smi);
+    if (threadIdx.x == 0) {
+        const int NB = gridDim.x;
+        scr[blockIdx.x] = mx;
+        scr[NB + blockIdx.x] = (mx == -INFINITY) ? 0.f : s;
+        scr[2 * NB + blockIdx.x] = b.v;
+        reinterpret_cast<int *>(scr)[3 * NB + blockIdx.x] = b.i;
+    }
+}
+
+// force_mode: 0 = plain argmax; 1 = argmax but never eos (scheduled mode, mid-response);
+//             2 = argmax computed, eos written (scheduled mode, last token)
+__global__ __launch_bounds__(64) void greedy_final_kernel(const float *__restrict__ scr, int NB, int V, int64_t *tok_out, int eos,
+                                                          int force_mode) {
+    ArgBest b = {-INFINITY, 0x7fffffff};
+    for (int k = threadIdx.x; k < NB; k += 64) b = better(b, (ArgBest){scr[2 * NB + k], reinterpret_cast<const int *>(scr)[3 * NB + k]});
+    b = wave_argbest(b);
     if (threadIdx.x == 0) {
         int t = b.i;
         if (force_mode == 1 && t == eos) t = (eos + 1) % V;
@@ -456,40 +487,54 @@ __global__ __launch_bounds__(1024) void greedy_sample_kernel(const bf16_t *__res
         *tok_out = t;
     }
 }
-hipError_t greedy_sample_launch(const unsigned short *logits, int V, int64_t *tok_out, int eos, int force_mode, hipStream_t st) {
-    hipLaunchKernelGGL(greedy_sample_kernel, dim3(1), dim3(1024), 0, st, logits, V, tok_out, eos, force_mode);
+hipError_t greedy_sample_launch(const unsigned short *logits, int V, int64_t *tok_out, int eos, int force_mode, float *scratch,
+                                hipStream_t st) {
+    hipLaunchKernelGGL(sample_stats_kernel, dim3(SAMPLE_BLOCKS), dim3(SAMPLE_THREADS), 0, st, logits, V, scratch);
+    hipLaunchKernelGGL(greedy_final_kernel, dim3(1), dim3(64), 0, st, scratch, SAMPLE_BLOCKS, V, tok_out, eos, force_mode);
     return hipGetLastError();
 }
 
-// demo/inference.py:76-79: softmax over a bf16 tensor (fp32 inside, bf16 out), threshold, argmax
-__global__ __launch_bounds__(1024) void stream_sample_kernel(const bf16_t *__restrict__ logits, int V, float threshold,
-                                                             int interval_id, int64_t *tok_out, float *p_interval_out) {
-    __shared__ float sm[16];
+// demo/inference.py:76-79: softmax over a bf16 tensor (fp32 inside, bf16 out), threshold on p[interval], argmax of p.
+// Every block recomputes the global (max, sum) from the NB partials, then scans its slice of p.
+__global__ __launch_bounds__(SAMPLE_THREADS) void stream_scan_kernel(const bf16_t *__restrict__ logits, int V, float threshold,
+                                                                     int interval_id, float *__restrict__ scr) {
     __shared__ float smv[16];
     __shared__ int smi[16];
-    float mx = -INFINITY;
-    for (int i = threadIdx.x; i < V; i += blockDim.x) mx = fmaxf(mx, bf2f(logits[i]));
-    mx = block_max(mx, sm);
-    float s = 0.f;
-    for (int i = threadIdx.x; i < V; i += blockDim.x) s += expf(bf2f(logits[i]) - mx);
-    s = block_sum(s, sm);
-    const float p_int = rbf(expf(bf2f(logits[interval_id]) - mx) / s);
+    const int NB = gridDim.x;
+    float M = -INFINITY;
+    for (int k = 0; k < NB; ++k) M = fmaxf(M, scr[k]);
+    float S = 0.f;
+    for (int k = 0; k < NB; ++k) S += scr[NB + k] * expf(scr[k] - M);
+    const float p_int = rbf(expf(bf2f(logits[interval_id]) - M) / S);
     const bool zero_int = p_int < threshold;
+    const int per = (V + NB - 1) / NB, lo = blockIdx.x * per, hi = min(V, lo + per);
     ArgBest b = {-INFINITY, 0x7fffffff};
-    for (int i = threadIdx.x; i < V; i += blockDim.x) {
-        float p = rbf(expf(bf2f(logits[i]) - mx) / s);
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        float p = rbf(expf(bf2f(logits[i]) - M) / S);
         if (i == interval_id && zero_int) p = 0.f;
         if (p > b.v) { b.v = p; b.i = i; }
     }
     b = block_argbest(b, smv, smi);
     if (threadIdx.x == 0) {
+        scr[4 * NB + blockIdx.x] = b.v;
+        reinterpret_cast<int *>(scr)[5 * NB + blockIdx.x] = b.i;
+        if (blockIdx.x == 0) scr[6 * NB] = p_int;
+    }
+}
+__global__ __launch_bounds__(64) void stream_final_kernel(const float *__restrict__ scr, int NB, int64_t *tok_out, float *p_interval_out) {
+    ArgBest b = {-INFINITY, 0x7fffffff};
+    for (int k = threadIdx.x; k < NB; k += 64) b = better(b, (ArgBest){scr[4 * NB + k], reinterpret_cast<const int *>(scr)[5 * NB + k]});
+    b = wave_argbest(b);
+    if (threadIdx.x == 0) {
         *tok_out = b.i;
-        if (p_interval_out) *p_interval_out = p_int;
+        if (p_interval_out) *p_interval_out = scr[6 * NB];
     }
 }
 hipError_t stream_sample_launch(const unsigned short *logits, int V, float threshold, int interval_id, int64_t *tok_out,
-                                float *p_interval_out, hipStream_t st) {
+                                float *p_interval_out, float *scratch, hipStream_t st) {
     if (interval_id < 0 || interval_id >= V) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(stream_sample_kernel, dim3(1), dim3(1024), 0, st, logits, V, threshold, interval_id, tok_out, p_interval_out);
+    hipLaunchKernelGGL(sample_stats_kernel, dim3(SAMPLE_BLOCKS), dim3(SAMPLE_THREADS), 0, st, logits, V, scratch);
+    hipLaunchKernelGGL(stream_scan_kernel, dim3(SAMPLE_BLOCKS), dim3(SAMPLE_THREADS), 0, st, logits, V, threshold, interval_id, scratch);
+    hipLaunchKernelGGL(stream_final_kernel, dim3(1), dim3(64), 0, st, scratch, SAMPLE_BLOCKS, tok_out, p_interval_out);
     return hipGetLastError();
 }

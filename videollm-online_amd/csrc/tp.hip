@@ -301,7 +301,7 @@ int vlo_tp_stream_sample(vlo_tp_session *t, float threshold, int interval_id, in
     vlo_session *s = t->ss[0];
     if (!s->has_logits) return vlo_fail(VLO_E_STATE, "no logits: call vlo_tp_llm_step first");
     TP_TRY(hipSetDevice(s->e->device));
-    TP_TRY(stream_sample_launch(s->last_logits, s->e->cfg.vocab_size, threshold, interval_id, tok_dev, p_interval_dev, (hipStream_t)stream));
+    TP_TRY(stream_sample_launch(s->last_logits, s->e->cfg.vocab_size, threshold, interval_id, tok_dev, p_interval_dev, s->sample_scratch, (hipStream_t)stream));
     return VLO_OK;
 }
 
@@ -320,7 +320,7 @@ int vlo_tp_greedy_generate(vlo_tp_session *t, const void *embeds_dev, int m, int
     for (;; ++i) {
         int mode = 0;
         if (force_len > 0) mode = (i == force_len - 1) ? 2 : 1;
-        TP_TRY(greedy_sample_launch(s->last_logits, V, out_ids_dev + i, eos_token_id, mode, st));
+        TP_TRY(greedy_sample_launch(s->last_logits, V, out_ids_dev + i, eos_token_id, mode, s->sample_scratch, st));
         TP_TRY(hipMemcpyAsync(s->host_tok, out_ids_dev + i, 8, hipMemcpyDeviceToHost, st));
         TP_TRY(hipStreamSynchronize(st));
         if (*s->host_tok == eos_token_id) break;
