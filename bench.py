@@ -258,11 +258,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # VLO_BENCH_BACKEND=gloo lets the multi-process path be exercised on a box with fewer GPUs than ranks
+    backend = os.environ.get("VLO_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from videollm_online_amd.engine import Engine, EngineConfig, TpGroup
     from videollm_online_amd.inference import LiveInfer
@@ -344,7 +351,7 @@ def main():
         vit_ms = e0.elapsed_time(e1) / 8 / B
     final_len = len(li.past_key_values)
 
-    elapsed = reduce_elapsed_max(dist, elapsed)
+    elapsed = reduce_elapsed_max(dist, elapsed, device="cuda" if backend == "nccl" else "cpu")
     fps = aggregate_fps(K, 1 if tp else world, elapsed)        # TP: the ranks share ONE stream of K frames
 
     out = None

@@ -44,8 +44,13 @@ def lib():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                           "(hipcc, gfx950).  The engine has no fallback path.")
+        try:                                   # same HIP sources, built on the spot — not a fallback path
+            from .build import build
+            build()
+        except Exception as ex:
+            raise RuntimeError(f"{LIB_PATH} not found and could not be built ({ex}).  Build it with "
+                               "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950).  "
+                               "The engine has no non-HIP path.") from ex
     L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
     L.vlo_abi_version.restype = i32
