@@ -107,6 +107,11 @@ void    vlo_session_destroy(vlo_session *s);
  *      models/live_llama/modeling_live_llama.py:18-22).
  *      frames_dev: uint8 [B,3,R,R] NCHW;  out_dev: bf16 [B*frame_num_tokens, hidden_size] */
 int vlo_visual_embed(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_dev, void *stream);
+/* ---- vision tokens only: `vision_encode(model, frames)` as the offline feature extraction uses it
+ *      (data/utils.py:86-104 distributed_encode -> models/vision_live.py:10-30).
+ *      frames_dev: uint8 [B,3,R,R];  out_dev: bf16 [B, frame_num_tokens, vision_hidden_size] (CLS + pooled, PRE-connector;
+ *      the reference stores them with `.to(torch.bfloat16)`, data/utils.py:101) */
+int vlo_vision_tokens(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_dev, void *stream);
 /* connector only (frames already encoded: the `hasattr(self,'vision_encode')` false branch,
  * models/modeling_live.py:22-26).  feats_dev: bf16 [rows, vision_hidden_size] */
 int vlo_connector(vlo_engine *e, const void *feats_dev, int rows, void *out_dev, void *stream);

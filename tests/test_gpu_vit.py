@@ -92,3 +92,24 @@ def test_visual_embed_matches_reference_fixture(golden_dir):
     scale = np.abs(gold).max()
     assert e <= 2.0 * r + 2 * 2 ** -8 * scale + 5e-3 * scale, (e, r, scale)
     eng.close()
+
+
+def test_vision_tokens_match_reference_function_fixture(golden_dir):
+    """tokens in vit_toy.npz were produced by the reference's own `_siglip_vision_encode` (fp32, CPU)."""
+    g = np.load(os.path.join(golden_dir, "vit_toy.npz"))
+    spec, vspec = O.LLM_SPECS["toy128"], O.VIT_SPECS["toy"]
+    w, vw = O.init_llm_weights(spec, seed=3), O.init_vit_weights(vspec, seed=1)
+    frames = O.synthetic_frames(3, vspec.image_size, seed=1234)
+    eng = _engine(spec, vspec, w, vw)
+    tok = eng.vision_tokens(frames.cuda()).cpu().float()
+    gold = torch.from_numpy(g["tokens"])
+    amp = O.siglip_vision_encode(vw, vspec, frames, mm_dtype=torch.float16)        # the reference's GPU (autocast) numerics
+    e = (tok - gold).abs().max().item()
+    a = (amp - gold).abs().max().item()
+    scale = gold.abs().max().item()
+    assert tok.shape == gold.shape
+    assert e <= 2.0 * a + 2 * 2 ** -8 * scale, (e, a, scale)                       # fp16 path + bf16 output rounding
+    # batched offline extraction: batch boundaries must not matter
+    enc = eng.encode_video(frames.cuda(), batch_size=2).cpu().float()
+    assert torch.equal(enc, tok)
+    eng.close()

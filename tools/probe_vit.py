@@ -47,3 +47,11 @@ if __name__ == "__main__":
         t1.record(); torch.cuda.synchronize()
         ms = t0.elapsed_time(t1) / 20
         print(f"B={B}: {ms:.3f} ms per call, {ms/B:.3f} ms/frame, {384.4e9*B/(ms*1e-3)/1e12:.1f} TFLOP/s")
+    # offline feature extraction shape (data/preprocess/encode.py: batch 256): the MFMA-bound regime
+    for B in (32, 256):
+        frames = torch.randint(0, 256, (B, 3, 384, 384), dtype=torch.uint8, device="cuda")
+        eng.vision_tokens(frames); torch.cuda.synchronize()
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+        t0.record(); eng.vision_tokens(frames); eng.vision_tokens(frames); t1.record(); torch.cuda.synchronize()
+        ms = t0.elapsed_time(t1) / 2
+        print(f"vision_tokens B={B}: {ms:.2f} ms per call, {ms/B:.3f} ms/frame, {384.0e9*B/(ms*1e-3)/1e12:.1f} TFLOP/s")

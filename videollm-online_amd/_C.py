@@ -31,7 +31,7 @@ _lib = None
 EXPORTS = [
     "vlo_abi_version", "vlo_last_error", "vlo_engine_create", "vlo_engine_load_weight", "vlo_engine_finalize",
     "vlo_engine_destroy", "vlo_engine_weight_bytes", "vlo_session_create", "vlo_session_reset", "vlo_session_len",
-    "vlo_session_destroy", "vlo_visual_embed", "vlo_connector", "vlo_embed", "vlo_llm_step", "vlo_stream_sample",
+    "vlo_session_destroy", "vlo_visual_embed", "vlo_vision_tokens", "vlo_connector", "vlo_embed", "vlo_llm_step", "vlo_stream_sample",
     "vlo_greedy_generate", "vlo_session_read_kv", "vlo_step_algorithmic_bytes", "vlo_test_gemv",
     "vlo_profile_enable", "vlo_profile_read", "vlo_bench_gemv", "vlo_debug_read", "vlo_profile_calibrate",
     "vlo_tp_unique_id", "vlo_tp_group_create", "vlo_tp_group_destroy", "vlo_tp_session_create", "vlo_tp_session_reset",
@@ -69,6 +69,7 @@ def lib():
     L.vlo_session_destroy.argtypes = [vp]
     L.vlo_session_destroy.restype = None
     L.vlo_visual_embed.argtypes = [vp, vp, i32, vp, vp]
+    L.vlo_vision_tokens.argtypes = [vp, vp, i32, vp, vp]
     L.vlo_connector.argtypes = [vp, vp, i32, vp, vp]
     L.vlo_embed.argtypes = [vp, vp, i32, vp, vp]
     L.vlo_llm_step.argtypes = [vp, vp, i32, vp, vp, vp]

@@ -733,6 +733,13 @@ int vlo_visual_embed(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_
     return vit_visual_embed(e, frames_dev, B, out_dev, (hipStream_t)stream);
 }
 
+int vlo_vision_tokens(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_dev, void *stream) {
+    if (!e || !frames_dev || !out_dev || B <= 0) return fail(VLO_E_INVALID, "bad vision_tokens arguments");
+    if (!e->finalized || !e->cfg.has_vit || !e->vit) return fail(VLO_E_STATE, "engine built without a vision tower");
+    HIP_TRY(hipSetDevice(e->device));
+    return vit_vision_tokens(e, frames_dev, B, out_dev, (hipStream_t)stream);
+}
+
 int vlo_session_read_kv(vlo_session *s, int layer, int which, int kv_head, int64_t t0, int64_t t1, void *dst_dev, void *stream) {
     if (!s || !dst_dev || layer < 0 || layer >= s->e->cfg.num_layers || kv_head < 0 || kv_head >= s->e->nkv_l ||
         t0 < 0 || t1 > s->len || t1 < t0)

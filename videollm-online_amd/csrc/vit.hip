@@ -47,16 +47,17 @@ VLO_DEV float rh(float x) { return h2f(f2h(x)); }     // fp16 rounding point
 
 #define GEMM_BK 64
 
-template <int BM, int BN, int EP, int DEPTH>
-__global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs a) {
-    constexpr int MI = BM / 32, NI = BN / 32;          // 16x16 tiles per wave along m / n (2x2 waves)
+template <int BM, int BN, int WM, int WN, int EP, int DEPTH>
+__global__ __launch_bounds__(WM * WN * 64) void vit_gemm_kernel(GemmArgs a) {
+    constexpr int NTHR = WM * WN * 64;
+    constexpr int MI = BM / (WM * 16), NI = BN / (WN * 16);    // 16x16 MFMA tiles per wave along m / n (WM x WN waves)
     __shared__ __attribute__((aligned(16))) f16_t sX[2][BM * GEMM_BK];
     __shared__ __attribute__((aligned(16))) f16_t sW[2][BN * GEMM_BK];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wm = w >> 1, wn = w & 1;
+    const int wm = w / WN, wn = w % WN;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int r16 = lane & 15, qd = lane >> 4;
-    constexpr int XCH = BM * 8 / 256, WCH = BN * 8 / 256;   // 16-byte chunks per thread per tile
+    constexpr int XCH = BM * 8 / NTHR, WCH = BN * 8 / NTHR;   // 16-byte chunks per thread per tile
     // DEPTH = K tiles in flight (register ring)
     uint4 rx[DEPTH][XCH], rw[DEPTH][WCH];
 
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs a) {
     do {                                                                                                              \
         const int k0 = (k0_);                                                                                         \
         _Pragma("unroll") for (int i = 0; i < XCH; ++i) {                                                             \
-            const int id = tid + i * 256, row = id >> 3, c = id & 7;                                                  \
+            const int id = tid + i * NTHR, row = id >> 3, c = id & 7;                                                  \
             const int m = m0 + row;                                                                                   \
             uint4 v = make_uint4(0, 0, 0, 0);                                                                         \
             if (m < a.M) {                                                                                            \
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs a) {
             rx[slot][i] = v;                                                                                          \
         }                                                                                                             \
         _Pragma("unroll") for (int i = 0; i < WCH; ++i) {                                                             \
-            const int id = tid + i * 256, row = id >> 3, c = id & 7;                                                  \
+            const int id = tid + i * NTHR, row = id >> 3, c = id & 7;                                                  \
             const int n = n0 + row;                                                                                   \
             uint4 v = make_uint4(0, 0, 0, 0);                                                                         \
             if (n < a.N) v = *reinterpret_cast<const uint4 *>(a.W + (size_t)n * a.K + k0 + c * 8);                    \
@@ -102,11 +103,11 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs a) {
 #define STORE_TILE(slot, buf)                                                                                         \
     do {                                                                                                              \
         _Pragma("unroll") for (int i = 0; i < XCH; ++i) {                                                             \
-            const int id = tid + i * 256, row = id >> 3, c = id & 7;                                                  \
+            const int id = tid + i * NTHR, row = id >> 3, c = id & 7;                                                  \
             *reinterpret_cast<uint4 *>(&sX[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]) = rx[slot][i];               \
         }                                                                                                             \
         _Pragma("unroll") for (int i = 0; i < WCH; ++i) {                                                             \
-            const int id = tid + i * 256, row = id >> 3, c = id & 7;                                                  \
+            const int id = tid + i * NTHR, row = id >> 3, c = id & 7;                                                  \
             *reinterpret_cast<uint4 *>(&sW[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]) = rw[slot][i];               \
         }                                                                                                             \
     } while (0)
@@ -141,12 +142,12 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs a) {
                     const int c = kk * 4 + qd;
 #pragma unroll
                     for (int i = 0; i < MI; ++i) {
-                        const int row = wm * (BM / 2) + i * 16 + r16;
+                        const int row = wm * (BM / WM) + i * 16 + r16;
                         fx[i] = *reinterpret_cast<const frag_ab *>(&sX[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]);
                     }
 #pragma unroll
                     for (int jn = 0; jn < NI; ++jn) {
-                        const int row = wn * (BN / 2) + jn * 16 + r16;
+                        const int row = wn * (BN / WN) + jn * 16 + r16;
                         fw[jn] = *reinterpret_cast<const frag_ab *>(&sW[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]);
                     }
 #pragma unroll
@@ -165,11 +166,11 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(GemmArgs a) {
     // epilogue: lane holds out[m][n .. n+3], m = tile row (lane&15), n = tile col (lane>>4)*4
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wm * (BM / 2) + i * 16 + r16;
+        const int m = m0 + wm * (BM / WM) + i * 16 + r16;
         if (m >= a.M) continue;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 16 + qd * 4;
+            const int n = n0 + wn * (BN / WN) + j * 16 + qd * 4;
             if (n >= a.N) continue;
             const float4 bv = *reinterpret_cast<const float4 *>(a.bias + n);
             float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
@@ -222,15 +223,21 @@ template <int EP>
 static hipError_t gemm_launch(GemmArgs a, hipStream_t st) {
     if (a.K % GEMM_BK || (a.N & 3)) return hipErrorInvalidValue;
     // No split-K: slicing K with fp32 atomics into the residual stream measured no faster at one frame (3.50 vs
-    // 3.57 ms) and makes results depend on the atomic order; 128x128 tiles (4x4 MFMA tiles per wave, 64 KB LDS,
-    // ~200 VGPRs -> one block per CU) measured 1.5-1.9x SLOWER than 64x64 at B = 4..8.  Both stay out.
+    // 3.57 ms) and makes results depend on the atomic order.
     a.ksplit = 1;
+    static const int big_min_tiles = getenv("VLO_VIT_BIG_TILES") ? atoi(getenv("VLO_VIT_BIG_TILES")) : 200;
+    const int big_tiles = ((a.M + 127) / 128) * (a.N / 128);
     if (a.M <= 32) {
         dim3 grid((a.N + 63) / 64, (a.M + 31) / 32, 1);
-        hipLaunchKernelGGL((vit_gemm_kernel<32, 64, EP, 4>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((vit_gemm_kernel<32, 64, 2, 2, EP, 4>), grid, dim3(256), 0, st, a);
+    } else if (a.N % 128 == 0 && big_min_tiles > 0 && big_tiles >= big_min_tiles) {
+        // batched frames (offline feature extraction, deep prefetch): 128x128 tiles on 8 waves (2 x 4, each 64x32):
+        // half the L2->LDS bytes per FLOP of the 64x64 kernel, which is L2-bandwidth-bound (~450 TFLOP/s ceiling)
+        dim3 grid(a.N / 128, (a.M + 127) / 128, 1);
+        hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 4, EP, 2>), grid, dim3(512), 0, st, a);
     } else {
         dim3 grid((a.N + 63) / 64, (a.M + 63) / 64, 1);
-        hipLaunchKernelGGL((vit_gemm_kernel<64, 64, EP, 4>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((vit_gemm_kernel<64, 64, 2, 2, EP, 4>), grid, dim3(256), 0, st, a);
     }
     return hipGetLastError();
 }
@@ -684,7 +691,7 @@ static int vit_reserve(vlo_engine *e, VitState *v, int B) {
 int vlo_connector_reserve(vlo_engine *e);      // engine.hip
 
 // the ~180-launch encode of B frames: frames (uint8, device) -> out (bf16 [B*T][H], device)
-static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_dev, hipStream_t st) {
+static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_dev, hipStream_t st, bool with_connector = true) {
     VitState *v = e->vit;
     const int D = v->D, I = v->I, S = v->S, M = B * S;
     const float scale = 1.0f / sqrtf((float)v->hd);
@@ -755,6 +762,10 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
     }
     hipLaunchKernelGGL(pool_concat_kernel, dim3(1 + v->ph * v->pw, B, (D + 255) / 256), dim3(256), 0, st, v->last, v->tmp32, v->tokens, v->G, D, v->ph, v->pw);
     VIT_TRY(hipGetLastError());
+    if (!with_connector) {     // offline feature extraction: the CLS + pooled tokens themselves
+        VIT_TRY(hipMemcpyAsync(out_dev, v->tokens, (size_t)B * (1 + v->ph * v->pw) * D * 2, hipMemcpyDeviceToDevice, st));
+        return VLO_OK;
+    }
     // connector (bf16 skinny GEMMs, gemv.hip)
     return vlo_connector(e, v->tokens, B * (1 + v->ph * v->pw), out_dev, st);
 }
@@ -789,6 +800,13 @@ int vit_visual_embed(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_
     VIT_TRY(hipGraphLaunch(it->second, st));
     VIT_TRY(hipMemcpyAsync(out_dev, v->out_stage, out_bytes, hipMemcpyDeviceToDevice, st));
     return VLO_OK;
+}
+
+int vit_vision_tokens(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_dev, hipStream_t st) {
+    VitState *v = e->vit;
+    int rc;
+    if ((rc = vit_reserve(e, v, B))) return rc;
+    return vit_run(e, frames_dev, B, out_dev, st, false);
 }
 
 void vit_destroy(vlo_engine *e) {

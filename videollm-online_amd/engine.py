@@ -181,6 +181,21 @@ class Engine:
         _C.check(_C.lib().vlo_visual_embed(self._h, _ptr(frames_u8), B, _ptr(out), _stream_handle(stream)))
         return out
 
+    def vision_tokens(self, frames_u8: torch.Tensor, stream=None) -> torch.Tensor:
+        """CLS + pooled tokens before the connector: bf16 [B, frame_num_tokens, vision_hidden_size]."""
+        assert frames_u8.dtype == torch.uint8 and frames_u8.dim() == 4 and frames_u8.is_cuda
+        frames_u8 = frames_u8.contiguous()
+        B = frames_u8.shape[0]
+        out = torch.empty(B, self.cfg.frame_num_tokens, self.cfg.vision_hidden_size, dtype=torch.bfloat16, device=self.device)
+        _C.check(_C.lib().vlo_vision_tokens(self._h, _ptr(frames_u8), B, _ptr(out), _stream_handle(stream)))
+        return out
+
+    def encode_video(self, frames_u8: torch.Tensor, batch_size: int = 256) -> torch.Tensor:
+        """Offline feature extraction of one video, as data/utils.py:97-101 does it: split into batches of
+        ``batch_size`` frames, encode, concatenate, keep bf16 -> [T, frame_num_tokens, vision_hidden_size]."""
+        outs = [self.vision_tokens(frames_u8[i:i + batch_size].to(self.device)) for i in range(0, frames_u8.shape[0], batch_size)]
+        return torch.cat(outs)
+
     def llm_step(self, session: Session, embeds: torch.Tensor, want_last=True, want_all=False, stream=None):
         """Returns (last_logits [V] bf16 | None, all_logits [n,V] bf16 | None)."""
         embeds = embeds.to(device=self.device, dtype=torch.bfloat16).contiguous().view(-1, self.cfg.hidden_size)
