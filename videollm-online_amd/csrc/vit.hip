@@ -47,9 +47,15 @@ VLO_DEV float rh(float x) { return h2f(f2h(x)); }     // fp16 rounding point
 
 #define GEMM_BK 64
 
+// DEPTH == 0 selects the direct-to-LDS path: tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging,
+// no ds_write pass); the destination of a wave instruction is linear (base + lane*16 B), so the XOR swizzle of the
+// 16-byte chunks is applied to the per-lane SOURCE address — it permutes chunks inside one 128-B row segment, i.e.
+// coalescing is unchanged — and again on the fragment reads (cdna guide rule 21).  Two LDS buffers, one barrier per K tile.
 template <int BM, int BN, int WM, int WN, int EP, int DEPTH>
 __global__ __launch_bounds__(WM * WN * 64) void vit_gemm_kernel(GemmArgs a) {
     constexpr int NTHR = WM * WN * 64;
+    constexpr bool GLDS = (DEPTH == 0);
+    constexpr int RING = GLDS ? 1 : DEPTH;
     constexpr int MI = BM / (WM * 16), NI = BN / (WN * 16);    // 16x16 MFMA tiles per wave along m / n (WM x WN waves)
     __shared__ __attribute__((aligned(16))) f16_t sX[2][BM * GEMM_BK];
     __shared__ __attribute__((aligned(16))) f16_t sW[2][BN * GEMM_BK];
@@ -59,7 +65,7 @@ __global__ __launch_bounds__(WM * WN * 64) void vit_gemm_kernel(GemmArgs a) {
     const int r16 = lane & 15, qd = lane >> 4;
     constexpr int XCH = BM * 8 / NTHR, WCH = BN * 8 / NTHR;   // 16-byte chunks per thread per tile
     // DEPTH = K tiles in flight (register ring)
-    uint4 rx[DEPTH][XCH], rw[DEPTH][WCH];
+    uint4 rx[RING][XCH], rw[RING][WCH];
 
     // global -> registers for K tile starting at k0, into ring slot `slot` (compile-time after unrolling)
 #define LOAD_TILE(slot, k0_)                                                                                          \
@@ -121,6 +127,56 @@ __global__ __launch_bounds__(WM * WN * 64) void vit_gemm_kernel(GemmArgs a) {
     const int nk_all = a.K / GEMM_BK;
     const int nk = (EP == EP_RESID && a.ksplit > 1) ? nk_all / a.ksplit : nk_all;
     const int kbeg = (EP == EP_RESID && a.ksplit > 1) ? blockIdx.z * nk * GEMM_BK : 0;
+    if (GLDS) {
+        constexpr int XI = BM / 8 / (WM * WN), WI = BN / 8 / (WM * WN);     // 1-KiB (8-row) pieces per wave per tile
+        const int lrow = lane >> 3, lc = (lane & 7) ^ (lrow & 7);           // source chunk of this lane (swizzle on the source)
+        auto issue = [&](int buf, int k0) {
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const int piece = w * XI + i;
+                const int m = min(m0 + piece * 8 + lrow, a.M - 1);          // clamp: rows past M are computed and dropped
+                const f16_t *g = a.X + (size_t)m * a.ldx + k0 + lc * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                 (__attribute__((address_space(3))) void *)&sX[buf][piece * 8 * GEMM_BK], 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < WI; ++i) {
+                const int piece = w * WI + i;
+                const int n = min(n0 + piece * 8 + lrow, a.N - 1);
+                const f16_t *g = a.W + (size_t)n * a.K + k0 + lc * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                 (__attribute__((address_space(3))) void *)&sW[buf][piece * 8 * GEMM_BK], 16, 0, 0);
+            }
+        };
+        issue(0, kbeg);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) issue(buf ^ 1, kbeg + (kt + 1) * GEMM_BK);
+#pragma unroll
+            for (int kk = 0; kk < GEMM_BK / 32; ++kk) {
+                frag_ab fx[MI], fw[NI];
+                const int c = kk * 4 + qd;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int row = wm * (BM / WM) + i * 16 + r16;
+                    fx[i] = *reinterpret_cast<const frag_ab *>(&sX[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]);
+                }
+#pragma unroll
+                for (int jn = 0; jn < NI; ++jn) {
+                    const int row = wn * (BN / WN) + jn * 16 + r16;
+                    fw[jn] = *reinterpret_cast<const frag_ab *>(&sW[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < NI; ++jn) acc[i][jn] = mfma_f16(fw[jn], fx[i], acc[i][jn]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile kt+1 has landed (issued a whole compute phase ago)
+            __syncthreads();                                      // and every wave is done reading tile kt
+        }
+    } else {
     // prologue: DEPTH tiles in flight; the first one lands in LDS buffer 0
 #pragma unroll
     for (int j = 0; j < DEPTH; ++j)
@@ -159,6 +215,7 @@ __global__ __launch_bounds__(WM * WN * 64) void vit_gemm_kernel(GemmArgs a) {
                 __syncthreads();
             }
         }
+    }
     }
 #undef LOAD_TILE
 #undef STORE_TILE
@@ -234,7 +291,11 @@ static hipError_t gemm_launch(GemmArgs a, hipStream_t st) {
         // batched frames (offline feature extraction, deep prefetch): 128x128 tiles on 8 waves (2 x 4, each 64x32):
         // half the L2->LDS bytes per FLOP of the 64x64 kernel, which is L2-bandwidth-bound (~450 TFLOP/s ceiling)
         dim3 grid(a.N / 128, (a.M + 127) / 128, 1);
-        hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 4, EP, 2>), grid, dim3(512), 0, st, a);
+        static const bool use_glds = getenv("VLO_VIT_GLDS") ? atoi(getenv("VLO_VIT_GLDS")) != 0 : true;
+        if (use_glds && EP != EP_PATCH)
+            hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 4, EP, 0>), grid, dim3(512), 0, st, a);
+        else
+            hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 4, EP, 2>), grid, dim3(512), 0, st, a);
     } else {
         dim3 grid((a.N + 63) / 64, (a.M + 63) / 64, 1);
         hipLaunchKernelGGL((vit_gemm_kernel<64, 64, 2, 2, EP, 4>), grid, dim3(256), 0, st, a);
