@@ -60,6 +60,13 @@ __global__ __launch_bounds__(RMS_THREADS) void add_rmsnorm_kernel(bf16_t *__rest
             for (int j = 0; j < 8; ++j) ss += v[c][j] * v[c][j];
         }
     }
+    // norm weights are fetched BEFORE the block-wide reduction so their latency hides behind its two barriers
+    uint4 wraw[RMS_MAXCH];
+#pragma unroll
+    for (int c = 0; c < RMS_MAXCH; ++c) {
+        const int ch = threadIdx.x + c * RMS_THREADS;
+        wraw[c] = (ch < nch) ? *reinterpret_cast<const uint4 *>(w + ch * 8) : make_uint4(0, 0, 0, 0);
+    }
     ss = block_sum(ss, sm);
     const float rs = 1.0f / sqrtf(ss / (float)H + eps);
     bf16_t *xr = x + (size_t)m * ldx;
@@ -67,8 +74,7 @@ __global__ __launch_bounds__(RMS_THREADS) void add_rmsnorm_kernel(bf16_t *__rest
     for (int c = 0; c < RMS_MAXCH; ++c) {
         const int ch = threadIdx.x + c * RMS_THREADS;
         if (ch < nch) {
-            const uint4 wraw = *reinterpret_cast<const uint4 *>(w + ch * 8);
-            const bf16_t *we = reinterpret_cast<const bf16_t *>(&wraw);
+            const bf16_t *we = reinterpret_cast<const bf16_t *>(&wraw[c]);
             uint4 o;
             bf16_t *oe = reinterpret_cast<bf16_t *>(&o);
 #pragma unroll
