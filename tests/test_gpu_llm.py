@@ -307,3 +307,48 @@ def test_engine_from_checkpoint_with_lora_merge(tmp_path):
     e, r, scale = _three_way(allr.cpu(), rl, gl)
     assert e <= 1.5 * r + 1e-3 * scale, (e, r)
     sess.close(); eng.close()
+
+
+def test_error_paths_and_edge_inputs():
+    """Empty / malformed calls fail through the C-ABI error convention instead of touching the GPU; ragged steps work."""
+    import ctypes as C
+    from videollm_online_amd import _C
+    spec = O.LLM_SPECS["toy"]
+    w = O.init_llm_weights(spec, seed=0)
+    eng = _engine(spec, w, kv_pool_tokens=512)
+    sess = eng.new_session()
+    L = _C.lib()
+    x = torch.randn(3, spec.hidden_size).bfloat16().cuda()
+    assert L.vlo_llm_step(sess._h, C.c_void_p(x.data_ptr()), 0, None, None, None) == -1            # n = 0
+    assert b"llm_step" in L.vlo_last_error()
+    assert L.vlo_llm_step(None, C.c_void_p(x.data_ptr()), 3, None, None, None) == -1               # null session
+    tok = torch.zeros(1, dtype=torch.long, device="cuda")
+    assert L.vlo_stream_sample(sess._h, C.c_float(0.5), 11, C.c_void_p(tok.data_ptr()), None, None) == -4   # no logits yet
+    with pytest.raises(RuntimeError, match="without a vision tower"):
+        eng.visual_embed(torch.zeros(1, 3, 96, 96, dtype=torch.uint8, device="cuda"))
+    with pytest.raises(RuntimeError, match="already finalized"):
+        eng.load_weight("model.norm.weight", w["model.norm.weight"])
+    # ragged step sizes 1..17 in one session (17 = chunk boundary + 1) against the oracle
+    ref = O.LlamaOracle(spec, w, torch.bfloat16)
+    gold = O.LlamaOracle(spec, w, torch.float32)
+    g = torch.Generator().manual_seed(9)
+    rc = gc = None
+    for n in (1, 2, 15, 16, 17, 7):
+        xs = torch.randn(n, spec.hidden_size, generator=g).bfloat16()
+        rl, rc = ref.forward(xs, rc)
+        gl, gc = gold.forward(xs, gc)
+        last, _ = eng.llm_step(sess, xs.cuda())
+        torch.cuda.synchronize()
+        e = (last.cpu().float() - gl[-1]).abs().max().item()
+        r = (rl[-1].float() - gl[-1]).abs().max().item()
+        assert e <= 1.5 * r + 2e-3 * gl[-1].abs().max().item(), (n, e, r)
+    assert sess.get_seq_length() == 58
+    # a missing weight is reported by name at finalize
+    from videollm_online_amd.engine import Engine, EngineConfig
+    cfg = EngineConfig(hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size, num_hidden_layers=spec.num_layers,
+                       num_attention_heads=spec.num_heads, num_key_value_heads=spec.num_kv_heads, vocab_size=spec.vocab_size)
+    e2 = Engine(cfg)
+    e2.load_weights({k: v for k, v in w.items() if "layers.1.mlp.down_proj" not in k})
+    with pytest.raises(RuntimeError, match="missing weight: model.layers.1.mlp.down_proj.weight"):
+        e2.finalize()
+    e2.close(); sess.close(); eng.close()

@@ -177,13 +177,13 @@ static int take(vlo_engine *e, const std::string &name, std::vector<int64_t> sha
 // pack rows [row0, row0+N) x columns [col0, col0+K) of the full bf16 linear `name` [Nfull][Kfull] into dst tiles
 // (see gemv.hip); the slice is this rank's tensor-parallel shard (the whole matrix when tp_size == 1)
 static int pack_into(vlo_engine *e, const std::string &name, int Nfull, int Kfull, int row0, int N, int col0, int K, void *dst,
-                     int tile_stride, int tile_offset) {
+                     int tile_stride, int tile_offset, int half = -1) {
     RawTensor t;
     int rc = take(e, name, {Nfull, Kfull}, &t);
     if (rc) return rc;
-    const int NT = (N + 15) / 16;
+    const int NT = half < 0 ? (N + 15) / 16 : (N + 7) / 8;
     const unsigned short *src = (const unsigned short *)t.ptr + (size_t)row0 * Kfull + col0;
-    HIP_TRY(pack_weight_launch(src, dst, N, K, Kfull, NT, tile_stride, tile_offset, 0));
+    HIP_TRY(pack_weight_launch(src, dst, N, K, Kfull, NT, tile_stride, tile_offset, half, 0));
     return VLO_OK;
 }
 
@@ -242,8 +242,9 @@ int vlo_engine_finalize(vlo_engine *e) {
         if ((rc = pack_into(e, p + "self_attn.o_proj.weight", H, NqF, 0, H, r * Nq, Nq, L.o.Wp, 1, 0))) return rc;
         if ((rc = make_linear(e, &L.gate_up, 2 * I, H, false))) return rc;       // SwiGLU epilogue needs whole K
         if (I % 16) return fail(VLO_E_UNSUPPORTED, "intermediate_size (per rank) must be a multiple of 16");
-        if ((rc = pack_into(e, p + "mlp.gate_proj.weight", Ifull, H, r * I, I, 0, H, L.gate_up.Wp, 2, 0))) return rc;
-        if ((rc = pack_into(e, p + "mlp.up_proj.weight", Ifull, H, r * I, I, 0, H, L.gate_up.Wp, 2, 1))) return rc;
+        // gate and up share every tile (8 + 8 rows): I/8 single tiles, SwiGLU inside one tile
+        if ((rc = pack_into(e, p + "mlp.gate_proj.weight", Ifull, H, r * I, I, 0, H, L.gate_up.Wp, 1, 0, 0))) return rc;
+        if ((rc = pack_into(e, p + "mlp.up_proj.weight", Ifull, H, r * I, I, 0, H, L.gate_up.Wp, 1, 0, 1))) return rc;
         if ((rc = make_linear(e, &L.down, H, I, true))) return rc;
         if ((rc = pack_into(e, p + "mlp.down_proj.weight", H, Ifull, 0, H, r * I, I, L.down.Wp, 1, 0))) return rc;
         if ((rc = take_vec(e, p + "input_layernorm.weight", H, &L.ln_in))) return rc;
@@ -762,7 +763,7 @@ int vlo_test_gemv(const void *x_dev, const void *W_dev, float *y_dev, int n, int
     HIP_TRY(hipMalloc((void **)&P, (size_t)plan.ksplit * 16 * NT * 16 * 4));
     HIP_TRY(hipMemsetAsync(xp, 0, (size_t)32 * K * 2, st));
     HIP_TRY(hipMemcpyAsync(xp, x_dev, (size_t)n * K * 2, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(pack_weight_launch(W_dev, Wp, N, K, K, NT, 1, 0, st));
+    HIP_TRY(pack_weight_launch(W_dev, Wp, N, K, K, NT, 1, 0, -1, st));
     GemvArgs a{};
     a.Wp = Wp; a.x = (const unsigned short *)xp; a.out_f32 = P;
     a.K = K; a.ldx = K; a.ldo = NT * 16; a.NT = NT; a.N_valid = N; a.n_rows = n;
@@ -815,7 +816,7 @@ int vlo_bench_gemv(int N, int K, int n_rows, int epi, int iters, int nbuf, doubl
     HIP_TRY(hipMemset(pt, 0, 64));
     GemvArgs a{};
     a.x = (const unsigned short *)x; a.out_f32 = (float *)o32; a.out_bf16 = (unsigned short *)o16;
-    a.K = K; a.ldx = K; a.ldo = (epi == EPI_SWIGLU) ? NT * 8 : NT * 16; a.NT = NT; a.N_valid = N; a.n_rows = n_rows;
+    a.K = K; a.ldx = K; a.ldo = (epi == EPI_SWIGLU) ? NT * 8 : NT * 16; a.NT = NT; a.N_valid = N; a.n_rows = n_rows;   // SwiGLU: 8 output columns per tile
     int xsrc = XSRC_PLAIN;
     if (epi == EPI_SWIGLU && !(getenv("VLO_FUSE_NORM") && atoi(getenv("VLO_FUSE_NORM")) == 0)) {
         xsrc = XSRC_NORM;

@@ -10,7 +10,7 @@ enum {
     EPI_PARTIAL_F32 = 0,     // fp32 split-K partials [ksplit][16][ldo]            (unit tests)
     EPI_BF16 = 1,            // bf16(acc + bias)                                     (lm_head, connector.2)
     EPI_BF16_GELU_ERF = 2,   // HF python-GELU on bf16(acc + bias)                   (connector.0)
-    EPI_SWIGLU = 3,          // gate/up interleaved tiles -> bf16(silu(g) * u)       (gate_up)
+    EPI_SWIGLU = 3,          // tile = 8 gate rows + 8 up rows of the same columns -> bf16(silu(g) * u)   (gate_up)
     EPI_RESID = 4,           // h[m][col] = bf16(h + bf16(acc)); per-row sum of squares partials (o_proj, down_proj)
     EPI_ROPE = 5             // q/k/v split, RoPE, q buffer + paged K / V^T append   (qkv)
 };
@@ -54,5 +54,6 @@ int gemv_plan(int K, bool allow_ksplit, GemvPlan *p);
 int gemv_grid_x(const GemvArgs &a, const GemvPlan &p, int epi);
 hipError_t gemv_launch(GemvArgs a, const GemvPlan &p, int xsrc, int epi, hipStream_t st);
 // source tiles [0,NT) of row-major W[N_valid][K] (row stride ldw elements) -> packed tiles t*tile_stride + tile_offset of Wp
+// half = -1: 16-row tiles; half = 0/1: 8-row interleave of two matrices into one tile (gate / up)
 hipError_t pack_weight_launch(const void *W, void *Wp, int N_valid, int K, int ldw, int NT, int tile_stride, int tile_offset,
-                              hipStream_t st);
+                              int half, hipStream_t st);

@@ -41,18 +41,28 @@
 // to interleave gate/up 16-row tiles for the SwiGLU epilogue).
 // ------------------------------------------------------------------------------------
 // `ldw` = source row stride in elements (>= K): lets a tensor-parallel rank pack a column slice of W.
+// `half` = -1: whole 16-row tiles.  half = 0 / 1: 8-row interleave — source rows 8t..8t+7 land in rows 0..7 (half 0) or
+// 8..15 (half 1) of destination tile t and the other 8 lanes-rows are left untouched (gate/up share a tile so that the
+// SwiGLU epilogue finds both in ONE tile and I/8 single tiles balance over the 256 CUs).
 __global__ void pack_weight_kernel(const bf16_t *__restrict__ W, uint4 *__restrict__ Wp, int N_valid, int K, int ldw,
-                                   int NT, int KFtot, int tile_stride, int tile_offset) {
+                                   int NT, int KFtot, int tile_stride, int tile_offset, int half) {
     const size_t total = (size_t)NT * KFtot * 64;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int lane = (int)(i & 63);
         const size_t t = i >> 6;
         const int kf = (int)(t % KFtot);
         const int tile = (int)(t / KFtot);
-        const int n = tile * 16 + (lane & 15);
         const int k = kf * 32 + (lane >> 4) * 8;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (n < N_valid) v = *reinterpret_cast<const uint4 *>(W + (size_t)n * ldw + k);
+        if (half < 0) {
+            const int n = tile * 16 + (lane & 15);
+            if (n < N_valid) v = *reinterpret_cast<const uint4 *>(W + (size_t)n * ldw + k);
+        } else {
+            const int r16 = lane & 15;
+            if ((r16 >> 3) != half) continue;                     // the other half belongs to the other matrix
+            const int n = tile * 8 + (r16 & 7);
+            if (n < N_valid) v = *reinterpret_cast<const uint4 *>(W + (size_t)n * ldw + k);
+        }
         Wp[((size_t)(tile * tile_stride + tile_offset) * KFtot + kf) * 64 + lane] = v;
     }
 }
@@ -91,7 +101,7 @@ __global__ __launch_bounds__(NW * 64) void gemv16_kernel(GemvArgs a) {
     const int tph = (EPI == EPI_ROPE) ? hd / 16 : 2;           // tiles per head
     const int hp = tph / 2;                                    // rotary pairs of tiles per head
     // a.CT == 1: one tile per group (narrow outputs such as o_proj: NT = 256 tiles -> 256 blocks instead of 128)
-    const bool single = (EPI != EPI_ROPE && EPI != EPI_SWIGLU && a.CT == 1);
+    const bool single = (EPI != EPI_ROPE && a.CT == 1);
     const int ngroups = (EPI == EPI_ROPE) ? a.NT / 2 : (single ? a.NT : (a.NT + 1) / 2);
     auto tile_a = [&](int g) { return (EPI == EPI_ROPE) ? (g / hp) * tph + (g % hp) : (single ? g : 2 * g); };
     auto tile_b = [&](int g) { return (EPI == EPI_ROPE) ? (g / hp) * tph + (g % hp) + hp : (single ? a.NT : 2 * g + 1); };
@@ -201,8 +211,8 @@ __global__ __launch_bounds__(NW * 64) void gemv16_kernel(GemvArgs a) {
         __syncthreads();
 
         // ---- cross-wave reduction + epilogue ------------------------------------------------
-        if (EPI == EPI_SWIGLU || EPI == EPI_ROPE) {
-            // both tiles of the group are needed by the same lane (gate/up, rotary pair): one wave
+        if (EPI == EPI_ROPE) {
+            // both tiles of the group are needed by the same lane (rotary pair): one wave
             if (threadIdx.x < 64) {
                 const int l = lane;
                 float4 sA = make_float4(0, 0, 0, 0), sB = make_float4(0, 0, 0, 0);
@@ -214,13 +224,7 @@ __global__ __launch_bounds__(NW * 64) void gemv16_kernel(GemvArgs a) {
                 const int m = l & 15;
                 if (m < a.n_rows) {
                     const float va[4] = {sA.x, sA.y, sA.z, sA.w}, vb[4] = {sB.x, sB.y, sB.z, sB.w};
-                    if (EPI == EPI_SWIGLU) {
-                        const int col = g * 16 + (l >> 4) * 4;            // tiles (2g, 2g+1) = (gate, up) of columns 16g..
-                        bf16_t o[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = f2bf(silu_bf16(rbf(va[r])) * rbf(vb[r]));
-                        *reinterpret_cast<ushort4 *>(a.out_bf16 + (size_t)m * a.ldo + col) = *reinterpret_cast<const ushort4 *>(o);
-                    } else {
+                    {
                         const int half = hd >> 1, nh = a.num_heads, nkv = a.kv.num_kv_heads;
                         const int head = g / hp, i = (g % hp) * 16 + (l >> 4) * 4;   // column inside the head, < half
                         const long long pos = a.pos0 + m;
@@ -267,7 +271,19 @@ __global__ __launch_bounds__(NW * 64) void gemv16_kernel(GemvArgs a) {
                 const int m = l & 15;
                 const int col = tile * 16 + (l >> 4) * 4;
                 const bool live = (m < a.n_rows) && (tile < a.NT);
-                if (EPI == EPI_RESID) {
+                if (EPI == EPI_SWIGLU) {
+                    // tile = 8 gate rows (fragment rows 0..7, lanes 0..31) + the 8 up rows of the same columns (lanes 32..63)
+                    if (live && l < 32) {
+                        float4 u = make_float4(0, 0, 0, 0);
+#pragma unroll
+                        for (int ww = 0; ww < NW; ++ww) u = f4add(u, rb[(ww * CTG + ct) * 64 + l + 32]);
+                        const float gv[4] = {s.x, s.y, s.z, s.w}, uv[4] = {u.x, u.y, u.z, u.w};
+                        bf16_t o[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = f2bf(silu_bf16(rbf(gv[r])) * rbf(uv[r]));
+                        *reinterpret_cast<ushort4 *>(a.out_bf16 + (size_t)m * a.ldo + tile * 8 + (l >> 4) * 4) = *reinterpret_cast<const ushort4 *>(o);
+                    }
+                } else if (EPI == EPI_RESID) {
                     float sq = 0.f;
                     if (live) {
                         bf16_t *hp4 = a.h + (size_t)m * a.ldo + col;
@@ -349,11 +365,16 @@ int gemv_plan(int K, bool allow_ksplit, GemvPlan *p) {
     return -1;
 }
 
-// groups of two column tiles, or single tiles when pairs would leave CUs idle (pairing is mandatory for the
-// rotary and gate/up epilogues)
+// groups of two column tiles, or single tiles when that balances better over the CUs (pairs are mandatory for the
+// rotary epilogue).  e.g. gate/up: 1792 tiles = 7.0 per CU as singles, 896 pairs = 3.5 -> 4 per CU (87.5 %).
 static bool single_tile_groups(const GemvArgs &a, const GemvPlan &p, int epi) {
-    if (epi == EPI_ROPE || epi == EPI_SWIGLU) return false;
-    return ((a.NT + 1) / 2) * p.ksplit < 256;
+    if (epi == EPI_ROPE) return false;
+    const int slots = 256 / p.ksplit > 0 ? 256 / p.ksplit : 1;
+    auto eff = [&](int items) {
+        const int rounds = (items + slots - 1) / slots;
+        return (double)items / ((double)rounds * slots);
+    };
+    return eff(a.NT) > eff((a.NT + 1) / 2) + 0.2;     // HBM saturates below 256 CUs: a 12 % idle-CU tail costs less than 2x the barriers
 }
 static int groups_of(const GemvArgs &a, const GemvPlan &p, int epi) {
     if (epi == EPI_ROPE) return a.NT / 2;
@@ -396,7 +417,6 @@ static hipError_t launch_variant(const GemvArgs &a, int xsrc, int epi, dim3 grid
 hipError_t gemv_launch(GemvArgs a, const GemvPlan &p, int xsrc, int epi, hipStream_t st) {
     if (epi != EPI_PARTIAL_F32 && p.ksplit != 1) return hipErrorInvalidValue;
     if (epi == EPI_ROPE && ((a.NT & 1) || (a.kv.head_dim != 64 && a.kv.head_dim != 128))) return hipErrorInvalidValue;
-    if (epi == EPI_SWIGLU && (a.NT & 1)) return hipErrorInvalidValue;
     a.CT = single_tile_groups(a, p, epi) ? 1 : 2;
     a.KC = p.KC;
     dim3 grid(gemv_grid_x(a, p, epi), p.ksplit);
@@ -410,12 +430,12 @@ hipError_t gemv_launch(GemvArgs a, const GemvPlan &p, int xsrc, int epi, hipStre
 }
 
 hipError_t pack_weight_launch(const void *W, void *Wp, int N_valid, int K, int ldw, int NT, int tile_stride, int tile_offset,
-                              hipStream_t st) {
+                              int half, hipStream_t st) {
     const int KFtot = K >> 5;
     const size_t total = (size_t)NT * KFtot * 64;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 65535) blocks = 65535;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, st, (const bf16_t *)W, (uint4 *)Wp, N_valid, K, ldw, NT,
-                       KFtot, tile_stride, tile_offset);
+                       KFtot, tile_stride, tile_offset, half);
     return hipGetLastError();
 }
