@@ -51,3 +51,28 @@ def test_single_process_passthrough():
     assert bench.reduce_elapsed_max(None, 3.5) == 3.5
     assert bench.aggregate_fps(1200, 1, 12.0) == 100.0
     assert bench.usable_cores() >= 1
+
+
+def _uid_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from videollm_online_amd.engine import TpGroup
+    # bench.py --tp bootstrap: rank 0 creates the RCCL unique id (librccl is dlopen'ed by libvlo.so; no GPU needed for
+    # this call), every rank receives the same 128 bytes
+    uid = [TpGroup.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    q.put((rank, bytes(uid[0])))
+    dist.destroy_process_group()
+
+
+def test_tp_unique_id_broadcast_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_uid_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = dict(q.get(timeout=180) for _ in range(world))
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    assert len(res[0]) == 128 and res[0] == res[1] and any(res[0])
