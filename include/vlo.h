@@ -187,6 +187,10 @@ int vlo_profile_read(vlo_engine *e, int64_t *launches, double *total_ms, double 
  * the fixed cost every bracket above includes on top of the kernel's own duration */
 int vlo_profile_calibrate(vlo_engine *e, void *stream, double *empty_bracket_us);
 
+/* host-side planner of the weight-streaming GEMV (no GPU needed): for a reduction length K returns
+ * out4 = {waves per block, fragments per wave per chunk, K chunks per wave, K slices across blocks}; < 0 if K is not covered */
+int vlo_debug_gemv_plan(int K, int allow_ksplit, int *out4);
+
 /* micro-benchmark of the weight-streaming GEMV on synthetic data (tools/bench_gemv.py): `nbuf` distinct
  * packed weight images are cycled so the 256 MiB Infinity Cache cannot serve re-reads. */
 int vlo_bench_gemv(int N, int K, int n_rows, int epi, int iters, int nbuf, double *avg_us);

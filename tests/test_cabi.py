@@ -55,3 +55,25 @@ def test_engine_refuses_to_run_without_gpu():
     from videollm_online_amd.engine import Engine, EngineConfig
     with pytest.raises(RuntimeError, match="no CPU path"):
         Engine(EngineConfig(64, 128, 1, 4, 2, 128))
+
+
+def test_gemv_planner_covers_every_model_shape():
+    """Host-side planner (no GPU): every reduction length of the supported models — incl. the tensor-parallel shards —
+    decomposes as K/32 = waves x fragments x chunks x slices, and whole-K plans never split across blocks."""
+    import ctypes as C
+    from videollm_online_amd import _C
+    L = _C.lib()
+    out = (C.c_int * 4)()
+    shapes = {  # K : where it occurs
+        4096: "8B hidden", 14336: "8B intermediate", 2048: "TinyLlama hidden / 8B o_proj TP=2", 5632: "TinyLlama intermediate",
+        8192: "70B hidden", 28672: "70B intermediate", 1024: "connector / SigLIP", 7168: "8B I/2", 3584: "8B I/4 / 70B I/8",
+        1792: "8B I/8", 512: "8B o_proj TP=8", 1408: "TinyLlama I/4", 256: "toy", 704: "toy", 128: "toy vision"}
+    for K, where in shapes.items():
+        for allow in (0, 1):
+            assert L.vlo_debug_gemv_plan(K, allow, out) == 0, (K, where)
+            nw, kf, kc, ks = list(out)
+            assert nw * kf * kc * ks * 32 == K, (K, where, list(out))
+            assert nw in (1, 2, 4, 8) and 1 <= kf <= 16
+            if not allow:
+                assert ks == 1
+    assert L.vlo_debug_gemv_plan(100, 0, out) < 0 and b"no GEMV plan" in L.vlo_last_error()    # K % 32 != 0

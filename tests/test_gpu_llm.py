@@ -352,3 +352,39 @@ def test_error_paths_and_edge_inputs():
     with pytest.raises(RuntimeError, match="missing weight: model.layers.1.mlp.down_proj.weight"):
         e2.finalize()
     e2.close(); sess.close(); eng.close()
+
+
+def test_full_depth_tinyllama_parity():
+    """BASELINE.json configs[0] shape at FULL depth (TinyLlama-1.1B, 22 layers): error accumulation over the whole
+    stack stays at the reference-bf16 level and the sampled tokens agree (near-ties excepted)."""
+    spec = O.LLM_SPECS["tinyllama-1.1b"]
+    w = O.init_llm_weights(spec, seed=11)
+    toks = O.default_tokens(spec, seed=7, n_start=35)
+    ref = O.LlamaOracle(spec, w, torch.bfloat16)
+    gold = O.LlamaOracle(spec, w, torch.float32)
+    eng = _engine(spec, w, kv_pool_tokens=2048)
+    sess = eng.new_session()
+    g = torch.Generator().manual_seed(21)
+    frame = lambda: torch.randn(10, spec.hidden_size, generator=g).bfloat16()
+    steps = [torch.cat([ref.embed(torch.tensor(toks.start_ids)), frame()])] + \
+            [torch.cat([ref.embed(torch.tensor([toks.interval_id])), frame()]) for _ in range(4)] + \
+            [ref.embed(torch.tensor(toks.stream_generation_ids))] + [ref.embed(torch.tensor([100 + i])) for i in range(3)]
+    rc = gc = None
+    agree = 0
+    for i, x in enumerate(steps):
+        rl, rc = ref.forward(x, rc)
+        gl, gc = gold.forward(x, gc)
+        last, _ = eng.llm_step(sess, x.cuda())
+        torch.cuda.synchronize()
+        last = last.cpu()
+        e = (last.float() - gl[-1]).abs().max().item()
+        r = (rl[-1].float() - gl[-1]).abs().max().item()
+        scale = gl[-1].abs().max().item()
+        print(f"[tinyllama-1.1b full] step {i} n={x.shape[0]}: engine err {e:.4g} ref-bf16 err {r:.4g} scale {scale:.3g}")
+        assert e <= 1.5 * r + 2e-3 * scale, (i, e, r)
+        te, tr = int(last.float().argmax()), int(rl[-1].float().argmax())
+        assert _tokens_agree(te, gl[-1], tr), (i, te, tr)
+        agree += te == tr
+    assert agree >= len(steps) - 2
+    assert sess.get_seq_length() == len(rc)
+    sess.close(); eng.close()

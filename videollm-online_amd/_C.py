@@ -33,7 +33,7 @@ EXPORTS = [
     "vlo_engine_destroy", "vlo_engine_weight_bytes", "vlo_session_create", "vlo_session_reset", "vlo_session_len",
     "vlo_session_destroy", "vlo_visual_embed", "vlo_vision_tokens", "vlo_connector", "vlo_embed", "vlo_llm_step", "vlo_stream_sample",
     "vlo_greedy_generate", "vlo_session_read_kv", "vlo_step_algorithmic_bytes", "vlo_test_gemv",
-    "vlo_profile_enable", "vlo_profile_read", "vlo_bench_gemv", "vlo_debug_read", "vlo_profile_calibrate",
+    "vlo_profile_enable", "vlo_profile_read", "vlo_bench_gemv", "vlo_debug_read", "vlo_profile_calibrate", "vlo_debug_gemv_plan",
     "vlo_tp_unique_id", "vlo_tp_group_create", "vlo_tp_group_destroy", "vlo_tp_session_create", "vlo_tp_session_reset",
     "vlo_tp_session_len", "vlo_tp_session_destroy", "vlo_tp_llm_step", "vlo_tp_stream_sample", "vlo_tp_greedy_generate",
 ]
@@ -81,6 +81,7 @@ def lib():
     L.vlo_test_gemv.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.vlo_bench_gemv.argtypes = [i32, i32, i32, i32, i32, i32, C.POINTER(C.c_double)]
     L.vlo_debug_read.argtypes = [vp, i32, vp, i64, vp]
+    L.vlo_debug_gemv_plan.argtypes = [i32, i32, C.POINTER(i32)]
     L.vlo_profile_calibrate.argtypes = [vp, vp, C.POINTER(C.c_double)]
     L.vlo_tp_unique_id.argtypes = [vp]
     L.vlo_tp_group_create.argtypes = [C.POINTER(vp), i32, vp, C.POINTER(vp)]

@@ -854,3 +854,10 @@ int vlo_debug_read(vlo_session *s, int which, void *dst_dev, int64_t bytes, void
     HIP_TRY(hipMemcpyAsync(dst_dev, src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return VLO_OK;
 }
+
+int vlo_debug_gemv_plan(int K, int allow_ksplit, int *out4) {
+    GemvPlan p;
+    if (!out4 || gemv_plan(K, allow_ksplit != 0, &p)) return fail(VLO_E_UNSUPPORTED, "no GEMV plan for K=" + std::to_string(K));
+    out4[0] = p.NW; out4[1] = p.KF; out4[2] = p.KC; out4[3] = p.ksplit;
+    return VLO_OK;
+}
