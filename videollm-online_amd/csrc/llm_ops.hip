@@ -166,17 +166,25 @@ __global__ __launch_bounds__(512) void attn_chunk_kernel(const bf16_t *__restric
     const bf16_t *kbase = kv.k_pool + (size_t)layer * kv.layer_stride;
     const bf16_t *vbase = kv.vt_pool + (size_t)layer * kv.layer_stride;
 
-    for (int kt0 = c0 + ks * 32; kt0 < c1; kt0 += KS * 32) {
+    // K fragments are fetched one 32-key block AHEAD (register double buffer), so the HBM latency of block i+1 hides
+    // behind the MFMAs / softmax of block i; V^T fragments of the current block are issued first thing in the
+    // iteration and are only needed after QK^T + softmax.
+    auto load_k = [&](int kt0, frag_ab (&dst)[2][NKK]) {
         const int page = kv.page_table[kt0 / VLO_PAGE_TOKENS];
-        const int tok0 = kt0 % VLO_PAGE_TOKENS;
-        const bf16_t *kp = kbase + (size_t)page * kv.page_elems + ((size_t)kvh * VLO_PAGE_TOKENS + tok0) * HD;
-        const bf16_t *vp = vbase + (size_t)page * kv.page_elems + ((size_t)kvh * HD) * VLO_PAGE_TOKENS + tok0;
-        frag_ab kf[2][NKK];
+        const bf16_t *kp = kbase + (size_t)page * kv.page_elems + ((size_t)kvh * VLO_PAGE_TOKENS + kt0 % VLO_PAGE_TOKENS) * HD;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk)
-                kf[t][kk] = *reinterpret_cast<const frag_ab *>(kp + (size_t)(t * 16 + qrow) * HD + kk * 32 + qd * 8);
+                dst[t][kk] = *reinterpret_cast<const frag_ab *>(kp + (size_t)(t * 16 + qrow) * HD + kk * 32 + qd * 8);
+    };
+    frag_ab kf[2][NKK], kn[2][NKK];
+    const int kfirst = c0 + ks * 32;
+    if (kfirst < c1) load_k(kfirst, kf);
+    for (int kt0 = kfirst; kt0 < c1; kt0 += KS * 32) {
+        const int page = kv.page_table[kt0 / VLO_PAGE_TOKENS];
+        const int tok0 = kt0 % VLO_PAGE_TOKENS;
+        const bf16_t *vp = vbase + (size_t)page * kv.page_elems + ((size_t)kvh * HD) * VLO_PAGE_TOKENS + tok0;
         frag_ab vf[NDT];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
@@ -185,6 +193,8 @@ __global__ __launch_bounds__(512) void attn_chunk_kernel(const bf16_t *__restric
             const uint2 hi = *reinterpret_cast<const uint2 *>(vr + 16);
             vf[dt] = __builtin_bit_cast(frag_ab, make_uint4(lo.x, lo.y, hi.x, hi.y));
         }
+        const bool more = kt0 + KS * 32 < c1;
+        if (more) load_k(kt0 + KS * 32, kn);
         const int kb = kt0 + qd * 4;
 #pragma unroll
         for (int h = 0; h < HPW; ++h) {
@@ -225,6 +235,12 @@ __global__ __launch_bounds__(512) void attn_chunk_kernel(const bf16_t *__restric
                 o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
                 O[h][dt] = mfma_bf16(vf[dt], pb, o);
             }
+        }
+        if (more) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) kf[t][kk] = kn[t][kk];
         }
     }
 #pragma unroll
@@ -337,7 +353,8 @@ hipError_t attention_launch(const unsigned short *q, KvGeom kv, int layer, int n
     }
     // splits: ~one block per CU at long context; every wave should see at least one 32-key block
     int target = (L + KS * 32 - 1) / (KS * 32);
-    const int want = (256 + nkv - 1) / nkv;
+    static const int want_blocks = getenv("VLO_ATTN_BLOCKS") ? atoi(getenv("VLO_ATTN_BLOCKS")) : 256;
+    const int want = (want_blocks + nkv - 1) / nkv;
     if (target > want) target = want;
     if (target > VLO_MAX_SPLITS) target = VLO_MAX_SPLITS;
     if (target < 1) target = 1;
