@@ -613,3 +613,197 @@ def default_tokens(spec: LlmSpec, seed: int = 7, n_start: int = 35) -> StreamTok
     return StreamTokens(start_ids=start, stream_prompt_ids=rnd(2), stream_generation_ids=rnd(4),
                         eos_token_id=eos, interval_id=interval,
                         query_ids={"Please narrate the video in real time.": rnd(12)})
+
+
+# --------------------------------------------------------------------------------------
+# Teacher-forced evaluation: joint_embed / stream_evaluate / trim_past_key_values
+# (models/modeling_live.py:29-42, 44-168, 170-171) — SURVEY.md §8(f) rank 4
+# --------------------------------------------------------------------------------------
+def joint_embed(model: LlamaOracle, input_ids: torch.Tensor, frame_embeds: torch.Tensor | None, v_placeholder_id: int):
+    """models/modeling_live.py:29-42 with ``frame_embeds`` = visual_embed(frames) already computed
+    ([num_frames * frame_num_tokens, H]).  Ids are clamped to the vocabulary before the lookup (:38);
+    rows holding the placeholder are then overwritten in order (:39-41)."""
+    ids = input_ids.view(-1)
+    x = model.embed(ids.clamp(max=model.spec.vocab_size - 1)).clone()
+    at_v = ids == v_placeholder_id
+    if at_v.any():
+        if frame_embeds is None or int(at_v.sum()) != frame_embeds.shape[0]:
+            raise ValueError(f"{int(at_v.sum())} placeholder positions but "
+                             f"{0 if frame_embeds is None else frame_embeds.shape[0]} frame-token embeddings")
+        x[at_v] = frame_embeds.to(x.dtype)
+    return x
+
+
+def cache_prefix(cache: KVCacheOracle, stop: int) -> KVCacheOracle:
+    """trim_past_key_values(past, 0, stop) (models/modeling_live.py:170-171): a NEW cache holding the
+    first ``stop`` positions of every layer; the source cache is left untouched (the reference slices
+    views and DynamicCache.update concatenates into fresh tensors)."""
+    out = KVCacheOracle(len(cache.k))
+    for i in range(len(cache.k)):
+        out.k[i], out.v[i] = cache.k[i][:, :stop], cache.v[i][:, :stop]
+    return out
+
+
+def synthetic_eval_sample(spec: LlmSpec, toks: StreamTokens, turns, frame_num_tokens: int = 10, seed: int = 11,
+                          v_placeholder_id: int | None = None):
+    """A multi-turn teacher-forced sample with the token layout of the reference's chat template
+    (models/tokenization_live.py:27-65, learn ranges :84-105, label shift :137-146):
+
+        start_ids   { <v>*10 (, <v>*10)*  ]\\nAssistant: <response> EOS  \\n[ }*
+
+    ``turns`` = [(num_frames, response_len, learn_frames)] per turn.  Labels are next-token targets on
+    the last <v> of each learnt frame (the interval, or ``]`` for the frame the reply follows), on the
+    ``]\\nAssistant:`` tokens and on the response through EOS; everything else is -100.  Placeholder
+    targets are replaced by EOS as the reference's collator does (:148-150).
+    Returns (input_ids [n], labels [n], total_frames)."""
+    g = torch.Generator().manual_seed(seed)
+    V = spec.vocab_size
+    v_id = V if v_placeholder_id is None else v_placeholder_id
+    ids, learn = list(toks.start_ids), [False] * len(toks.start_ids)
+    total = 0
+    for t, (nf, resp_len, learn_frames) in enumerate(turns):
+        if t > 0:
+            ids += list(toks.stream_prompt_ids); learn += [False] * len(toks.stream_prompt_ids)
+        for f in range(nf):
+            if f > 0:
+                ids.append(toks.interval_id); learn.append(False)
+            ids += [v_id] * frame_num_tokens
+            learn += [False] * (frame_num_tokens - 1) + [f < learn_frames or f == nf - 1]
+        total += nf
+        gen = list(toks.stream_generation_ids)
+        resp = torch.randint(12, V - 4, (resp_len,), generator=g).tolist()
+        resp = [i if i not in (toks.eos_token_id, toks.interval_id) else i + 1 for i in resp]
+        ids += gen + resp + [toks.eos_token_id]
+        learn += [True] * (len(gen) + resp_len) + [False]
+    input_ids = torch.tensor(ids, dtype=torch.long)
+    labels = torch.full_like(input_ids, -100)
+    m = torch.tensor(learn)
+    labels[m] = torch.roll(input_ids, -1)[m]
+    labels[labels >= V] = toks.eos_token_id
+    return input_ids, labels, total
+
+
+@torch.no_grad()
+def stream_evaluate(model: LlamaOracle, input_ids: torch.Tensor, labels: torch.Tensor, frame_embeds: torch.Tensor, *,
+                    v_placeholder_id: int, interval_id: int | None, eos_token_id: int, frame_num_tokens: int = 10,
+                    threshold: float = 0.0, ignore_token_id: int = -100, detail: dict | None = None):
+    """models/modeling_live.py:44-168.  Returns float32 [lm_ppl, frame_diff, fluency, lm_correctness].
+
+    One full-sequence forward (:67), then per dialogue turn (EOS-delimited, :62-63):
+      * LM perplexity / leading-correct fraction over learnt non-placeholder positions (:93-102);
+      * time-to-reply error in frames over learnt placeholder positions (:105-149): first position
+        whose softmax argmax is not the interval token; if there is none, the KV prefix up to the
+        last streamed frame is continued with the next turn's frames to see how LATE the reply comes;
+      * fluency (:152-161).
+    Reference quirks kept on purpose: thresholding zeroes the whole score row (:110-111, so its argmax
+    becomes id 0); a turn without learnt tokens does not advance the frame counter (:83-84 vs :163)."""
+    ids, lab = input_ids.view(-1), labels.view(-1)
+    fnt = frame_num_tokens
+    sil = interval_id if interval_id is not None else eos_token_id           # :72-73
+    logits, cache = model.forward(joint_embed(model, ids, frame_embeds, v_placeholder_id), None)
+    stops = ((ids == eos_token_id).nonzero().view(-1) + 1).tolist()
+    starts = [0] + stops[:-1]
+
+    margins = []                            # test bookkeeping: how far each decision is from flipping
+
+    def replies(rows, used=None):           # rows of logits -> bool per row: "the model speaks here"
+        sc = rows.softmax(dim=-1)
+        p_sil = sc[:, sil].float().clone()
+        if threshold > 0:
+            sc[sc[:, sil] < threshold] = 0
+        out = sc.argmax(dim=-1) != sil
+        if detail is not None:
+            z = rows.float()
+            others = z.clone()
+            others[:, sil] = -float("inf")
+            gap = (z[:, sil] - others.max(dim=-1).values).abs()
+            if threshold > 0:
+                # a row speaks if p_sil < threshold OR another token beats the interval
+                gap = torch.where(p_sil < threshold, (threshold - p_sil) * 8, torch.minimum(gap, (p_sil - threshold) * 8))
+            sel = torch.ones_like(out) if used is None else used
+            n_dec = int(out[sel].nonzero()[0, 0]) + 1 if out[sel].any() else int(sel.sum())
+            margins.extend(gap[sel][:n_dec].tolist())
+        return out
+
+    ppls, diffs, fluencies, corrects = [], [], [], []
+    frames_seen = 0
+    turn_log = []
+    for r, (a, b) in enumerate(zip(starts, stops)):
+        L = lab[a:b]
+        learnt = L != ignore_token_id
+        if not learnt.any():
+            continue
+        Z, I = logits[a:b], ids[a:b]
+        at_v = I == v_placeholder_id
+        n_frames = int(at_v.sum()) // fnt
+        on_stream = at_v & learnt
+        on_text = learnt & ~on_stream
+        n_ok = diff = branch = None
+        if on_text.any():
+            zt, lt = Z[on_text], L[on_text]
+            ppls.append(F.cross_entropy(zt, lt).exp())
+            wrong = zt.argmax(dim=-1) != lt
+            n_ok = int(wrong.nonzero()[0, 0]) if wrong.any() else int((~wrong).sum())
+            if detail is not None:
+                t2 = zt.float().topk(2).values
+                at_label = zt.float().gather(1, lt[:, None])[:, 0]
+                m = torch.where(wrong, t2[:, 0] - at_label, t2[:, 0] - t2[:, 1])
+                margins.extend(m[:n_ok + 1].tolist())
+            corrects.append(torch.tensor(n_ok) / lt.numel())
+        if on_stream.any():
+            speak = replies(Z, on_stream)[on_stream]
+            branch = "hit"
+            n_stream = int(on_stream.sum())
+            if speak.any():
+                diff = n_stream - int(speak.nonzero()[0, 0]) - 1
+            else:
+                keep = a + int(on_stream.nonzero()[-1, 0]) + 1
+                if r == len(starts) - 1:
+                    diff, branch = 0, "late-last-turn"
+                else:
+                    nxt = int((ids[starts[r + 1]:stops[r + 1]] == v_placeholder_id).sum()) // fnt
+                    k = min(nxt, n_frames - 1)
+                    if k == 0:
+                        diff, branch = 0, "late-no-room"
+                    else:
+                        f0 = frames_seen + n_frames
+                        unit = ([interval_id] if interval_id is not None else []) + [v_placeholder_id] * fnt
+                        more = torch.tensor(unit * k, dtype=torch.long)
+                        z2, _ = model.forward(joint_embed(model, more, frame_embeds[f0 * fnt:(f0 + k) * fnt], v_placeholder_id),
+                                              cache_prefix(cache, keep))
+                        late = replies(z2[len(unit) - 1::len(unit)])
+                        diff = -(int(late.nonzero()[0, 0]) + 1) if late.any() else -k
+                        branch = "late-hit" if late.any() else "late-none"
+            diffs.append(abs(diff))
+        if on_text.any() and on_stream.any():
+            n_v = int(on_stream.sum())
+            denom = int(on_text.sum()) + n_v
+            if diff == 0:
+                fluencies.append((n_v + n_ok) / denom)
+            elif diff > 0:
+                fluencies.append((n_v - diff) / denom)
+            else:
+                fluencies.append((n_v - 1) / denom)
+        turn_log.append((r, n_ok, diff, branch))
+        frames_seen += n_frames
+    if detail is not None:
+        detail["turns"], detail["logits"], detail["cache"], detail["margins"] = turn_log, logits, cache, margins
+    lm_ppl = torch.stack(ppls).mean().float() if ppls else torch.tensor(1.0)
+    frame_diff = torch.tensor(diffs, dtype=torch.float32).mean() if diffs else torch.tensor(0.0)
+    fluency = torch.tensor(fluencies, dtype=torch.float32).mean() if fluencies else torch.tensor(1.0)
+    correct = torch.stack(corrects).float().mean() if corrects else torch.tensor(1.0)
+    return torch.stack([lm_ppl, frame_diff, fluency, correct])
+
+
+def eval_case_from_golden(g, c: int, spec: LlmSpec, base_seed: int = 3):
+    """Rebuild case ``c`` of tests/golden/eval_toy128.npz: (weights with the patched interval row, input_ids, labels,
+    vision features [T, 10, vision_hidden], threshold).  The recipe lives in oracle/make_golden.py::eval_case."""
+    w = init_llm_weights(spec, seed=base_seed, dtype=torch.bfloat16)
+    toks = default_tokens(spec, seed=7, n_start=19)
+    w["lm_head.weight"] = w["lm_head.weight"].clone()
+    w["lm_head.weight"][toks.interval_id] = torch.from_numpy(g[f"c{c}_interval_row"]).to(torch.bfloat16)
+    ids, labels = torch.from_numpy(g[f"c{c}_ids"]), torch.from_numpy(g[f"c{c}_labels"])
+    T = int((ids == spec.vocab_size).sum()) // 10
+    gen = torch.Generator().manual_seed(int(g[f"c{c}_feat_seed"]))
+    feats = torch.randn(T, 10, spec.vision_hidden_size, generator=gen)
+    return w, toks, ids, labels, feats, float(g[f"c{c}_threshold"])
