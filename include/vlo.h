@@ -154,6 +154,28 @@ double vlo_step_algorithmic_bytes(const vlo_engine *e, int64_t Lc, int n);
  * W_dev is an ordinary row-major device tensor; packs on every call (tests only). */
 int vlo_test_gemv(const void *x_dev, const void *W_dev, float *y_dev, int n, int N, int K, void *stream);
 
+/* ---- teacher-forced evaluation: the arithmetic of LiveMixin.joint_embed / stream_evaluate /
+ *      trim_past_key_values (models/modeling_live.py:29-42, 44-168, 170-171).  The per-turn bookkeeping over these
+ *      per-row numbers stays on the host (videollm-online_amd/modeling_live.py::LiveModel.stream_evaluate).
+ *
+ * joint_embed (:29-42): out[i] = ids[i] == v_placeholder_id ? frame_rows[r_i] : embed_tokens[min(ids[i], vocab-1)], r_i =
+ *      number of placeholder positions before i.  ids_dev int64 [k]; frame_rows_dev bf16 [n_frame_rows, hidden] (the
+ *      output of vlo_visual_embed / vlo_connector); out_dev bf16 [k, hidden].  Synchronises the stream; fails with
+ *      VLO_E_INVALID when the number of placeholder positions != n_frame_rows (the reference's masked assignment raises). */
+int vlo_joint_embed(vlo_engine *e, const int64_t *ids_dev, int k, int64_t v_placeholder_id, const void *frame_rows_dev,
+                    int n_frame_rows, void *out_dev, void *stream);
+/* per-row statistics of logits_dev bf16 [n, vocab] (e.g. vlo_llm_step's all_logits_dev): lse (fp32 log-sum-exp; cross
+ *      entropy :95 = lse - label_logit), argmax (:97), label_logit = logits[r][labels[r]] (labels_dev int64 [n] or NULL;
+ *      0 for labels outside the vocabulary), p_interval = bf16-rounded softmax probability of interval_id (:107-110),
+ *      p_argmax = argmax of the bf16-rounded softmax row (:112, :144).  All outputs are device arrays of n elements. */
+int vlo_logit_rows(vlo_engine *e, const void *logits_dev, int n, const int64_t *labels_dev, int interval_id, float *lse_dev,
+                   int64_t *argmax_dev, float *label_logit_dev, float *p_interval_dev, int64_t *p_argmax_dev, void *stream);
+/* trim_past_key_values(past, 0, n_tokens) (:170-171) as the reference uses it (:118, :134): a NEW session holding a copy
+ *      of the first n_tokens positions; the source keeps its full length.  Copies whole KV pages on `stream`. */
+int vlo_session_fork(vlo_session *src, int64_t n_tokens, vlo_session **out, void *stream);
+/* in-place variant: forget every position >= n_tokens and return the freed pages to the pool (device-synchronising). */
+int vlo_session_crop(vlo_session *s, int64_t n_tokens);
+
 /* ---- tensor parallelism (north_star; new capability — the reference has none) -------------------
  * Engines created with vlo_config.tp_size = T > 1 / tp_rank = r hold rank r's shard (load_weight still takes the FULL
  * tensors and slices them).  They are stepped through a group:

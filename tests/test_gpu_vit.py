@@ -113,3 +113,33 @@ def test_vision_tokens_match_reference_function_fixture(golden_dir):
     enc = eng.encode_video(frames.cuda(), batch_size=2).cpu().float()
     assert torch.equal(enc, tok)
     eng.close()
+
+
+def test_distributed_encode_writes_reference_layout(tmp_path):
+    """data/utils.py:86-104 mirror: two ranks split the directory, every video becomes a bf16 [T,10,Hv] .pt in the
+    reference's output directory, and the features equal a direct vision_tokens call."""
+    from videollm_online_amd import preprocess as P
+    spec, vspec = O.LLM_SPECS["toy128"], O.VIT_SPECS["toy"]
+    w, vw = O.init_llm_weights(spec, seed=3), O.init_vit_weights(vspec, seed=1)
+    eng = _engine(spec, vspec, w, vw)
+    src = tmp_path / "videos_2fps_384"
+    src.mkdir()
+    vids = {}
+    for i, T in enumerate((5, 1, 7)):
+        fr = O.synthetic_frames(T, vspec.image_size, seed=50 + i)
+        vids[f"clip{i}"] = fr
+        if i % 2:
+            np.save(src / f"clip{i}.npy", fr.numpy())
+        else:
+            torch.save(fr, src / f"clip{i}.pt")
+    written = []
+    for rank in range(2):
+        written += P.distributed_encode(eng, src_root=str(src), vision_pretrained="google/siglip-large-patch16-384",
+                                        embed_mark="2fps_384_1+3x3", batch_size=3, save_bf16=True, rank=rank, world_size=2)
+    dst = str(src) + "_1+3x3_google--siglip-large-patch16-384"
+    assert sorted(os.listdir(dst)) == ["clip0.pt", "clip1.pt", "clip2.pt"] and len(written) == 3
+    for name, fr in vids.items():
+        feats = torch.load(os.path.join(dst, name + ".pt"), weights_only=True)
+        assert feats.dtype == torch.bfloat16 and feats.shape == (fr.shape[0], vspec.frame_num_tokens, vspec.hidden_size)
+        assert torch.equal(feats, eng.vision_tokens(fr.cuda()).cpu())
+    eng.close()

@@ -36,6 +36,7 @@ EXPORTS = [
     "vlo_profile_enable", "vlo_profile_read", "vlo_bench_gemv", "vlo_debug_read", "vlo_profile_calibrate", "vlo_debug_gemv_plan",
     "vlo_tp_unique_id", "vlo_tp_group_create", "vlo_tp_group_destroy", "vlo_tp_session_create", "vlo_tp_session_reset",
     "vlo_tp_session_len", "vlo_tp_session_destroy", "vlo_tp_llm_step", "vlo_tp_stream_sample", "vlo_tp_greedy_generate",
+    "vlo_joint_embed", "vlo_logit_rows", "vlo_session_fork", "vlo_session_crop",
 ]
 
 
@@ -69,6 +70,10 @@ def lib():
     L.vlo_session_destroy.argtypes = [vp]
     L.vlo_session_destroy.restype = None
     L.vlo_visual_embed.argtypes = [vp, vp, i32, vp, vp]
+    L.vlo_joint_embed.argtypes = [vp, vp, i32, i64, vp, i32, vp, vp]
+    L.vlo_logit_rows.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.vlo_session_fork.argtypes = [vp, i64, C.POINTER(vp), vp]
+    L.vlo_session_crop.argtypes = [vp, i64]
     L.vlo_vision_tokens.argtypes = [vp, vp, i32, vp, vp]
     L.vlo_connector.argtypes = [vp, vp, i32, vp, vp]
     L.vlo_embed.argtypes = [vp, vp, i32, vp, vp]

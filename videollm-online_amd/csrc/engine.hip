@@ -750,6 +750,85 @@ int vlo_session_read_kv(vlo_session *s, int layer, int which, int kv_head, int64
     return VLO_OK;
 }
 
+// ---- teacher-forced evaluation surface (models/modeling_live.py:29-42, 44-168, 170-171) -------------------------------
+int vlo_joint_embed(vlo_engine *e, const int64_t *ids_dev, int k, int64_t v_placeholder_id, const void *frame_rows_dev,
+                    int n_frame_rows, void *out_dev, void *stream) {
+    if (!e || !ids_dev || !out_dev || k <= 0 || n_frame_rows < 0 || (n_frame_rows > 0 && !frame_rows_dev))
+        return fail(VLO_E_INVALID, "bad joint_embed arguments");
+    if (!e->finalized) return fail(VLO_E_STATE, "engine not finalized");
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)stream;
+    int *scratch = nullptr;
+    HIP_TRY(hipMalloc((void **)&scratch, ((size_t)k + 1) * sizeof(int)));
+    hipError_t he = joint_embed_launch((const unsigned short *)e->embed, ids_dev, k, v_placeholder_id, (const unsigned short *)frame_rows_dev,
+                                       n_frame_rows, e->cfg.hidden_size, e->cfg.vocab_size, scratch, scratch + k,
+                                       (unsigned short *)out_dev, st);
+    int count = -1;
+    if (he == hipSuccess) he = hipMemcpyAsync(&count, scratch + k, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    hipFree(scratch);
+    HIP_TRY(he);
+    // `inputs_embeds[v_mask] = self.visual_embed(frames)` raises on a shape mismatch (:41)
+    if (count != n_frame_rows)
+        return fail(VLO_E_INVALID, std::to_string(count) + " placeholder positions but " + std::to_string(n_frame_rows) +
+                                       " frame-token embeddings");
+    return VLO_OK;
+}
+
+int vlo_logit_rows(vlo_engine *e, const void *logits_dev, int n, const int64_t *labels_dev, int interval_id, float *lse_dev,
+                   int64_t *argmax_dev, float *label_logit_dev, float *p_interval_dev, int64_t *p_argmax_dev, void *stream) {
+    if (!e || !logits_dev || n <= 0 || !lse_dev || !argmax_dev || !label_logit_dev || !p_interval_dev || !p_argmax_dev)
+        return fail(VLO_E_INVALID, "bad logit_rows arguments");
+    HIP_TRY(hipSetDevice(e->device));
+    const int V = e->cfg.vocab_size;
+    HIP_TRY(logit_rows_launch((const unsigned short *)logits_dev, n, V, V, labels_dev, interval_id, lse_dev, argmax_dev, label_logit_dev,
+                              p_interval_dev, p_argmax_dev, (hipStream_t)stream));
+    return VLO_OK;
+}
+
+int vlo_session_fork(vlo_session *src, int64_t n_tokens, vlo_session **out, void *stream) {
+    if (!src || !out || n_tokens < 0 || n_tokens > src->len) return fail(VLO_E_INVALID, "bad session_fork arguments");
+    vlo_engine *e = src->e;
+    if (e->tp_size > 1) return fail(VLO_E_STATE, "tensor-parallel sessions cannot be forked");
+    hipStream_t st = (hipStream_t)stream;
+    vlo_session *d = nullptr;
+    int rc = vlo_session_create(e, n_tokens, &d);
+    if (rc) return rc;
+    if ((rc = ensure_pages(d, n_tokens, st))) {
+        vlo_session_destroy(d);
+        return rc;
+    }
+    const int pages = (int)((n_tokens + VLO_PAGE_TOKENS - 1) / VLO_PAGE_TOKENS);
+    hipError_t he = kv_copy_pages_launch(kv_geom(src), src->page_table, d->page_table, pages, e->cfg.num_layers, st);
+    if (he != hipSuccess) {
+        vlo_session_destroy(d);
+        HIP_TRY(he);
+    }
+    d->len = n_tokens;
+    *out = d;
+    return VLO_OK;
+}
+
+int vlo_session_crop(vlo_session *s, int64_t n_tokens) {
+    if (!s || n_tokens < 0 || n_tokens > s->len) return fail(VLO_E_INVALID, "bad session_crop arguments");
+    vlo_engine *e = s->e;
+    if (e->tp_size > 1) return fail(VLO_E_STATE, "tensor-parallel sessions cannot be cropped");
+    const size_t keep = (size_t)((n_tokens + VLO_PAGE_TOKENS - 1) / VLO_PAGE_TOKENS);
+    if (keep < s->pages.size()) {
+        // pages go back to the pool (and page-table slots will be rewritten): let queued kernels that still read them drain
+        HIP_TRY(hipSetDevice(e->device));
+        HIP_TRY(hipDeviceSynchronize());
+        std::lock_guard<std::mutex> g(e->pool_mu);
+        while (s->pages.size() > keep) {
+            e->free_pages.push_back(s->pages.back());
+            s->pages.pop_back();
+        }
+    }
+    s->len = n_tokens;
+    s->has_logits = false;
+    return VLO_OK;
+}
+
 int vlo_test_gemv(const void *x_dev, const void *W_dev, float *y_dev, int n, int N, int K, void *stream) {
     if (!x_dev || !W_dev || !y_dev || n <= 0 || n > 16 || N <= 0 || (N & 3)) return fail(VLO_E_INVALID, "bad test_gemv arguments");
     hipStream_t st = (hipStream_t)stream;

@@ -44,3 +44,15 @@ hipError_t stream_sample_launch(const unsigned short *logits, int V, float thres
 hipError_t copy_rows_launch(const unsigned short *src, unsigned short *dst, int rows, int H, hipStream_t st);
 hipError_t read_kv_launch(KvGeom kv, int layer, int which, int kv_head, int64_t t0, int64_t t1, unsigned short *dst,
                           hipStream_t st);
+
+// ---- teacher-forced evaluation helpers (models/modeling_live.py:29-42, 44-168, 170-171)
+// out[i] = ids[i] == v_id ? frame_rows[rank of i among placeholder positions] : table[clamp(ids[i])];
+// *count_out (device int) = number of placeholder positions; src_idx_scratch: k device ints
+hipError_t joint_embed_launch(const unsigned short *table, const int64_t *ids, int k, int64_t v_id, const unsigned short *frame_rows,
+                              int n_frame_rows, int H, int64_t vocab, int *src_idx_scratch, int *count_out, unsigned short *out,
+                              hipStream_t st);
+// copy `pages` whole KV pages (all layers, K and V^T) from the physical pages src_pt[i] to dst_pt[i] (device int arrays)
+hipError_t kv_copy_pages_launch(KvGeom kv, const int *src_pt, const int *dst_pt, int pages, int layers, hipStream_t st);
+// per-row logit statistics, see llm_ops.hip
+hipError_t logit_rows_launch(const unsigned short *logits, int n, int V, int64_t ld, const int64_t *labels, int interval_id, float *lse,
+                             int64_t *amax, float *label_logit, float *p_interval, int64_t *p_amax, hipStream_t st);

@@ -529,7 +529,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void stream_scan_kernel(const bf16_
     float S = 0.f;
     for (int k = 0; k < NB; ++k) S += scr[NB + k] * expf(scr[k] - M);
     const float p_int = rbf(expf(bf2f(logits[interval_id]) - M) / S);
-    const bool zero_int = p_int < threshold;
+    const bool zero_int = p_int < rbf(threshold);   // torch compares a bf16 tensor with a Python float in bf16
     const int per = (V + NB - 1) / NB, lo = blockIdx.x * per, hi = min(V, lo + per);
     ArgBest b = {-INFINITY, 0x7fffffff};
     for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
@@ -559,5 +559,133 @@ hipError_t stream_sample_launch(const unsigned short *logits, int V, float thres
     hipLaunchKernelGGL(sample_stats_kernel, dim3(SAMPLE_BLOCKS), dim3(SAMPLE_THREADS), 0, st, logits, V, scratch);
     hipLaunchKernelGGL(stream_scan_kernel, dim3(SAMPLE_BLOCKS), dim3(SAMPLE_THREADS), 0, st, logits, V, threshold, interval_id, scratch);
     hipLaunchKernelGGL(stream_final_kernel, dim3(1), dim3(64), 0, st, scratch, SAMPLE_BLOCKS, tok_out, p_interval_out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// Teacher-forced evaluation helpers (models/modeling_live.py:29-42, 44-168, 170-171)
+// ------------------------------------------------------------------------------------
+// joint_embed (:38-41): rank of every placeholder position among the placeholders (exclusive scan, one block).
+__global__ __launch_bounds__(1024) void placeholder_rank_kernel(const int64_t *__restrict__ ids, int k, int64_t v_id,
+                                                                int *__restrict__ src_idx, int *__restrict__ count_out) {
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < k; i0 += 1024) {
+        const int i = i0 + threadIdx.x;
+        const int f = (i < k && ids[i] == v_id) ? 1 : 0;
+        int inc = f;                                   // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += y;
+        }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        int before = base_s;
+        for (int j = 0; j < w; ++j) before += wsum[j];
+        if (i < k) src_idx[i] = f ? before + inc - 1 : -1;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int j = 0; j < 16; ++j) t += wsum[j];
+            base_s += t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count_out = base_s;
+}
+// rows with src_idx >= 0 take frame-token row src_idx, the others the (clamped) embedding-table row
+__global__ void joint_gather_kernel(const bf16_t *__restrict__ table, const int64_t *__restrict__ ids, const int *__restrict__ src_idx,
+                                    const bf16_t *__restrict__ frame_rows, int n_frame_rows, int H, int64_t vocab,
+                                    bf16_t *__restrict__ out) {
+    const int r = src_idx[blockIdx.x];
+    const uint4 *src;
+    if (r >= 0) {
+        if (r >= n_frame_rows) return;                 // count mismatch: the host reports the error
+        src = reinterpret_cast<const uint4 *>(frame_rows + (size_t)r * H);
+    } else {
+        int64_t id = ids[blockIdx.x];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        src = reinterpret_cast<const uint4 *>(table + (size_t)id * H);
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(out + (size_t)blockIdx.x * H);
+    for (int i = threadIdx.x; i < H / 8; i += blockDim.x) dst[i] = src[i];
+}
+hipError_t joint_embed_launch(const unsigned short *table, const int64_t *ids, int k, int64_t v_id, const unsigned short *frame_rows,
+                              int n_frame_rows, int H, int64_t vocab, int *src_idx_scratch, int *count_out, unsigned short *out,
+                              hipStream_t st) {
+    hipLaunchKernelGGL(placeholder_rank_kernel, dim3(1), dim3(1024), 0, st, ids, k, v_id, src_idx_scratch, count_out);
+    hipLaunchKernelGGL(joint_gather_kernel, dim3(k), dim3(256), 0, st, table, ids, src_idx_scratch, frame_rows, n_frame_rows, H, vocab,
+                       out);
+    return hipGetLastError();
+}
+
+// trim_past_key_values(past, 0, stop) as a fork: copy the pages holding positions [0, stop) of every layer into the
+// pages of another session.  grid = (pages, layers, 2 {K, V^T}).
+__global__ void kv_copy_pages_kernel(KvGeom kv, const int *__restrict__ src_pt, const int *__restrict__ dst_pt) {
+    unsigned short *pool = blockIdx.z == 0 ? kv.k_pool : kv.vt_pool;
+    const size_t lay = (size_t)blockIdx.y * kv.layer_stride;
+    const uint4 *src = reinterpret_cast<const uint4 *>(pool + lay + (size_t)src_pt[blockIdx.x] * kv.page_elems);
+    uint4 *dst = reinterpret_cast<uint4 *>(pool + lay + (size_t)dst_pt[blockIdx.x] * kv.page_elems);
+    const int n16 = (int)(kv.page_elems / 8);
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+}
+hipError_t kv_copy_pages_launch(KvGeom kv, const int *src_pt, const int *dst_pt, int pages, int layers, hipStream_t st) {
+    if (pages <= 0) return hipSuccess;
+    hipLaunchKernelGGL(kv_copy_pages_kernel, dim3(pages, layers, 2), dim3(256), 0, st, kv, src_pt, dst_pt);
+    return hipGetLastError();
+}
+
+// Per-row statistics of a bf16 logits matrix [n][ld] (one block per row): everything stream_evaluate reads from the
+// logits (models/modeling_live.py:95-97, 107-112, 140-144) without materialising softmax rows:
+//   lse[r]          log sum exp (fp32)                  -> cross entropy = lse - label_logit
+//   argmax[r]       first maximum of the logits         (:97)
+//   label_logit[r]  logits[r][labels[r]] (0 when the label is outside [0, V))
+//   p_interval[r]   softmax(logits)[interval] rounded to bf16 as the reference's bf16 softmax does (:107,:110)
+//   p_argmax[r]     first maximum of the bf16-rounded softmax row (:112; rounding can merge near-ties into exact ties,
+//                   which argmax then resolves to the lower index — not always the logits' argmax)
+__global__ __launch_bounds__(256) void logit_rows_kernel(const bf16_t *__restrict__ logits, int V, int64_t ld,
+                                                         const int64_t *__restrict__ labels, int interval_id, float *__restrict__ lse,
+                                                         int64_t *__restrict__ amax, float *__restrict__ label_logit,
+                                                         float *__restrict__ p_interval, int64_t *__restrict__ p_amax) {
+    __shared__ float sm[16];
+    __shared__ float smv[16];
+    __shared__ int smi[16];
+    const bf16_t *x = logits + (size_t)blockIdx.x * ld;
+    float mx = -INFINITY;
+    ArgBest b = {-INFINITY, 0x7fffffff};
+    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+        const float v = bf2f(x[i]);
+        mx = fmaxf(mx, v);
+        if (v > b.v) { b.v = v; b.i = i; }
+    }
+    const float M = block_max(mx, sm);
+    float s = 0.f;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) s += expf(bf2f(x[i]) - M);
+    const float S = block_sum(s, sm);
+    b = block_argbest(b, smv, smi);
+    ArgBest pb = {-INFINITY, 0x7fffffff};
+    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+        const float p = rbf(expf(bf2f(x[i]) - M) / S);
+        if (p > pb.v) { pb.v = p; pb.i = i; }
+    }
+    pb = block_argbest(pb, smv, smi);
+    if (threadIdx.x == 0) {
+        const int r = blockIdx.x;
+        lse[r] = M + logf(S);
+        amax[r] = b.i;
+        const int64_t lab = labels ? labels[r] : -1;
+        label_logit[r] = (lab >= 0 && lab < V) ? bf2f(x[lab]) : 0.f;
+        p_interval[r] = (interval_id >= 0 && interval_id < V) ? rbf(expf(bf2f(x[interval_id]) - M) / S) : 0.f;
+        p_amax[r] = pb.i;
+    }
+}
+hipError_t logit_rows_launch(const unsigned short *logits, int n, int V, int64_t ld, const int64_t *labels, int interval_id, float *lse,
+                             int64_t *amax, float *label_logit, float *p_interval, int64_t *p_amax, hipStream_t st) {
+    hipLaunchKernelGGL(logit_rows_kernel, dim3(n), dim3(256), 0, st, logits, V, ld, labels, interval_id, lse, amax, label_logit,
+                       p_interval, p_amax);
     return hipGetLastError();
 }

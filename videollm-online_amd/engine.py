@@ -93,6 +93,19 @@ class Session:
         except Exception:
             pass
 
+    def fork(self, n_tokens: int, stream=None) -> "Session":
+        """A new session holding a copy of the first ``n_tokens`` positions (trim_past_key_values(past, 0, n),
+        models/modeling_live.py:170-171); this session is left untouched."""
+        h = C.c_void_p()
+        _C.check(_C.lib().vlo_session_fork(self._h, n_tokens, C.byref(h), _stream_handle(stream)))
+        out = Session.__new__(Session)
+        out.engine, out._h = self.engine, h
+        return out
+
+    def crop(self, n_tokens: int):
+        """Forget every position >= n_tokens in place."""
+        _C.check(_C.lib().vlo_session_crop(self._h, n_tokens))
+
     def read_kv(self, layer, which, kv_head, t0, t1):
         out = torch.empty(t1 - t0, self.engine.head_dim, dtype=torch.bfloat16, device=self.engine.device)
         _C.check(_C.lib().vlo_session_read_kv(self._h, layer, which, kv_head, t0, t1, _ptr(out), _stream_handle()))
@@ -195,6 +208,36 @@ class Engine:
         ``batch_size`` frames, encode, concatenate, keep bf16 -> [T, frame_num_tokens, vision_hidden_size]."""
         outs = [self.vision_tokens(frames_u8[i:i + batch_size].to(self.device)) for i in range(0, frames_u8.shape[0], batch_size)]
         return torch.cat(outs)
+
+    def joint_embed(self, ids: torch.Tensor, frame_rows: torch.Tensor | None, v_placeholder_id: int, stream=None) -> torch.Tensor:
+        """models/modeling_live.py:29-42: token embeddings with the placeholder rows replaced, in order, by ``frame_rows``
+        (bf16 [num_frames * frame_num_tokens, H], from visual_embed / connector).  Raises on a count mismatch."""
+        ids = ids.to(device=self.device, dtype=torch.long).contiguous().view(-1)
+        n_rows = 0
+        if frame_rows is not None and frame_rows.numel():
+            frame_rows = frame_rows.to(device=self.device, dtype=torch.bfloat16).contiguous().view(-1, self.cfg.hidden_size)
+            n_rows = frame_rows.shape[0]
+        out = torch.empty(ids.numel(), self.cfg.hidden_size, dtype=torch.bfloat16, device=self.device)
+        _C.check(_C.lib().vlo_joint_embed(self._h, _ptr(ids), ids.numel(), v_placeholder_id, _ptr(frame_rows) if n_rows else None,
+                                          n_rows, _ptr(out), _stream_handle(stream)))
+        return out
+
+    def logit_rows(self, logits: torch.Tensor, labels: torch.Tensor | None = None, interval_id: int = -1, stream=None) -> dict:
+        """Per-row statistics of bf16 logits [n, V] (see include/vlo.h::vlo_logit_rows): lse, argmax, label_logit,
+        p_interval, p_argmax — device tensors of n elements."""
+        logits = logits.view(-1, self.cfg.vocab_size)
+        assert logits.dtype == torch.bfloat16 and logits.is_cuda and logits.is_contiguous()
+        n = logits.shape[0]
+        if labels is not None:
+            labels = labels.to(device=self.device, dtype=torch.long).contiguous().view(-1)
+            assert labels.numel() == n
+        f = lambda dt: torch.empty(n, dtype=dt, device=self.device)
+        out = dict(lse=f(torch.float32), argmax=f(torch.long), label_logit=f(torch.float32), p_interval=f(torch.float32),
+                   p_argmax=f(torch.long))
+        _C.check(_C.lib().vlo_logit_rows(self._h, _ptr(logits), n, _ptr(labels) if labels is not None else None, interval_id,
+                                         _ptr(out["lse"]), _ptr(out["argmax"]), _ptr(out["label_logit"]), _ptr(out["p_interval"]),
+                                         _ptr(out["p_argmax"]), _stream_handle(stream)))
+        return out
 
     def llm_step(self, session: Session, embeds: torch.Tensor, want_last=True, want_all=False, stream=None):
         """Returns (last_logits [V] bf16 | None, all_logits [n,V] bf16 | None)."""
