@@ -188,6 +188,9 @@ int vlo_session_crop(vlo_session *s, int64_t n_tokens);
 typedef struct vlo_tp_group vlo_tp_group;
 typedef struct vlo_tp_session vlo_tp_session;
 int  vlo_tp_unique_id(void *out128);
+/* one-rank RCCL round trip (communicator, fp32 all-reduce, byte all-gather) on `device`: checks the run-time binding of
+ * librccl that the one-process-per-GPU mode relies on, on a box with a single GPU */
+int  vlo_tp_selftest(int device);
 int  vlo_tp_group_create(vlo_engine **engines, int n_local, const void *rccl_unique_id, vlo_tp_group **out);
 void vlo_tp_group_destroy(vlo_tp_group *g);
 int  vlo_tp_session_create(vlo_tp_group *g, int64_t max_tokens_hint, vlo_tp_session **out);

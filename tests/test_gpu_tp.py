@@ -74,3 +74,10 @@ def test_tp_rejects_bad_partitions():
                        tp_rank=0, tp_size=4)
     with pytest.raises(RuntimeError, match="tp_size must divide"):
         Engine(cfg)
+
+
+def test_rccl_binding_one_rank_roundtrip():
+    """The RCCL entry points the one-process-per-GPU mode dlopens, driven with a 1-rank communicator on this GPU:
+    unique id -> ncclCommInitRank -> fp32 sum all-reduce -> byte all-gather, data checked in the library."""
+    from videollm_online_amd import _C
+    _C.check(_C.lib().vlo_tp_selftest(0))

@@ -101,6 +101,61 @@ int vlo_tp_unique_id(void *out128) {
     return VLO_OK;
 }
 
+// One-rank RCCL round trip on `device`: communicator from a fresh unique id, an fp32 sum all-reduce and a byte all-gather
+// (the two collectives tp_chunk issues), results checked on the host.  Exercises the dlopen'ed entry points, their
+// argument layout and the datatype / op enums on a box with a single GPU.
+int vlo_tp_selftest(int device) {
+    int rc = rccl_load();
+    if (rc) return rc;
+    TP_TRY(hipSetDevice(device));
+    NcclUid id;
+    if (g_rccl.GetUniqueId(&id) != 0) return vlo_fail(VLO_E_HIP, "ncclGetUniqueId failed");
+    void *comm = nullptr;
+    if (g_rccl.CommInitRank(&comm, 1, id, 0) != 0 || !comm) return vlo_fail(VLO_E_HIP, "ncclCommInitRank(nranks=1) failed");
+    const int N = 4096;
+    std::vector<float> h(N), back(N);
+    for (int i = 0; i < N; ++i) h[i] = 0.25f * (float)(i % 97) - 3.f;
+    float *d = nullptr;
+    unsigned char *gsrc = nullptr, *gdst = nullptr;
+    hipStream_t st = nullptr;
+    int out = VLO_OK;
+    auto cleanup = [&]() {
+        if (st) hipStreamDestroy(st);
+        if (d) hipFree(d);
+        if (gsrc) hipFree(gsrc);
+        if (gdst) hipFree(gdst);
+        g_rccl.CommDestroy(comm);
+    };
+#define ST_TRY(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            cleanup();                                                                            \
+            return vlo_fail(VLO_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));        \
+        }                                                                                         \
+    } while (0)
+    ST_TRY(hipStreamCreate(&st));
+    ST_TRY(hipMalloc((void **)&d, N * sizeof(float)));
+    ST_TRY(hipMalloc((void **)&gsrc, N));
+    ST_TRY(hipMalloc((void **)&gdst, N));
+    ST_TRY(hipMemcpyAsync(d, h.data(), N * sizeof(float), hipMemcpyHostToDevice, st));
+    ST_TRY(hipMemcpyAsync(gsrc, h.data(), N, hipMemcpyHostToDevice, st));
+    ST_TRY(hipMemsetAsync(gdst, 0, N, st));
+    if (g_rccl.AllReduce(d, d, N, kNcclFloat32, kNcclSum, comm, st) != 0) out = vlo_fail(VLO_E_HIP, "ncclAllReduce failed");
+    if (!out && g_rccl.AllGather(gsrc, gdst, N, kNcclInt8, comm, st) != 0) out = vlo_fail(VLO_E_HIP, "ncclAllGather failed");
+    if (!out) {
+        std::vector<unsigned char> gb(N);
+        ST_TRY(hipMemcpyAsync(back.data(), d, N * sizeof(float), hipMemcpyDeviceToHost, st));
+        ST_TRY(hipMemcpyAsync(gb.data(), gdst, N, hipMemcpyDeviceToHost, st));
+        ST_TRY(hipStreamSynchronize(st));
+        if (memcmp(back.data(), h.data(), N * sizeof(float)) != 0) out = vlo_fail(VLO_E_HIP, "one-rank all-reduce changed the data");
+        else if (memcmp(gb.data(), h.data(), N) != 0) out = vlo_fail(VLO_E_HIP, "one-rank all-gather did not copy the data");
+    }
+#undef ST_TRY
+    cleanup();
+    return out;
+}
+
 int vlo_tp_group_create(vlo_engine **engines, int n_local, const void *rccl_unique_id, vlo_tp_group **out) {
     if (!engines || n_local <= 0 || !out) return vlo_fail(VLO_E_INVALID, "bad tp_group_create arguments");
     const int T = engines[0]->tp_size;
