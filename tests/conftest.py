@@ -10,8 +10,23 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _usable_cores():
+    """min(affinity, cgroup quota): the GPU box shows 256 logical CPUs under a 16-CPU quota, and a torch thread pool
+    sized for 256 makes every CPU-oracle matmul crawl."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import torch
+    torch.set_num_threads(min(_usable_cores(), 32))
 
 
 @pytest.fixture(scope="session")
