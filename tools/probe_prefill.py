@@ -1,0 +1,47 @@
+"""Teacher-forced prefill timing on the true Llama-3-8B shape: N tokens through vlo_llm_step (64-token block path, or
+16-row chunks with VLO_BLOCK_PATH=0), with and without all-row logits + per-row statistics (the stream_evaluate pass)."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from videollm_online_amd.engine import Engine, EngineConfig
+from probe_llm import SHAPES, random_llm_weights_to_engine
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="llama-3-8b")
+    ap.add_argument("--tokens", type=int, default=2048)
+    args = ap.parse_args()
+    cfg = EngineConfig(**SHAPES[args.model], kv_pool_tokens=max(16384, 2 * args.tokens))
+    eng = Engine(cfg)
+    random_llm_weights_to_engine(eng, cfg)
+    eng.finalize()
+    H = cfg.hidden_size
+    x = (torch.randn(args.tokens, H, device="cuda") * 0.5).bfloat16()
+    labels = torch.randint(0, cfg.vocab_size, (args.tokens,), device="cuda")
+    mode = "16-row chunks" if os.environ.get("VLO_BLOCK_PATH") == "0" else "64-token blocks"
+    for want_all in (False, True):
+        sess = eng.new_session()
+        eng.llm_step(sess, x[:80], want_last=True, want_all=want_all)          # warm-up (allocates the block workspaces)
+        sess.reset()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        if want_all:
+            for a in range(0, args.tokens, 2048):
+                _, lg = eng.llm_step(sess, x[a:a + 2048], want_last=False, want_all=True)
+                eng.logit_rows(lg, labels[a:a + 2048], 11)
+        else:
+            eng.llm_step(sess, x)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        print(f"[{mode}] {args.tokens} tokens, all-row logits+stats={want_all}: {dt*1e3:.1f} ms = {args.tokens/dt:.0f} tok/s "
+              f"({dt*1e3/args.tokens*64:.2f} ms per 64 tokens)")
+        sess.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -10,6 +10,7 @@
 
 #include "../../include/vlo.h"
 #include "gemv.h"
+#include "prefill.h"
 
 struct RawTensor {
     void *ptr = nullptr;
@@ -21,6 +22,7 @@ struct PackedLinear {
     void *Wp = nullptr;
     int N = 0, K = 0, NT = 0;
     GemvPlan plan{};
+    Gemm64Plan plan64{};      // the 64-token block path over the same packed image (prefill.hip)
 };
 
 struct LayerWeights {
@@ -85,6 +87,8 @@ struct vlo_session {
     float *sample_scratch = nullptr;
     int64_t *host_tok = nullptr;
     int *page_table = nullptr, *host_pt = nullptr;
+    // workspaces of the 64-token block path (allocated on first use): residual stream, normed rows, q, attention out, MLP act
+    unsigned short *bh = nullptr, *bx = nullptr, *bq = nullptr, *battn = nullptr, *bact = nullptr;
 };
 
 int dev_alloc(void **p, size_t bytes);

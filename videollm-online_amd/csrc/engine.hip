@@ -192,6 +192,7 @@ static int make_linear(vlo_engine *e, PackedLinear *pl, int N, int K, bool allow
     pl->K = K;
     pl->NT = (N + 15) / 16;
     if (gemv_plan(K, allow_ksplit, &pl->plan)) return fail(VLO_E_UNSUPPORTED, "no GEMV plan for K=" + std::to_string(K));
+    if (gemm64_plan(K, &pl->plan64)) return fail(VLO_E_UNSUPPORTED, "no block-GEMM plan for K=" + std::to_string(K));
     const size_t bytes = (size_t)pl->NT * 16 * K * 2;
     int rc = dev_alloc(&pl->Wp, bytes);
     if (rc) return rc;
@@ -620,6 +621,84 @@ static int run_chunk(vlo_session *s, const unsigned short *src, int m, bool want
     return VLO_OK;
 }
 
+// ---- block path: up to 64 new tokens per weight pass (prefill.hip) ---------------------------------------------------
+static int ensure_block_ws(vlo_session *s) {
+    if (s->bh) return VLO_OK;
+    vlo_engine *e = s->e;
+    const size_t H = e->cfg.hidden_size, I = e->I_l, qd = (size_t)e->nh_l * e->head_dim, R = VLO_BLOCK_TOKENS;
+    struct { unsigned short **p; size_t elems; } want[] = {{&s->bh, R * H}, {&s->bx, R * H}, {&s->bq, R * qd}, {&s->battn, R * qd}, {&s->bact, R * I}};
+    HIP_TRY(hipSetDevice(e->device));
+    for (auto &w : want) {
+        void *p = nullptr;
+        int rc = dev_alloc(&p, w.elems * 2);
+        if (rc) return rc;
+        s->owned.push_back(p);
+        *w.p = (unsigned short *)p;
+    }
+    return VLO_OK;
+}
+
+// one block of 16 < m <= 64 new tokens.  Per decoder layer: RMSNorm rows -> qkv GEMM [RoPE + KV append] -> attention per
+// 16-query sub-chunk (+ combine) -> o GEMM [residual add] -> RMSNorm rows -> gate/up GEMM [SwiGLU] -> down GEMM [residual
+// add].  Same rounding points as run_chunk (projection outputs and residual sums are bf16, accumulation fp32); only the
+// fp32 summation order inside a dot product differs (K is split over the waves of a block differently).
+static int run_block(vlo_session *s, const unsigned short *src, int m, bool want_last, unsigned short *all_logits, hipStream_t st) {
+    vlo_engine *e = s->e;
+    const vlo_config &c = e->cfg;
+    const int H = c.hidden_size, I = c.intermediate_size, hd = e->head_dim, nh = c.num_heads, V = c.vocab_size;
+    int rc;
+    if ((rc = ensure_block_ws(s))) return rc;
+    if ((rc = ensure_pages(s, s->len + m, st))) return rc;
+    const KvGeom kv = kv_geom(s);
+    HIP_TRY(copy_rows_launch(src, s->bh, m, H, st));
+    for (int l = 0; l < c.num_layers; ++l) {
+        const LayerWeights &L = e->layers[l];
+        HIP_TRY(add_rmsnorm_launch(s->bh, nullptr, 0, H, (const unsigned short *)L.ln_in, s->bx, H, H, c.rms_eps, m, st));
+        {   // qkv
+            GemvArgs a = gemv_args(L.qkv, s->bx, H, m);
+            a.out_bf16 = s->bq; a.cos_tab = (const unsigned short *)e->cos_tab; a.sin_tab = (const unsigned short *)e->sin_tab;
+            a.kv = kv; a.layer = l; a.num_heads = nh; a.pos0 = s->len;
+            HIP_TRY(gemm64_launch(a, L.qkv.plan64, EPI_ROPE, st));
+        }
+        for (int r0 = 0; r0 < m; r0 += 16)      // the chunk kernel takes <= 16 queries; keys of the whole block are already appended
+            HIP_TRY(attention_launch(s->bq + (size_t)r0 * nh * hd, kv, l, nh, s->len + r0, std::min(16, m - r0), s->part_o, s->part_ml,
+                                     s->battn + (size_t)r0 * nh * hd, st));
+        {   // o_proj + residual
+            GemvArgs a = gemv_args(L.o, s->battn, nh * hd, m);
+            a.h = s->bh; a.ldo = H;
+            HIP_TRY(gemm64_launch(a, L.o.plan64, EPI_RESID, st));
+        }
+        HIP_TRY(add_rmsnorm_launch(s->bh, nullptr, 0, H, (const unsigned short *)L.ln_post, s->bx, H, H, c.rms_eps, m, st));
+        {   // gate/up + SwiGLU
+            GemvArgs a = gemv_args(L.gate_up, s->bx, H, m);
+            a.out_bf16 = s->bact; a.ldo = I;
+            HIP_TRY(gemm64_launch(a, L.gate_up.plan64, EPI_SWIGLU, st));
+        }
+        {   // down_proj + residual
+            GemvArgs a = gemv_args(L.down, s->bact, I, m);
+            a.h = s->bh; a.ldo = H;
+            HIP_TRY(gemm64_launch(a, L.down.plan64, EPI_RESID, st));
+        }
+    }
+    if (want_last || all_logits) {
+        HIP_TRY(add_rmsnorm_launch(s->bh, nullptr, 0, H, (const unsigned short *)e->norm_w, s->bx, H, H, c.rms_eps, m, st));
+        if (all_logits) {                       // every row, straight into the caller's matrix
+            GemvArgs a = gemv_args(e->lm_head, s->bx, H, m);
+            a.out_bf16 = all_logits; a.ldo = V;
+            HIP_TRY(gemm64_launch(a, e->lm_head.plan64, EPI_BF16, st));
+            HIP_TRY(hipMemcpyAsync(s->logits, all_logits + (size_t)(m - 1) * V, (size_t)V * 2, hipMemcpyDeviceToDevice, st));
+        } else {                                // only the row that is read
+            GemvArgs a = gemv_args(e->lm_head, s->bx + (size_t)(m - 1) * H, H, 1);
+            a.out_bf16 = s->logits; a.ldo = V;
+            HIP_TRY(gemv_launch(a, e->lm_head.plan, XSRC_PLAIN, EPI_BF16, st));
+        }
+        s->last_logits = s->logits;
+        s->has_logits = true;
+    }
+    s->len += m;
+    return VLO_OK;
+}
+
 int vlo_llm_step(vlo_session *s, const void *embeds_dev, int n, void *last_logits_dev, void *all_logits_dev, void *stream) {
     if (!s || !embeds_dev || n <= 0) return fail(VLO_E_INVALID, "bad llm_step arguments");
     vlo_engine *e = s->e;
@@ -628,13 +707,23 @@ int vlo_llm_step(vlo_session *s, const void *embeds_dev, int n, void *last_logit
     hipStream_t st = (hipStream_t)stream;
     const int H = e->cfg.hidden_size, V = e->cfg.vocab_size;
     int rc;
-    for (int c0 = 0; c0 < n; c0 += 16) {
-        const int m = std::min(16, n - c0);
-        const bool last = (c0 + m == n);
-        if ((rc = run_chunk(s, (const unsigned short *)embeds_dev + (size_t)c0 * H, m, last, all_logits_dev != nullptr, st))) return rc;
-        if (all_logits_dev)
-            HIP_TRY(hipMemcpyAsync((unsigned short *)all_logits_dev + (size_t)c0 * V, s->logits, (size_t)m * V * 2,
-                                   hipMemcpyDeviceToDevice, st));
+    // inputs longer than one 16-row chunk go through the 64-token block path (one weight pass per 64 tokens); the live
+    // frame / decode steps (n <= 16) keep the fused 16-row pipeline.  VLO_BLOCK_PATH=0 forces 16-row chunks everywhere.
+    static const bool block_path = getenv("VLO_BLOCK_PATH") ? atoi(getenv("VLO_BLOCK_PATH")) != 0 : true;
+    for (int c0 = 0; c0 < n;) {
+        const int left = n - c0;
+        const unsigned short *src = (const unsigned short *)embeds_dev + (size_t)c0 * H;
+        unsigned short *all = all_logits_dev ? (unsigned short *)all_logits_dev + (size_t)c0 * V : nullptr;
+        if (block_path && left > 16) {
+            const int m = std::min(VLO_BLOCK_TOKENS, left);
+            if ((rc = run_block(s, src, m, c0 + m == n, all, st))) return rc;
+            c0 += m;
+            continue;
+        }
+        const int m = std::min(16, left);
+        if ((rc = run_chunk(s, src, m, c0 + m == n, all != nullptr, st))) return rc;
+        if (all) HIP_TRY(hipMemcpyAsync(all, s->logits, (size_t)m * V * 2, hipMemcpyDeviceToDevice, st));
+        c0 += m;
     }
     if (last_logits_dev) HIP_TRY(hipMemcpyAsync(last_logits_dev, s->last_logits, (size_t)V * 2, hipMemcpyDeviceToDevice, st));
     return VLO_OK;

@@ -1,0 +1,250 @@
+// prefill.hip — the Llama projections for a BLOCK of up to 64 new tokens per weight pass.
+//
+// The streaming step (gemv.hip) moves every weight byte once per <= 16 tokens, which is the right shape for the live
+// path (n = 11 frame steps, n = 1 decode) but makes a long teacher-forced input — stream_evaluate's whole-dialogue
+// forward, models/modeling_live.py:67, ~13 k tokens on the reference's data — pay one 15 GB weight pass per 16 tokens.
+// This kernel streams the SAME packed weight image (A-operand fragments, gemv.hip) once per 64 tokens: each weight
+// fragment feeds four MFMAs (one per 16-token tile) instead of one, so the pass stays HBM-bound (64 FLOP per weight
+// byte vs the ~310 ridge) while the tokens per byte quadruple.
+//
+//   D[ncol][token] = sum_k Wfrag[ncol][k] * xfrag[k][token]      (W as A, x as B, v_mfma_f32_16x16x32_bf16)
+//
+// Work split = gemv16_kernel's: persistent blocks stride over groups of two column tiles (rotary pairs for q/k/v,
+// 8 gate + 8 up rows per tile for SwiGLU), the block's waves split K, a wave walks its K range in chunks of KF
+// fragments, partial tiles meet in LDS and the epilogue runs on the reduced sums.  Differences: 4 token tiles per
+// weight fragment; the activation fragments of a chunk (4 x KF) are re-read from L2 per chunk (x is <= 1.8 MB and
+// shared by every block); no norm-on-load / split-K partial variants (the block path runs the row-parallel
+// add_rmsnorm kernel instead, its cost is amortised over 64 tokens).
+#include <stdlib.h>
+
+#include "common.cuh"
+#include "prefill.h"
+
+VLO_DEV float silu_bf16_p(float g) { return rbf(g / (1.0f + __expf(-g))); }     // F.silu on a bf16 tensor
+VLO_DEV float4 f4add_p(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+template <int KF, int EPI>
+__global__ __launch_bounds__(512) void gemm64_kernel(GemvArgs a) {
+    constexpr int MT = VLO_BLOCK_TOKENS / 16, CTG = 2;
+    extern __shared__ __attribute__((aligned(16))) float4 red[];          // [NW][CTG][MT][64] float4
+    const int NW = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int m16 = lane & 15, qd = lane >> 4;
+    const int KFtot = a.K >> 5;
+    const int kfw0 = w * a.KC * KF;                                        // first fragment of this wave's K range
+    const int mt_live = (a.n_rows + 15) >> 4;                              // token tiles that hold real rows
+
+    const int hd = a.kv.head_dim;
+    const int tph = (EPI == EPI_ROPE) ? hd / 16 : 2;
+    const int hp = tph / 2;
+    const bool single = (EPI != EPI_ROPE && a.CT == 1);
+    const int ngroups = (EPI == EPI_ROPE) ? a.NT / 2 : (single ? a.NT : (a.NT + 1) / 2);
+    auto tile_a = [&](int g) { return (EPI == EPI_ROPE) ? (g / hp) * tph + (g % hp) : (single ? g : 2 * g); };
+    auto tile_b = [&](int g) { return (EPI == EPI_ROPE) ? (g / hp) * tph + (g % hp) + hp : (single ? a.NT : 2 * g + 1); };
+
+    const frag_ab *wbase = reinterpret_cast<const frag_ab *>(a.Wp) + (size_t)kfw0 * 64 + lane;
+    const size_t tile_stride = (size_t)KFtot * 64;
+    auto item_ptr = [&](int tile, int c) { return wbase + (size_t)tile * tile_stride + (size_t)c * KF * 64; };
+
+    frag_ab wr[KF];
+    int g = blockIdx.x;
+    if (g < ngroups) {
+        const frag_ab *wp = item_ptr(tile_a(g), 0);
+#pragma unroll
+        for (int kf = 0; kf < KF; ++kf) wr[kf] = __builtin_nontemporal_load(wp + kf * 64);
+    }
+
+    for (; g < ngroups; g += gridDim.x) {
+        const int tA = tile_a(g), tB = tile_b(g);
+        const bool hasB = tB < a.NT;
+        const int gn = g + gridDim.x;
+        f32x4 acc[CTG][MT];
+#pragma unroll
+        for (int t = 0; t < CTG; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < a.KC; ++c) {
+            // activation fragments of this K chunk: x[mt*16 + (lane&15)][k .. k+8]
+            frag_ab xf[MT][KF];
+            const size_t k0 = (size_t)(kfw0 + c * KF) * 32 + qd * 8;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int row = mt * 16 + m16;
+                const bf16_t *xr = a.x + (size_t)row * a.ldx + k0;
+#pragma unroll
+                for (int kf = 0; kf < KF; ++kf) {
+                    frag_ab z = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (row < a.n_rows) z = *reinterpret_cast<const frag_ab *>(xr + kf * 32);
+                    xf[mt][kf] = z;
+                }
+            }
+            {   // tile A; the fragment register is refilled for the next item right after its MFMAs
+                const frag_ab *np = hasB ? item_ptr(tB, c)
+                                         : (c + 1 < a.KC ? item_ptr(tA, c + 1) : (gn < ngroups ? item_ptr(tile_a(gn), 0) : nullptr));
+#pragma unroll
+                for (int kf = 0; kf < KF; ++kf) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        if (mt < mt_live) acc[0][mt] = mfma_bf16(wr[kf], xf[mt][kf], acc[0][mt]);
+                    if (np) wr[kf] = __builtin_nontemporal_load(np + kf * 64);
+                }
+            }
+            if (hasB) {
+                const frag_ab *np = c + 1 < a.KC ? item_ptr(tA, c + 1) : (gn < ngroups ? item_ptr(tile_a(gn), 0) : nullptr);
+#pragma unroll
+                for (int kf = 0; kf < KF; ++kf) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        if (mt < mt_live) acc[1][mt] = mfma_bf16(wr[kf], xf[mt][kf], acc[1][mt]);
+                    if (np) wr[kf] = __builtin_nontemporal_load(np + kf * 64);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < CTG; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                red[((size_t)(w * CTG + t) * MT + mt) * 64 + lane] = make_float4(acc[t][mt][0], acc[t][mt][1], acc[t][mt][2], acc[t][mt][3]);
+        __syncthreads();
+
+        auto reduced = [&](int ct, int mt, int l) {
+            float4 s = make_float4(0, 0, 0, 0);
+            for (int ww = 0; ww < NW; ++ww) s = f4add_p(s, red[((size_t)(ww * CTG + ct) * MT + mt) * 64 + l]);
+            return s;
+        };
+        if (EPI == EPI_ROPE) {
+            // a lane needs both tiles of the rotary pair: items = (token tile, lane)
+            for (int t = threadIdx.x; t < MT * 64; t += blockDim.x) {
+                const int mt = t >> 6, l = t & 63;
+                const int m = mt * 16 + (l & 15);
+                if (m >= a.n_rows) continue;
+                const float4 sA = reduced(0, mt, l), sB = reduced(1, mt, l);
+                const float va[4] = {sA.x, sA.y, sA.z, sA.w}, vb[4] = {sB.x, sB.y, sB.z, sB.w};
+                const int half = hd >> 1, nh = a.num_heads, nkv = a.kv.num_kv_heads;
+                const int head = g / hp, i = (g % hp) * 16 + (l >> 4) * 4;           // column inside the head, < half
+                const long long pos = a.pos0 + m;
+                const int page = a.kv.page_table[pos / VLO_PAGE_TOKENS];
+                const int tok = (int)(pos % VLO_PAGE_TOKENS);
+                if (head < nh + nkv) {
+                    bf16_t *dst = (head < nh)
+                        ? a.out_bf16 + (size_t)m * nh * hd + (size_t)head * hd
+                        : a.kv.k_pool + (size_t)a.layer * a.kv.layer_stride + (size_t)page * a.kv.page_elems +
+                              ((size_t)(head - nh) * VLO_PAGE_TOKENS + tok) * hd;
+                    const ushort4 c4 = *reinterpret_cast<const ushort4 *>(a.cos_tab + pos * half + i);
+                    const ushort4 s4 = *reinterpret_cast<const ushort4 *>(a.sin_tab + pos * half + i);
+                    const bf16_t cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+                    bf16_t lo[4], hi[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x1 = rbf(va[r]), x2 = rbf(vb[r]);              // projection output is bf16
+                        const float cs = bf2f(cc[r]), sn = bf2f(ss[r]);
+                        lo[r] = f2bf(rbf(x1 * cs) + rbf(-x2 * sn));                // q*cos + rotate_half(q)*sin, bf16 at every op
+                        hi[r] = f2bf(rbf(x2 * cs) + rbf(x1 * sn));
+                    }
+                    *reinterpret_cast<ushort4 *>(dst + i) = *reinterpret_cast<const ushort4 *>(lo);
+                    *reinterpret_cast<ushort4 *>(dst + half + i) = *reinterpret_cast<const ushort4 *>(hi);
+                } else {
+                    bf16_t *dst = a.kv.vt_pool + (size_t)a.layer * a.kv.layer_stride + (size_t)page * a.kv.page_elems +
+                                  ((size_t)(head - nh - nkv) * hd) * VLO_PAGE_TOKENS + tok;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dst[(size_t)(i + r) * VLO_PAGE_TOKENS] = f2bf(va[r]);
+                        dst[(size_t)(half + i + r) * VLO_PAGE_TOKENS] = f2bf(vb[r]);
+                    }
+                }
+            }
+        } else {
+            for (int t = threadIdx.x; t < CTG * MT * 64; t += blockDim.x) {
+                const int ct = t / (MT * 64), mt = (t >> 6) % MT, l = t & 63;
+                const int tile = ct ? tB : tA;
+                const int m = mt * 16 + (l & 15);
+                if (tile >= a.NT || m >= a.n_rows) continue;
+                const int col = tile * 16 + (l >> 4) * 4;
+                if (EPI == EPI_SWIGLU) {
+                    // tile = 8 gate rows (lanes 0..31) + the 8 up rows of the same columns (lanes 32..63)
+                    if (l >= 32) continue;
+                    const float4 gsum = reduced(ct, mt, l), usum = reduced(ct, mt, l + 32);
+                    const float gv[4] = {gsum.x, gsum.y, gsum.z, gsum.w}, uv[4] = {usum.x, usum.y, usum.z, usum.w};
+                    bf16_t o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = f2bf(silu_bf16_p(rbf(gv[r])) * rbf(uv[r]));
+                    *reinterpret_cast<ushort4 *>(a.out_bf16 + (size_t)m * a.ldo + tile * 8 + (l >> 4) * 4) = *reinterpret_cast<const ushort4 *>(o);
+                } else if (EPI == EPI_RESID) {
+                    const float4 s = reduced(ct, mt, l);
+                    bf16_t *hp4 = a.h + (size_t)m * a.ldo + col;
+                    const ushort4 hv = *reinterpret_cast<const ushort4 *>(hp4);
+                    const bf16_t hh[4] = {hv.x, hv.y, hv.z, hv.w};
+                    const float sv[4] = {s.x, s.y, s.z, s.w};
+                    bf16_t o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(bf2f(hh[r]) + rbf(sv[r])));   // Linear output -> bf16, then the bf16 residual add
+                    *reinterpret_cast<ushort4 *>(hp4) = *reinterpret_cast<const ushort4 *>(o);
+                } else {                                                   // EPI_BF16
+                    if (col >= a.N_valid) continue;                        // N padded to 16 at pack time; N_valid % 4 == 0
+                    const float4 s = reduced(ct, mt, l);
+                    ushort4 o;
+                    o.x = f2bf(s.x); o.y = f2bf(s.y); o.z = f2bf(s.z); o.w = f2bf(s.w);
+                    *reinterpret_cast<ushort4 *>(a.out_bf16 + (size_t)m * a.ldo + col) = o;
+                }
+            }
+        }
+        __syncthreads();                                                   // `red` is rewritten by the next group
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------
+int gemm64_plan(int K, Gemm64Plan *p) {
+    if (K <= 0 || (K & 31)) return -1;
+    const int KFtot = K >> 5;
+    // 4-wave blocks first: at ~144 VGPRs (KF = 4) three of them fit a CU = 12 waves x 4 KB of weight loads in flight
+    static const int nws[] = {4, 8, 2, 1}, kfs[] = {4, 2, 1};
+    for (int nw : nws)
+        for (int kf : kfs)
+            if (KFtot % (nw * kf) == 0) {
+                p->NW = nw; p->KF = kf; p->KC = KFtot / (nw * kf);
+                return 0;
+            }
+    return -1;
+}
+
+template <int KF>
+static hipError_t launch64(const GemvArgs &a, int epi, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+#define VLO_GO64(EP)                                                                      \
+    do {                                                                                  \
+        static bool attr = false;                                                         \
+        if (!attr) {                                                                      \
+            hipFuncSetAttribute((const void *)gemm64_kernel<KF, EP>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+            attr = true;                                                                  \
+        }                                                                                 \
+        hipLaunchKernelGGL((gemm64_kernel<KF, EP>), grid, block, lds, st, a);             \
+        return hipGetLastError();                                                         \
+    } while (0)
+    if (epi == EPI_ROPE) VLO_GO64(EPI_ROPE);
+    if (epi == EPI_SWIGLU) VLO_GO64(EPI_SWIGLU);
+    if (epi == EPI_RESID) VLO_GO64(EPI_RESID);
+    if (epi == EPI_BF16) VLO_GO64(EPI_BF16);
+#undef VLO_GO64
+    return hipErrorInvalidValue;
+}
+
+hipError_t gemm64_launch(GemvArgs a, const Gemm64Plan &p, int epi, hipStream_t st) {
+    if (a.n_rows <= 0 || a.n_rows > VLO_BLOCK_TOKENS) return hipErrorInvalidValue;
+    if (epi == EPI_ROPE && ((a.NT & 1) || (a.kv.head_dim != 64 && a.kv.head_dim != 128))) return hipErrorInvalidValue;
+    a.KC = p.KC;
+    // single column tiles when pairs would leave most CUs without work (o_proj / down_proj: 256 tiles)
+    a.CT = (epi != EPI_ROPE && (a.NT + 1) / 2 < 256) ? 1 : 2;
+    const int ngroups = (epi == EPI_ROPE) ? a.NT / 2 : (a.CT == 1 ? a.NT : (a.NT + 1) / 2);
+    int gx = ngroups < 768 ? ngroups : 768;                                // three resident 4-wave blocks per CU
+    const int per = (ngroups + gx - 1) / gx;
+    gx = (ngroups + per - 1) / per;
+    const size_t lds = (size_t)p.NW * 2 * (VLO_BLOCK_TOKENS / 16) * 64 * sizeof(float4);
+    dim3 grid(gx), block(p.NW * 64);
+    switch (p.KF) {
+        case 4: return launch64<4>(a, epi, grid, block, lds, st);
+        case 2: return launch64<2>(a, epi, grid, block, lds, st);
+        case 1: return launch64<1>(a, epi, grid, block, lds, st);
+    }
+    return hipErrorInvalidValue;
+}
