@@ -653,7 +653,7 @@ static int run_block(vlo_session *s, const unsigned short *src, int m, bool want
     HIP_TRY(copy_rows_launch(src, s->bh, m, H, st));
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerWeights &L = e->layers[l];
-        HIP_TRY(add_rmsnorm_launch(s->bh, nullptr, 0, H, (const unsigned short *)L.ln_in, s->bx, H, H, c.rms_eps, m, st));
+        HIP_TRY(add_rmsnorm_launch(s->bh, nullptr, 0, H, (const unsigned short *)L.ln_in, s->bx, H, 0, c.rms_eps, m, st));   // packed-64
         {   // qkv
             GemvArgs a = gemv_args(L.qkv, s->bx, H, m);
             a.out_bf16 = s->bq; a.cos_tab = (const unsigned short *)e->cos_tab; a.sin_tab = (const unsigned short *)e->sin_tab;
@@ -662,13 +662,13 @@ static int run_block(vlo_session *s, const unsigned short *src, int m, bool want
         }
         for (int r0 = 0; r0 < m; r0 += 16)      // the chunk kernel takes <= 16 queries; keys of the whole block are already appended
             HIP_TRY(attention_launch(s->bq + (size_t)r0 * nh * hd, kv, l, nh, s->len + r0, std::min(16, m - r0), s->part_o, s->part_ml,
-                                     s->battn + (size_t)r0 * nh * hd, st));
+                                     s->battn, st, r0));
         {   // o_proj + residual
             GemvArgs a = gemv_args(L.o, s->battn, nh * hd, m);
             a.h = s->bh; a.ldo = H;
             HIP_TRY(gemm64_launch(a, L.o.plan64, EPI_RESID, st));
         }
-        HIP_TRY(add_rmsnorm_launch(s->bh, nullptr, 0, H, (const unsigned short *)L.ln_post, s->bx, H, H, c.rms_eps, m, st));
+        HIP_TRY(add_rmsnorm_launch(s->bh, nullptr, 0, H, (const unsigned short *)L.ln_post, s->bx, H, 0, c.rms_eps, m, st));
         {   // gate/up + SwiGLU
             GemvArgs a = gemv_args(L.gate_up, s->bx, H, m);
             a.out_bf16 = s->bact; a.ldo = I;
@@ -681,7 +681,7 @@ static int run_block(vlo_session *s, const unsigned short *src, int m, bool want
         }
     }
     if (want_last || all_logits) {
-        HIP_TRY(add_rmsnorm_launch(s->bh, nullptr, 0, H, (const unsigned short *)e->norm_w, s->bx, H, H, c.rms_eps, m, st));
+        HIP_TRY(add_rmsnorm_launch(s->bh, nullptr, 0, H, (const unsigned short *)e->norm_w, s->bx, H, all_logits ? 0 : H, c.rms_eps, m, st));
         if (all_logits) {                       // every row, straight into the caller's matrix
             GemvArgs a = gemv_args(e->lm_head, s->bx, H, m);
             a.out_bf16 = all_logits; a.ldo = V;

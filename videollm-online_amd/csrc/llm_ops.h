@@ -18,7 +18,15 @@ struct KvGeom {
     int num_kv_heads, head_dim;
 };
 
-// h[m] (+)= bf16(sum_s partial[s][m]) ; x[m] = RMSNorm(h[m]) * w     (rows m < n)
+// "packed-64" activation layout of the 64-token block path (prefill.hip): the B-operand fragments of
+// v_mfma_f32_16x16x32_bf16 stored contiguously, so one fragment load is one coalesced 1 KiB read instead of 16 half-used
+// cache lines of a row-major matrix.  Element (row < 64, k) lives at
+//   ((k / 32 * 4 + row / 16) * 64 + (k % 32 / 8) * 16 + row % 16) * 8 + k % 8
+__host__ __device__ inline size_t vlo_pack64_elem(int row, int k) {
+    return ((size_t)((k >> 5) * 4 + (row >> 4)) * 64 + (size_t)(((k & 31) >> 3) * 16 + (row & 15))) * 8 + (k & 7);
+}
+
+// h[m] (+)= bf16(sum_s partial[s][m]) ; x[m] = RMSNorm(h[m]) * w     (rows m < n).  ldx == 0: x is written packed-64.
 hipError_t add_rmsnorm_launch(unsigned short *h, const float *partial, int ksplit, int partial_ld,
                               const unsigned short *w, unsigned short *x, int H, int ldx, float eps, int n,
                               hipStream_t st);
@@ -27,8 +35,9 @@ hipError_t add_rmsnorm_launch(unsigned short *h, const float *partial, int kspli
 hipError_t prep_rows_launch(const unsigned short *src, unsigned short *h, float *sq_out, int rows, int H, hipStream_t st);
 
 // chunk attention (n <= 16 queries at positions pos0..pos0+n-1 against keys [0, pos0+n))
+// pack_row0 >= 0: `out` is a packed-64 matrix and query i goes to row pack_row0 + i (block path); -1: row-major [n][nh*hd]
 hipError_t attention_launch(const unsigned short *q, KvGeom kv, int layer, int num_heads, int64_t pos0, int n,
-                            float *part_o, float *part_ml, unsigned short *out, hipStream_t st);
+                            float *part_o, float *part_ml, unsigned short *out, hipStream_t st, int pack_row0 = -1);
 
 hipError_t embed_gather_launch(const unsigned short *table, const int64_t *ids, int k, int H, int64_t vocab,
                                unsigned short *out, hipStream_t st);

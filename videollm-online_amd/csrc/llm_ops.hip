@@ -79,7 +79,8 @@ __global__ __launch_bounds__(RMS_THREADS) void add_rmsnorm_kernel(bf16_t *__rest
             bf16_t *oe = reinterpret_cast<bf16_t *>(&o);
 #pragma unroll
             for (int j = 0; j < 8; ++j) oe[j] = f2bf(bf2f(we[j]) * rbf(v[c][j] * rs));   // weight * x.to(bf16)
-            *reinterpret_cast<uint4 *>(xr + ch * 8) = o;
+            bf16_t *dst = ldx ? xr + ch * 8 : x + vlo_pack64_elem(m, ch * 8);            // ldx == 0: packed-64 (block path)
+            *reinterpret_cast<uint4 *>(dst) = o;
         }
     }
 }
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(512) void attn_chunk_kernel(const bf16_t *__restric
 
 // grid = (nh, n); block = 256 threads = (256 / HD) split-lanes x HD columns
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restrict__ part_o, const float *__restrict__ part_ml,
-                                                           int nsplit, int nh, int HD, bf16_t *__restrict__ out) {
+                                                           int nsplit, int nh, int HD, bf16_t *__restrict__ out, int pack_row0) {
     __shared__ float wgt[VLO_MAX_SPLITS];
     __shared__ float red[256];
     __shared__ float Ltot;
@@ -334,12 +335,13 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restri
     __syncthreads();
     if (ql == 0) {
         for (int k2 = 1; k2 < nql; ++k2) acc += red[k2 * HD + d];
-        out[(size_t)qrow * nh * HD + (size_t)head * HD + d] = f2bf(acc / Ltot);
+        const size_t at = pack_row0 < 0 ? (size_t)qrow * nh * HD + (size_t)head * HD + d : vlo_pack64_elem(pack_row0 + qrow, head * HD + d);
+        out[at] = f2bf(acc / Ltot);
     }
 }
 
 hipError_t attention_launch(const unsigned short *q, KvGeom kv, int layer, int num_heads, int64_t pos0, int n,
-                            float *part_o, float *part_ml, unsigned short *out, hipStream_t st) {
+                            float *part_o, float *part_ml, unsigned short *out, hipStream_t st, int pack_row0) {
     const int nkv = kv.num_kv_heads, hd = kv.head_dim, G = num_heads / nkv;
     const int L = (int)(pos0 + n);
     const int hpw = (G % 2 == 0) ? 2 : 1;
@@ -382,7 +384,7 @@ hipError_t attention_launch(const unsigned short *q, KvGeom kv, int layer, int n
 #undef VLO_ATTN
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(attn_combine_kernel, dim3(num_heads, n), dim3(256), 0, st, part_o, part_ml, nsplit, num_heads, hd, out);
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(num_heads, n), dim3(256), 0, st, part_o, part_ml, nsplit, num_heads, hd, out, pack_row0);
     return hipGetLastError();
 }
 

@@ -13,7 +13,8 @@
 // 8 gate + 8 up rows per tile for SwiGLU), the block's waves split K, a wave walks its K range in chunks of KF
 // fragments, partial tiles meet in LDS and the epilogue runs on the reduced sums.  Differences: 4 token tiles per
 // weight fragment; the activation fragments of a chunk (4 x KF) are re-read from L2 per chunk (x is <= 1.8 MB and
-// shared by every block); no norm-on-load / split-K partial variants (the block path runs the row-parallel
+// shared by every block) and therefore live in a fragment-packed layout ("packed-64", llm_ops.h) written by their
+// producers — row-major rows cost 16 half-used cache lines per fragment and made the kernel L2-line-bound; no norm-on-load / split-K partial variants (the block path runs the row-parallel
 // add_rmsnorm kernel instead, its cost is amortised over 64 tokens).
 #include <stdlib.h>
 
@@ -29,7 +30,6 @@ __global__ __launch_bounds__(512) void gemm64_kernel(GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 red[];          // [NW][CTG][MT][64] float4
     const int NW = blockDim.x >> 6;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int m16 = lane & 15, qd = lane >> 4;
     const int KFtot = a.K >> 5;
     const int kfw0 = w * a.KC * KF;                                        // first fragment of this wave's K range
     const int mt_live = (a.n_rows + 15) >> 4;                              // token tiles that hold real rows
@@ -46,12 +46,29 @@ __global__ __launch_bounds__(512) void gemm64_kernel(GemvArgs a) {
     const size_t tile_stride = (size_t)KFtot * 64;
     auto item_ptr = [&](int tile, int c) { return wbase + (size_t)tile * tile_stride + (size_t)c * KF * 64; };
 
-    frag_ab wr[KF];
+    // Weight fragments of BOTH tiles of the current K chunk sit in registers (2 x KF KiB per wave in flight) and each is
+    // refilled for the next chunk right after the MFMAs that consumed it; the four activation fragments of step kf+1
+    // are fetched (L2) while step kf computes.
+    frag_ab wrA[KF], wrB[KF];
+    frag_ab xc[MT], xn[MT];
+    const frag_ab *xbase = reinterpret_cast<const frag_ab *>(a.x) + (size_t)kfw0 * MT * 64 + lane;   // packed-64 (llm_ops.h)
+    auto load_x = [&](int step, frag_ab (&dst)[MT]) {                      // step = c * KF + kf inside this wave's K range
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            if (mt < mt_live) dst[mt] = xbase[((size_t)step * MT + mt) * 64];
+    };
     int g = blockIdx.x;
     if (g < ngroups) {
-        const frag_ab *wp = item_ptr(tile_a(g), 0);
+        const frag_ab *pa = item_ptr(tile_a(g), 0);
+        const int tb = tile_b(g);
 #pragma unroll
-        for (int kf = 0; kf < KF; ++kf) wr[kf] = __builtin_nontemporal_load(wp + kf * 64);
+        for (int kf = 0; kf < KF; ++kf) wrA[kf] = __builtin_nontemporal_load(pa + kf * 64);
+        if (tb < a.NT) {
+            const frag_ab *pb = item_ptr(tb, 0);
+#pragma unroll
+            for (int kf = 0; kf < KF; ++kf) wrB[kf] = __builtin_nontemporal_load(pb + kf * 64);
+        }
+        load_x(0, xc);
     }
 
     for (; g < ngroups; g += gridDim.x) {
@@ -64,40 +81,28 @@ __global__ __launch_bounds__(512) void gemm64_kernel(GemvArgs a) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int c = 0; c < a.KC; ++c) {
-            // activation fragments of this K chunk: x[mt*16 + (lane&15)][k .. k+8]
-            frag_ab xf[MT][KF];
-            const size_t k0 = (size_t)(kfw0 + c * KF) * 32 + qd * 8;
+            const bool last_c = c + 1 == a.KC;
+            // where this chunk's registers are refilled from: the next chunk of this group, or chunk 0 of the next group
+            const frag_ab *na = !last_c ? item_ptr(tA, c + 1) : (gn < ngroups ? item_ptr(tile_a(gn), 0) : nullptr);
+            const int tBn = !last_c ? tB : (gn < ngroups ? tile_b(gn) : a.NT);
+            const frag_ab *nb = tBn < a.NT ? item_ptr(tBn, last_c ? 0 : c + 1) : nullptr;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int row = mt * 16 + m16;
-                const bf16_t *xr = a.x + (size_t)row * a.ldx + k0;
+            for (int kf = 0; kf < KF; ++kf) {
+                // x of the next step (wraps to step 0 — same K range — when the next group starts)
+                const int nstep = (last_c && kf == KF - 1) ? 0 : c * KF + kf + 1;
+                load_x(nstep, xn);
 #pragma unroll
-                for (int kf = 0; kf < KF; ++kf) {
-                    frag_ab z = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (row < a.n_rows) z = *reinterpret_cast<const frag_ab *>(xr + kf * 32);
-                    xf[mt][kf] = z;
-                }
-            }
-            {   // tile A; the fragment register is refilled for the next item right after its MFMAs
-                const frag_ab *np = hasB ? item_ptr(tB, c)
-                                         : (c + 1 < a.KC ? item_ptr(tA, c + 1) : (gn < ngroups ? item_ptr(tile_a(gn), 0) : nullptr));
-#pragma unroll
-                for (int kf = 0; kf < KF; ++kf) {
+                for (int mt = 0; mt < MT; ++mt)
+                    if (mt < mt_live) acc[0][mt] = mfma_bf16(wrA[kf], xc[mt], acc[0][mt]);
+                if (na) wrA[kf] = __builtin_nontemporal_load(na + kf * 64);
+                if (hasB) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        if (mt < mt_live) acc[0][mt] = mfma_bf16(wr[kf], xf[mt][kf], acc[0][mt]);
-                    if (np) wr[kf] = __builtin_nontemporal_load(np + kf * 64);
+                        if (mt < mt_live) acc[1][mt] = mfma_bf16(wrB[kf], xc[mt], acc[1][mt]);
                 }
-            }
-            if (hasB) {
-                const frag_ab *np = c + 1 < a.KC ? item_ptr(tA, c + 1) : (gn < ngroups ? item_ptr(tile_a(gn), 0) : nullptr);
+                if (nb) wrB[kf] = __builtin_nontemporal_load(nb + kf * 64);
 #pragma unroll
-                for (int kf = 0; kf < KF; ++kf) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        if (mt < mt_live) acc[1][mt] = mfma_bf16(wr[kf], xf[mt][kf], acc[1][mt]);
-                    if (np) wr[kf] = __builtin_nontemporal_load(np + kf * 64);
-                }
+                for (int mt = 0; mt < MT; ++mt) xc[mt] = xn[mt];
             }
         }
 #pragma unroll
@@ -168,7 +173,8 @@ __global__ __launch_bounds__(512) void gemm64_kernel(GemvArgs a) {
                     bf16_t o[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = f2bf(silu_bf16_p(rbf(gv[r])) * rbf(uv[r]));
-                    *reinterpret_cast<ushort4 *>(a.out_bf16 + (size_t)m * a.ldo + tile * 8 + (l >> 4) * 4) = *reinterpret_cast<const ushort4 *>(o);
+                    // act feeds the down projection of the block path: packed-64 (4 consecutive k = half a 16-byte unit)
+                    *reinterpret_cast<ushort4 *>(a.out_bf16 + vlo_pack64_elem(m, tile * 8 + (l >> 4) * 4)) = *reinterpret_cast<const ushort4 *>(o);
                 } else if (EPI == EPI_RESID) {
                     const float4 s = reduced(ct, mt, l);
                     bf16_t *hp4 = a.h + (size_t)m * a.ldo + col;
@@ -198,8 +204,9 @@ __global__ __launch_bounds__(512) void gemm64_kernel(GemvArgs a) {
 int gemm64_plan(int K, Gemm64Plan *p) {
     if (K <= 0 || (K & 31)) return -1;
     const int KFtot = K >> 5;
-    // 4-wave blocks first: at ~144 VGPRs (KF = 4) three of them fit a CU = 12 waves x 4 KB of weight loads in flight
-    static const int nws[] = {4, 8, 2, 1}, kfs[] = {4, 2, 1};
+    // 8-wave blocks, one per CU, each wave keeping 2 x KF KiB of weight loads in flight (KF = 8: 128 KiB per CU, what the
+    // 16-row GEMV keeps); the first try (4 KiB per wave, <= 12 waves per CU) was latency-bound at ~2 TB/s
+    static const int nws[] = {8, 4, 2, 1}, kfs[] = {8, 4, 2, 1};
     for (int nw : nws)
         for (int kf : kfs)
             if (KFtot % (nw * kf) == 0) {
@@ -236,12 +243,13 @@ hipError_t gemm64_launch(GemvArgs a, const Gemm64Plan &p, int epi, hipStream_t s
     // single column tiles when pairs would leave most CUs without work (o_proj / down_proj: 256 tiles)
     a.CT = (epi != EPI_ROPE && (a.NT + 1) / 2 < 256) ? 1 : 2;
     const int ngroups = (epi == EPI_ROPE) ? a.NT / 2 : (a.CT == 1 ? a.NT : (a.NT + 1) / 2);
-    int gx = ngroups < 768 ? ngroups : 768;                                // three resident 4-wave blocks per CU
+    int gx = ngroups < 256 ? ngroups : 256;                                // one resident 8-wave block per CU
     const int per = (ngroups + gx - 1) / gx;
     gx = (ngroups + per - 1) / per;
     const size_t lds = (size_t)p.NW * 2 * (VLO_BLOCK_TOKENS / 16) * 64 * sizeof(float4);
     dim3 grid(gx), block(p.NW * 64);
     switch (p.KF) {
+        case 8: return launch64<8>(a, epi, grid, block, lds, st);
         case 4: return launch64<4>(a, epi, grid, block, lds, st);
         case 2: return launch64<2>(a, epi, grid, block, lds, st);
         case 1: return launch64<1>(a, epi, grid, block, lds, st);
