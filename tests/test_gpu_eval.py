@@ -143,7 +143,7 @@ def test_stream_evaluate_matches_reference_fixture(golden_dir):
 
 
 def test_stream_evaluate_slabs_and_long_dialogue():
-    """A dialogue longer than one slab and than two KV pages: slab size must not change the result."""
+    """A dialogue longer than one slab and than two KV pages: slab size must not change the metrics."""
     from videollm_online_amd.modeling_live import LiveModel
     spec = O.LLM_SPECS["toy128"]
     w = O.init_llm_weights(spec, seed=3)
@@ -158,7 +158,10 @@ def test_stream_evaluate_slabs_and_long_dialogue():
     orig = model._row_stats
     model._row_stats = lambda *args, **kw: orig(*args, slab=100, **{k: v for k, v in kw.items() if k != "slab"})
     b = model.stream_evaluate(ids[None].cuda(), labels[None].cuda(), feats.cuda())
-    assert torch.equal(a, b)
+    # slab boundaries move the 64-token block / 16-query sub-chunk boundaries, i.e. fp32 summation orders: the discrete
+    # metrics must not move, the perplexity only by bf16 noise
+    assert torch.equal(a[1:], b[1:]), (a, b)
+    assert abs(float(a[0]) - float(b[0])) <= 0.02 * float(a[0]), (a, b)
     ref = O.LlamaOracle(spec, w, torch.bfloat16)
     fe = O.connector(ref.W, feats.bfloat16()).view(-1, spec.hidden_size)
     d = {}

@@ -660,9 +660,8 @@ static int run_block(vlo_session *s, const unsigned short *src, int m, bool want
             a.kv = kv; a.layer = l; a.num_heads = nh; a.pos0 = s->len;
             HIP_TRY(gemm64_launch(a, L.qkv.plan64, EPI_ROPE, st));
         }
-        for (int r0 = 0; r0 < m; r0 += 16)      // the chunk kernel takes <= 16 queries; keys of the whole block are already appended
-            HIP_TRY(attention_launch(s->bq + (size_t)r0 * nh * hd, kv, l, nh, s->len + r0, std::min(16, m - r0), s->part_o, s->part_ml,
-                                     s->battn, st, r0));
+        // one launch for the (up to four) 16-query sub-chunks; the keys of the whole block are already appended
+        HIP_TRY(attention_launch(s->bq, kv, l, nh, s->len, m, s->part_o, s->part_ml, s->battn, st, 0));
         {   // o_proj + residual
             GemvArgs a = gemv_args(L.o, s->battn, nh * hd, m);
             a.h = s->bh; a.ldo = H;

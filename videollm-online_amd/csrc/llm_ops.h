@@ -34,7 +34,8 @@ hipError_t add_rmsnorm_launch(unsigned short *h, const float *partial, int kspli
 // copy `rows` embedding rows into the residual stream h and write their sums of squares to sq_out[0..rows)
 hipError_t prep_rows_launch(const unsigned short *src, unsigned short *h, float *sq_out, int rows, int H, hipStream_t st);
 
-// chunk attention (n <= 16 queries at positions pos0..pos0+n-1 against keys [0, pos0+n))
+// chunk attention (n <= 16 queries at positions pos0..pos0+n-1 against keys [0, pos0+n); the block path passes n <= 64
+// = up to four 16-query sub-chunks in one launch)
 // pack_row0 >= 0: `out` is a packed-64 matrix and query i goes to row pack_row0 + i (block path); -1: row-major [n][nh*hd]
 hipError_t attention_launch(const unsigned short *q, KvGeom kv, int layer, int num_heads, int64_t pos0, int n,
                             float *part_o, float *part_ml, unsigned short *out, hipStream_t st, int pack_row0 = -1);

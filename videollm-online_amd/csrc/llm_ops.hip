@@ -140,6 +140,15 @@ __global__ __launch_bounds__(512) void attn_chunk_kernel(const bf16_t *__restric
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int hg = w % NHG, ks = w / NHG;
     const int split = blockIdx.x, kvh = blockIdx.y;
+    // blockIdx.z = 16-query sub-chunk of a longer block of new tokens (block path): queries z*16 .. z*16+n-1
+    {
+        const int z = blockIdx.z;
+        q += (size_t)z * 16 * nh * HD;
+        pos0 += 16 * z;
+        n = min(16, n - 16 * z);
+        part_o += (size_t)z * gridDim.x * nh * 16 * HD;
+        part_ml += (size_t)z * gridDim.x * nh * 16 * 2;
+    }
     const int L = (int)(pos0 + n);
     const int c0 = split * chunk, c1 = min(L, c0 + chunk);
     const int head0 = kvh * G + hg * HPW;
@@ -313,7 +322,16 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restri
     __shared__ float wgt[VLO_MAX_SPLITS];
     __shared__ float red[256];
     __shared__ float Ltot;
-    const int head = blockIdx.x, qrow = blockIdx.y, t = threadIdx.x;
+    const int head = blockIdx.x, t = threadIdx.x;
+    int qrow = blockIdx.y;
+    {                                              // blockIdx.y walks all query rows, 16 per sub-chunk (z = 0 on the live path)
+        const int z = qrow >> 4;
+        part_o += (size_t)z * nsplit * nh * 16 * HD;
+        part_ml += (size_t)z * nsplit * nh * 16 * 2;
+        if (pack_row0 >= 0) pack_row0 += z * 16;
+        else out += (size_t)z * 16 * nh * HD;
+        qrow &= 15;
+    }
     if (t < 64) {                                  // one wave: softmax weights of the splits
         float ms = -INFINITY, ls = 0.f;
         if (t < nsplit) {
@@ -353,18 +371,22 @@ hipError_t attention_launch(const unsigned short *q, KvGeom kv, int layer, int n
         static const int force = getenv("VLO_ATTN_KS") ? atoi(getenv("VLO_ATTN_KS")) : 0;
         if (force > 0) KS = force;
     }
+    // n > 16 (block path): grid.z sub-chunks of 16 queries share one launch and one split geometry; sub-chunk z sees the
+    // keys [0, pos0 + 16 z + n_z), splits beyond that write empty partials
+    const int nz = (n + 15) / 16;
+    if (nz > 4) return hipErrorInvalidValue;
     // splits: ~one block per CU at long context; every wave should see at least one 32-key block
     int target = (L + KS * 32 - 1) / (KS * 32);
     static const int want_blocks = getenv("VLO_ATTN_BLOCKS") ? atoi(getenv("VLO_ATTN_BLOCKS")) : 256;
-    const int want = (want_blocks + nkv - 1) / nkv;
+    const int want = (want_blocks + nkv * nz - 1) / (nkv * nz);
     if (target > want) target = want;
-    if (target > VLO_MAX_SPLITS) target = VLO_MAX_SPLITS;
+    if (target > VLO_MAX_SPLITS / nz) target = VLO_MAX_SPLITS / nz;
     if (target < 1) target = 1;
     int chunk = (L + target - 1) / target;
     chunk = (chunk + 31) & ~31;
     const int nsplit = (L + chunk - 1) / chunk;
     const float scale = 1.0f / sqrtf((float)hd);
-    dim3 grid(nsplit, nkv), block(nhg * KS * 64);
+    dim3 grid(nsplit, nkv, nz), block(nhg * KS * 64);
     const size_t lds = (size_t)(KS - 1) * nhg * hpw * ((size_t)(hd / 16) * 64 * 16 + 16 * 2 * 4);
     static bool attr_done = false;
     if (!attr_done) {
