@@ -11,8 +11,11 @@ triggered).  Weights are seeded random-init at the true shapes and frames are sy
 Random weights make the speak/silent decision arbitrary, so the speech schedule is fixed
 ("scheduled" mode): the sampler still runs every frame, a 16-token response is
 generated every 10th frame plus one for the t=0 user query; ``--mode silent`` and ``--mode free``
-are available.  N > 1 runs one independent stream per GPU (replicas, weak scaling — the path does
-not shard across streams; TP is a later round) under torchrun, barrier + max-over-ranks timing.
+are available.  N > 1 runs one independent stream per GPU (replicas, weak scaling: streams are
+independent, there is no exchange step) under torchrun, barrier + max-over-ranks timing — that is
+``value``.  The same invocation then measures ONE stream with the Llama tensor-parallel over the N
+GPUs (``--tp``, RCCL all-reduce x2 per layer) in child processes and reports it under ``"tp"``; a
+failure there is recorded, never fatal.
 
 Prints ONE JSON line (rank 0) with the driver's contract keys plus ``roofline`` (dominant kernel =
 the gate/up weight-streaming GEMV, timed live with HIP events on its own stream) and
@@ -234,6 +237,47 @@ def cpu_baseline(model_name, frames_u8_cpu, toks, mode, sample_frames, budget_s=
                       f"one random layer's weights aliased across layers (timing-equivalent)"}
 
 
+def run_tp_leg(args, rank, world, local):
+    """Spawn `bench.py --tp` as a child of every rank (same RANK / LOCAL_RANK / WORLD_SIZE, rendezvous on MASTER_PORT + 17),
+    wait with a deadline, kill the child's process group on timeout.  Rank 0 returns the child's headline numbers."""
+    import signal
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC") and k not in ("GROUP_RANK", "ROLE_RANK")}
+    env.update(RANK=str(rank), LOCAL_RANK=str(local), WORLD_SIZE=str(world), MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
+               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 17), VLO_BENCH_TP_LEG="0")
+    steps = max(20, min(args.steps, args.tp_leg_steps))
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(steps), "--warmup", "10", "--tp",
+           "--no-cpu-baseline", "--model", args.model, "--mode", args.mode, "--fps", str(args.fps),
+           "--prefetch-frames", str(args.prefetch_frames)]
+    log(f"tp leg: {' '.join(cmd[1:])}")
+    t0 = time.time()
+    try:
+        child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    except Exception as ex:
+        return {"error": f"spawn failed: {ex!r}"}
+    try:
+        so, se = child.communicate(timeout=args.tp_leg_timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(child.pid, signal.SIGKILL)          # the session we started, nothing else
+        except Exception:
+            pass
+        so, se = child.communicate()
+        return {"error": f"timeout after {args.tp_leg_timeout:.0f}s", "stderr_tail": (se or "")[-400:]}
+    if rank != 0:
+        return None
+    line = next((l for l in reversed((so or "").splitlines()) if l.startswith("{")), None)
+    if child.returncode != 0 or line is None:
+        return {"error": f"child exit code {child.returncode}", "stderr_tail": (se or "")[-400:]}
+    d = json.loads(line)
+    keep = ("value", "unit", "ms_per_step", "p50_frame_latency_ms", "p95_frame_latency_ms", "steps", "scaling")
+    r = {k: d.get(k) for k in keep}
+    r.update(parallelism=d["config"]["parallelism"], stream_hbm_roofline=d.get("stream_hbm_roofline"), wall_s=round(time.time() - t0, 1),
+             note="ONE stream, Llama tensor-parallel over the same GPUs (RCCL all-reduce x2 per layer + logits all-gather), "
+                  "ViT replicated; measured by `bench.py --tp` in child processes")
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -250,6 +294,10 @@ def main():
     ap.add_argument("--tp", action="store_true",
                     help="N > 1: ONE stream, Llama tensor-parallel over the N GPUs (RCCL all-reduce), strong scaling; "
                          "default is one independent stream per GPU (replicas, weak scaling)")
+    ap.add_argument("--no-tp-leg", action="store_true",
+                    help="N > 1: skip the extra tensor-parallel measurement (run in child processes after the replica run)")
+    ap.add_argument("--tp-leg-steps", type=int, default=300)
+    ap.add_argument("--tp-leg-timeout", type=float, default=420.0)
     args = ap.parse_args()
 
     import torch
@@ -393,6 +441,15 @@ def main():
                          "launches_timed": n_launch, "avg_launch_us": round(net_ms * 1e3, 2), "avg_bracket_us_raw": round(avg_ms * 1e3, 2),
                          "empty_bracket_us": round(empty_us, 2), "bytes_per_launch": bytes_per_launch},
         }
+    # N > 1, replica mode: also measure ONE stream tensor-parallel over the same N GPUs (BASELINE.json north_star).  It
+    # runs in child processes (one per rank, own rendezvous port) so that a failure or hang of the RCCL leg — which no
+    # single-GPU box can exercise beforehand — can never cost the replica line above.
+    tp_leg = None
+    if world > 1 and not tp and not args.no_tp_leg and os.environ.get("VLO_BENCH_TP_LEG", "1") != "0":
+        tp_leg = run_tp_leg(args, rank, world, local)
+    if rank == 0:
+        if tp_leg is not None:
+            out["tp"] = tp_leg
         if world == 1 and not args.no_cpu_baseline:
             log("cpu_baseline: building CPU oracle")
             try:

@@ -76,3 +76,23 @@ def test_tp_unique_id_broadcast_gloo():
     [p.join(60) for p in ps]
     assert all(p.exitcode == 0 for p in ps)
     assert len(res[0]) == 128 and res[0] == res[1] and any(res[0])
+
+
+def test_bench_tp_leg_child_failure_is_recorded_not_fatal():
+    """bench.py measures the tensor-parallel variant in child processes; on a box where the child cannot run (here: no
+    GPU at all) the parent must get an error record back instead of dying or hanging."""
+    import argparse
+    import bench
+    args = argparse.Namespace(steps=40, tp_leg_steps=30, tp_leg_timeout=120.0, model="tinyllama-1.1b", mode="scheduled", fps=2.0,
+                              prefetch_frames=4)
+    old = {k: os.environ.get(k) for k in ("MASTER_PORT", "MASTER_ADDR")}
+    os.environ["MASTER_PORT"], os.environ["MASTER_ADDR"] = "29871", "127.0.0.1"
+    try:
+        r = bench.run_tp_leg(args, rank=0, world=2, local=0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert isinstance(r, dict) and "error" in r and "value" not in r
