@@ -40,6 +40,7 @@ typedef int (*fn_ncclCommInitRank)(void **, int, NcclUid, int);
 typedef int (*fn_ncclAllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
 typedef int (*fn_ncclAllGather)(const void *, void *, size_t, int, void *, hipStream_t);
 typedef int (*fn_ncclCommDestroy)(void *);
+typedef const char *(*fn_ncclGetErrorString)(int);
 enum { kNcclInt8 = 0, kNcclFloat32 = 7, kNcclSum = 0 };
 
 struct Rccl {
@@ -49,8 +50,15 @@ struct Rccl {
     fn_ncclAllReduce AllReduce = nullptr;
     fn_ncclAllGather AllGather = nullptr;
     fn_ncclCommDestroy CommDestroy = nullptr;
+    fn_ncclGetErrorString GetErrorString = nullptr;
 };
 static Rccl g_rccl;
+
+static std::string rccl_err(const char *what, int code) {
+    std::string m = std::string(what) + " failed (rccl code " + std::to_string(code) + ")";
+    if (g_rccl.GetErrorString) m += std::string(": ") + g_rccl.GetErrorString(code);
+    return m;
+}
 
 static int rccl_load() {
     if (g_rccl.dl) return VLO_OK;
@@ -64,6 +72,7 @@ static int rccl_load() {
     g_rccl.AllReduce = (fn_ncclAllReduce)dlsym(dl, "ncclAllReduce");
     g_rccl.AllGather = (fn_ncclAllGather)dlsym(dl, "ncclAllGather");
     g_rccl.CommDestroy = (fn_ncclCommDestroy)dlsym(dl, "ncclCommDestroy");
+    g_rccl.GetErrorString = (fn_ncclGetErrorString)dlsym(dl, "ncclGetErrorString");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather || !g_rccl.CommDestroy)
         return vlo_fail(VLO_E_UNSUPPORTED, "librccl lacks an expected symbol");
     g_rccl.dl = dl;
@@ -179,9 +188,10 @@ int vlo_tp_group_create(vlo_engine **engines, int n_local, const void *rccl_uniq
         if (rc) { delete g; return rc; }
         NcclUid id;
         memcpy(&id, rccl_unique_id, sizeof(id));
-        if (hipSetDevice(engines[0]->device) != hipSuccess || g_rccl.CommInitRank(&g->comm, T, id, engines[0]->tp_rank) != 0) {
+        int nrc = -1;
+        if (hipSetDevice(engines[0]->device) != hipSuccess || (nrc = g_rccl.CommInitRank(&g->comm, T, id, engines[0]->tp_rank)) != 0) {
             delete g;
-            return vlo_fail(VLO_E_HIP, "ncclCommInitRank failed");
+            return vlo_fail(VLO_E_HIP, rccl_err("ncclCommInitRank", nrc));
         }
     }
     *out = g;
@@ -228,7 +238,8 @@ static int tp_allreduce(vlo_tp_session *t, float *(vlo_session::*buf), size_t co
     if (g->tp_size == 1) return VLO_OK;
     if (g->comm) {
         float *b = t->ss[0]->*buf;
-        if (g_rccl.AllReduce(b, b, count, kNcclFloat32, kNcclSum, g->comm, st) != 0) return vlo_fail(VLO_E_HIP, "ncclAllReduce failed");
+        const int nrc = g_rccl.AllReduce(b, b, count, kNcclFloat32, kNcclSum, g->comm, st);
+        if (nrc != 0) return vlo_fail(VLO_E_HIP, rccl_err("ncclAllReduce", nrc));
         return VLO_OK;
     }
     PtrList L;
