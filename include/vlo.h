@@ -92,7 +92,7 @@ int  vlo_engine_create(const vlo_config *cfg, int device, vlo_engine **out);
 int  vlo_engine_load_weight(vlo_engine *e, const char *name, const void *data, int dtype,
                             const int64_t *shape, int ndim);
 int  vlo_engine_finalize(vlo_engine *e);              /* verifies completeness, builds tables */
-void vlo_engine_destroy(vlo_engine *e);
+void vlo_engine_destroy(vlo_engine *e);               /* destroy the engine's sessions FIRST: they borrow its KV pool */
 int64_t vlo_engine_weight_bytes(const vlo_engine *e); /* packed bytes resident in HBM */
 
 /* ---- session = the KV handle (`past_key_values`, HF:cache_utils.py DynamicCache;

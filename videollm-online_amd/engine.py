@@ -2,6 +2,7 @@
 the caller-side device buffers and the HIP streams whose handles are passed down; every
 computation happens in libvlo.so's HIP kernels."""
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 
 import torch
@@ -70,6 +71,7 @@ class Session:
         h = C.c_void_p()
         _C.check(_C.lib().vlo_session_create(engine._h, max_tokens_hint, C.byref(h)))
         self._h = h
+        engine._sessions.add(self)
 
     def __bool__(self):
         return True
@@ -100,6 +102,7 @@ class Session:
         _C.check(_C.lib().vlo_session_fork(self._h, n_tokens, C.byref(h), _stream_handle(stream)))
         out = Session.__new__(Session)
         out.engine, out._h = self.engine, h
+        self.engine._sessions.add(out)
         return out
 
     def crop(self, n_tokens: int):
@@ -124,6 +127,7 @@ class Engine:
         _C.check(_C.lib().vlo_engine_create(C.byref(cc), self.device.index, C.byref(h)))
         self._h = h
         self._finalized = False
+        self._sessions = weakref.WeakSet()      # sessions borrow the engine's KV pool: closed before the engine is
 
     # ---- weights -------------------------------------------------------------------------
     def load_weight(self, name: str, t: torch.Tensor):
@@ -169,6 +173,8 @@ class Engine:
 
     def close(self):
         if self._h:
+            for sess in list(self._sessions):   # a session handle must not outlive its engine (include/vlo.h)
+                sess.close()
             _C.lib().vlo_engine_destroy(self._h)
             self._h = None
 
