@@ -215,6 +215,9 @@ int vlo_profile_calibrate(vlo_engine *e, void *stream, double *empty_bracket_us)
 /* host-side planner of the weight-streaming GEMV (no GPU needed): for a reduction length K returns
  * out4 = {waves per block, fragments per wave per chunk, K chunks per wave, K slices across blocks}; < 0 if K is not covered */
 int vlo_debug_gemv_plan(int K, int allow_ksplit, int *out4);
+/* block path (csrc/prefill.hip): (NW, KF, KC) chosen for a K; element offset of (row < 64, k) in the packed-64 layout */
+int vlo_debug_gemm64_plan(int K, int *out3);
+int64_t vlo_debug_pack64_elem(int row, int k);
 
 /* micro-benchmark of the weight-streaming GEMV on synthetic data (tools/bench_gemv.py): `nbuf` distinct
  * packed weight images are cycled so the 256 MiB Infinity Cache cannot serve re-reads. */

@@ -77,3 +77,33 @@ def test_gemv_planner_covers_every_model_shape():
             if not allow:
                 assert ks == 1
     assert L.vlo_debug_gemv_plan(100, 0, out) < 0 and b"no GEMV plan" in L.vlo_last_error()    # K % 32 != 0
+
+
+def test_block_path_geometry():
+    """Host-side geometry of the 64-token block path (csrc/prefill.hip), no GPU: the K split of every model shape, and
+    the packed-64 activation layout — a bijection onto [0, 64 K) in which the 8 consecutive k of one (row, k/8) stay a
+    contiguous 16-byte unit and the 64 units of one MFMA B fragment (16 rows x 4 k-groups) are contiguous."""
+    import ctypes as C
+    import numpy as np
+    from videollm_online_amd import _C
+    L = _C.lib()
+    out = (C.c_int * 3)()
+    for K in (4096, 14336, 2048, 5632, 8192, 28672, 1024, 7168, 3584, 1792, 512, 1408, 256, 704, 128):
+        assert L.vlo_debug_gemm64_plan(K, out) == 0, K
+        nw, kf, kc = list(out)
+        assert nw * kf * kc * 32 == K and nw in (1, 2, 4, 8) and kf in (1, 2, 4, 8), (K, list(out))
+    assert L.vlo_debug_gemm64_plan(100, out) < 0
+    K = 256
+    idx = np.array([[L.vlo_debug_pack64_elem(r, k) for k in range(K)] for r in range(64)])
+    assert sorted(idx.ravel().tolist()) == list(range(64 * K))
+    assert (idx[:, 1:][:, np.arange(K - 1) % 8 != 7] - idx[:, :-1][:, np.arange(K - 1) % 8 != 7] == 1).all()
+    for kf in range(K // 32):
+        for mt in range(4):
+            frag = idx[mt * 16:(mt + 1) * 16, kf * 32:(kf + 1) * 32]
+            lo = (kf * 4 + mt) * 64 * 8
+            assert frag.min() == lo and frag.max() == lo + 64 * 8 - 1
+            # lane = (k % 32 / 8) * 16 + row % 16 owns unit `lane` of the fragment
+            for r in (0, 5, 15):
+                for q in range(4):
+                    assert idx[mt * 16 + r, kf * 32 + q * 8] == lo + (q * 16 + r) * 8
+    assert L.vlo_debug_pack64_elem(64, 0) == -1 and L.vlo_debug_pack64_elem(0, -1) == -1

@@ -36,7 +36,7 @@ EXPORTS = [
     "vlo_profile_enable", "vlo_profile_read", "vlo_bench_gemv", "vlo_debug_read", "vlo_profile_calibrate", "vlo_debug_gemv_plan",
     "vlo_tp_unique_id", "vlo_tp_group_create", "vlo_tp_group_destroy", "vlo_tp_session_create", "vlo_tp_session_reset",
     "vlo_tp_session_len", "vlo_tp_session_destroy", "vlo_tp_llm_step", "vlo_tp_stream_sample", "vlo_tp_greedy_generate",
-    "vlo_joint_embed", "vlo_logit_rows", "vlo_session_fork", "vlo_session_crop", "vlo_tp_selftest",
+    "vlo_joint_embed", "vlo_logit_rows", "vlo_session_fork", "vlo_session_crop", "vlo_tp_selftest", "vlo_debug_gemm64_plan", "vlo_debug_pack64_elem",
 ]
 
 
@@ -90,6 +90,9 @@ def lib():
     L.vlo_profile_calibrate.argtypes = [vp, vp, C.POINTER(C.c_double)]
     L.vlo_tp_unique_id.argtypes = [vp]
     L.vlo_tp_selftest.argtypes = [i32]
+    L.vlo_debug_gemm64_plan.argtypes = [i32, C.POINTER(i32)]
+    L.vlo_debug_pack64_elem.argtypes = [i32, i32]
+    L.vlo_debug_pack64_elem.restype = i64
     L.vlo_tp_group_create.argtypes = [C.POINTER(vp), i32, vp, C.POINTER(vp)]
     L.vlo_tp_group_destroy.argtypes = [vp]
     L.vlo_tp_group_destroy.restype = None

@@ -623,12 +623,13 @@ static int run_chunk(vlo_session *s, const unsigned short *src, int m, bool want
 
 // ---- block path: up to 64 new tokens per weight pass (prefill.hip) ---------------------------------------------------
 static int ensure_block_ws(vlo_session *s) {
-    if (s->bh) return VLO_OK;
+    if (s->bact) return VLO_OK;                 // the LAST buffer allocated below: set only when all of them exist
     vlo_engine *e = s->e;
     const size_t H = e->cfg.hidden_size, I = e->I_l, qd = (size_t)e->nh_l * e->head_dim, R = VLO_BLOCK_TOKENS;
     struct { unsigned short **p; size_t elems; } want[] = {{&s->bh, R * H}, {&s->bx, R * H}, {&s->bq, R * qd}, {&s->battn, R * qd}, {&s->bact, R * I}};
     HIP_TRY(hipSetDevice(e->device));
     for (auto &w : want) {
+        if (*w.p) continue;                     // kept from an earlier, partially failed attempt
         void *p = nullptr;
         int rc = dev_alloc(&p, w.elems * 2);
         if (rc) return rc;
@@ -1021,6 +1022,15 @@ int vlo_debug_read(vlo_session *s, int which, void *dst_dev, int64_t bytes, void
     HIP_TRY(hipMemcpyAsync(dst_dev, src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return VLO_OK;
 }
+
+/* host-side geometry of the 64-token block path, for unit tests: plan (NW, KF, KC) for a K, packed-64 element offset */
+int vlo_debug_gemm64_plan(int K, int *out3) {
+    Gemm64Plan p;
+    if (!out3 || gemm64_plan(K, &p)) return fail(VLO_E_UNSUPPORTED, "no block-GEMM plan for K=" + std::to_string(K));
+    out3[0] = p.NW; out3[1] = p.KF; out3[2] = p.KC;
+    return VLO_OK;
+}
+int64_t vlo_debug_pack64_elem(int row, int k) { return (row < 0 || row >= VLO_BLOCK_TOKENS || k < 0) ? -1 : (int64_t)vlo_pack64_elem(row, k); }
 
 int vlo_debug_gemv_plan(int K, int allow_ksplit, int *out4) {
     GemvPlan p;
