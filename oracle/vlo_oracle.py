@@ -360,7 +360,12 @@ class KVCacheOracle:
 class LlamaOracle:
     def __init__(self, spec: LlmSpec, weights: dict, dtype=torch.bfloat16):
         self.spec, self.dtype = spec, dtype
-        self.W = {k: v.to(dtype) for k, v in weights.items()}
+        done = {}                                   # tensors aliased under several names are converted (and held) once
+        self.W = {}
+        for k, v in weights.items():
+            if id(v) not in done:
+                done[id(v)] = v.to(dtype)
+            self.W[k] = done[id(v)]
 
     def new_cache(self):
         return KVCacheOracle(self.spec.num_layers)
