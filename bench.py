@@ -287,7 +287,7 @@ def main():
     ap.add_argument("--mode", default="scheduled", choices=["scheduled", "silent", "free"])
     ap.add_argument("--fps", type=float, default=2.0)
     ap.add_argument("--no-prefetch", action="store_true")
-    ap.add_argument("--prefetch-frames", type=int, default=4, help="frames encoded ahead per batched ViT call")
+    ap.add_argument("--prefetch-frames", type=int, default=8, help="frames encoded ahead per batched ViT call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=12)
     ap.add_argument("--prof-stride", type=int, default=8)
