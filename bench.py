@@ -297,7 +297,7 @@ def main():
     ap.add_argument("--no-tp-leg", action="store_true",
                     help="N > 1: skip the extra tensor-parallel measurement (run in child processes after the replica run)")
     ap.add_argument("--tp-leg-steps", type=int, default=300)
-    ap.add_argument("--tp-leg-timeout", type=float, default=420.0)
+    ap.add_argument("--tp-leg-timeout", type=float, default=240.0)
     args = ap.parse_args()
 
     import torch
