@@ -1,7 +1,6 @@
 """Host logic of the checkpoint loader on synthetic safetensors: LoRA merge == the
 reference's un-merged run-time LoRA up to rounding, connector restored from modules_to_save, SigLIP keys mapped."""
 import json
-import os
 
 import pytest
 import torch

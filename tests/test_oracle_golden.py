@@ -2,7 +2,6 @@
 classes (oracle/make_golden.py, run in the build container where /root/reference exists).
 CPU only; no /root/reference access at run time."""
 import os
-from functools import lru_cache
 
 import numpy as np
 import pytest

@@ -1,6 +1,5 @@
 """Measured machine ceilings on this MI355X (SURVEY.md §8d asks for them next to the spec numbers): device-to-device copy
 and read-only streaming bandwidth, library bf16/fp16 GEMM rate.  torch / hipBLASLt kernels only — calibration, not product."""
-import time
 
 import torch
 
