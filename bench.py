@@ -14,8 +14,8 @@ generated every 10th frame plus one for the t=0 user query; ``--mode silent`` an
 are available.  N > 1 runs one independent stream per GPU (replicas, weak scaling: streams are
 independent, there is no exchange step) under torchrun, barrier + max-over-ranks timing — that is
 ``value``.  The same invocation then measures ONE stream with the Llama tensor-parallel over the N
-GPUs (``--tp``, RCCL all-reduce x2 per layer) in child processes and reports it under ``"tp"``; a
-failure there is recorded, never fatal.
+GPUs (``--tp``) in child processes, once with RCCL all-reduces (``"tp"``) and once with the one-shot
+peer-to-peer all-reduce over xGMI (``"tp_p2p"``); a failure there is recorded, never fatal.
 
 Prints ONE JSON line (rank 0) with the driver's contract keys plus ``roofline`` (dominant kernel =
 the gate/up weight-streaming GEMV, timed live with HIP events on its own stream) and
@@ -237,17 +237,18 @@ def cpu_baseline(model_name, frames_u8_cpu, toks, mode, sample_frames, budget_s=
                       f"one random layer's weights aliased across layers (timing-equivalent)"}
 
 
-def run_tp_leg(args, rank, world, local):
-    """Spawn `bench.py --tp` as a child of every rank (same RANK / LOCAL_RANK / WORLD_SIZE, rendezvous on MASTER_PORT + 17),
-    wait with a deadline, kill the child's process group on timeout.  Rank 0 returns the child's headline numbers."""
+def run_tp_leg(args, rank, world, local, allreduce="rccl", port_offset=17):
+    """Spawn `bench.py --tp --tp-allreduce <allreduce>` as a child of every rank (same RANK / LOCAL_RANK / WORLD_SIZE,
+    rendezvous on MASTER_PORT + port_offset), wait with a deadline, kill the child's process group on timeout.  Rank 0
+    returns the child's headline numbers."""
     import signal
     import subprocess
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC") and k not in ("GROUP_RANK", "ROLE_RANK")}
     env.update(RANK=str(rank), LOCAL_RANK=str(local), WORLD_SIZE=str(world), MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
-               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 17), VLO_BENCH_TP_LEG="0")
+               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + port_offset), VLO_BENCH_TP_LEG="0")
     steps = max(20, min(args.steps, args.tp_leg_steps))
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(steps), "--warmup", "10", "--tp",
-           "--no-cpu-baseline", "--model", args.model, "--mode", args.mode, "--fps", str(args.fps),
+           "--tp-allreduce", allreduce, "--no-cpu-baseline", "--model", args.model, "--mode", args.mode, "--fps", str(args.fps),
            "--prefetch-frames", str(args.prefetch_frames)]
     log(f"tp leg: {' '.join(cmd[1:])}")
     t0 = time.time()
@@ -272,9 +273,12 @@ def run_tp_leg(args, rank, world, local):
     d = json.loads(line)
     keep = ("value", "unit", "ms_per_step", "p50_frame_latency_ms", "p95_frame_latency_ms", "steps", "scaling")
     r = {k: d.get(k) for k in keep}
+    how = ("RCCL all-reduce x2 per layer + logits all-gather" if allreduce == "rccl" else
+           "one-shot peer-to-peer all-reduce over xGMI fused with residual add + RMSNorm, x2 per layer, + p2p logits gather; no RCCL")
     r.update(parallelism=d["config"]["parallelism"], stream_hbm_roofline=d.get("stream_hbm_roofline"), wall_s=round(time.time() - t0, 1),
-             note="ONE stream, Llama tensor-parallel over the same GPUs (RCCL all-reduce x2 per layer + logits all-gather), "
-                  "ViT replicated; measured by `bench.py --tp` in child processes")
+             exchange=d["config"].get("tp_exchange"),
+             note=f"ONE stream, Llama tensor-parallel over the same GPUs ({how}), ViT replicated; measured by "
+                  f"`bench.py --tp --tp-allreduce {allreduce}` in child processes")
     return r
 
 
@@ -294,10 +298,13 @@ def main():
     ap.add_argument("--tp", action="store_true",
                     help="N > 1: ONE stream, Llama tensor-parallel over the N GPUs (RCCL all-reduce), strong scaling; "
                          "default is one independent stream per GPU (replicas, weak scaling)")
+    ap.add_argument("--tp-allreduce", default="rccl", choices=["rccl", "p2p"],
+                    help="--tp exchanges: RCCL all-reduce / all-gather, or the one-shot peer-to-peer all-reduce over xGMI fused "
+                         "with the residual add + RMSNorm (csrc/tp.hip, no RCCL)")
     ap.add_argument("--no-tp-leg", action="store_true",
                     help="N > 1: skip the extra tensor-parallel measurement (run in child processes after the replica run)")
     ap.add_argument("--tp-leg-steps", type=int, default=300)
-    ap.add_argument("--tp-leg-timeout", type=float, default=240.0)
+    ap.add_argument("--tp-leg-timeout", type=float, default=200.0, help="deadline of EACH tensor-parallel child leg (rccl, p2p)")
     args = ap.parse_args()
 
     import torch
@@ -334,9 +341,16 @@ def main():
     if tp:
         # every rank builds the SAME full random weights (same seed) and keeps its shard; the RCCL communicator is
         # bootstrapped from rank 0's unique id
-        uid = [TpGroup.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        eng = TpGroup(cfg, world, device=local, rank=rank, unique_id=uid[0])
+        if args.tp_allreduce == "p2p":
+            def gather_handles(mine):          # every rank's 64-byte mailbox handle, in rank order
+                out = [None] * world
+                dist.all_gather_object(out, mine)
+                return out
+            eng = TpGroup(cfg, world, device=local, rank=rank, allreduce="p2p", handle_allgather=gather_handles)
+        else:
+            uid = [TpGroup.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            eng = TpGroup(cfg, world, device=local, rank=rank, unique_id=uid[0])
         gpu_random_weights(eng, cfg, seed=0)
     else:
         eng = Engine(cfg, local)
@@ -425,11 +439,12 @@ def main():
             "p50_frame_latency_ms": round(statistics.median(costs) * 1e3, 4),
             "p95_frame_latency_ms": round(sorted(costs)[int(0.95 * (len(costs) - 1))] * 1e3, 4),
             "config": {"workload": f"{args.model} + siglip-l16-384, {K} frames @ {args.fps:g} FPS 384x384 uint8, "
-                                   + (f"ONE stream, Llama TP={world} (RCCL all-reduce x2/layer), ViT replicated, "
+                                   + (f"ONE stream, Llama TP={world} ({'RCCL' if args.tp_allreduce == 'rccl' else 'one-shot p2p'} all-reduce x2/layer), ViT replicated, "
                                       if tp else f"TP=1, one stream per GPU ({world} replica(s)), ") + f"mode={args.mode} "
                                    f"(16-token response every 10th frame + t=0 query), random-init weights at true shapes",
                        "frames": K, "final_kv_tokens": final_len, "llm_steps": llm_steps, "prefetch_encode": not args.no_prefetch, "prefetch_frames": args.prefetch_frames,
-                       "parallelism": f"tp{world}" if tp else f"replicas{world}"},
+                       "parallelism": f"tp{world}" if tp else f"replicas{world}",
+                       **({"tp_exchange": dict(kind=args.tp_allreduce, **(eng.p2p_status() if args.tp_allreduce == "p2p" else {}))} if tp else {})},
             "encode_stage": {"batch": max(1, args.prefetch_frames), "ms_per_frame": round(vit_ms, 4),
                              "tflops": round(VIT_GFLOP_PER_FRAME / vit_ms, 1), "mfma_peak_tflops": MFMA_PEAK_TFLOPS,
                              "frac_of_mfma_peak": round(VIT_GFLOP_PER_FRAME / vit_ms / MFMA_PEAK_TFLOPS, 4),
@@ -444,12 +459,17 @@ def main():
     # N > 1, replica mode: also measure ONE stream tensor-parallel over the same N GPUs (BASELINE.json north_star).  It
     # runs in child processes (one per rank, own rendezvous port) so that a failure or hang of the RCCL leg — which no
     # single-GPU box can exercise beforehand — can never cost the replica line above.
-    tp_leg = None
+    tp_leg = tp_p2p_leg = None
     if world > 1 and not tp and not args.no_tp_leg and os.environ.get("VLO_BENCH_TP_LEG", "1") != "0":
-        tp_leg = run_tp_leg(args, rank, world, local)
+        tp_leg = run_tp_leg(args, rank, world, local, "rccl", 17)
+        if dist is not None:
+            dist.barrier()                     # every rank's first child is gone before the second leg claims the GPUs
+        tp_p2p_leg = run_tp_leg(args, rank, world, local, "p2p", 29)
     if rank == 0:
         if tp_leg is not None:
             out["tp"] = tp_leg
+        if tp_p2p_leg is not None:
+            out["tp_p2p"] = tp_p2p_leg
         if world == 1 and not args.no_cpu_baseline:
             log("cpu_baseline: building CPU oracle")
             try:

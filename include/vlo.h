@@ -202,6 +202,26 @@ int  vlo_tp_stream_sample(vlo_tp_session *t, float threshold, int interval_id, i
 int  vlo_tp_greedy_generate(vlo_tp_session *t, const void *embeds_dev, int m, int eos_token_id, int64_t *out_ids_dev, int max_new,
                             int force_len, int *n_written, void *stream);
 
+/* One-shot peer-to-peer all-reduce over xGMI, fused with the residual add + RMSNorm that consumes it (opt-in replacement
+ * of the two RCCL all-reduces per layer and of the logits all-gather; SURVEY.md §8e "xGMI mapping").  Every rank owns a
+ * mailbox in its HBM that all peers map; an exchange is one posted write per peer and one hop of latency instead of a
+ * ring's 2(T-1).  No RCCL communicator is needed: vlo_tp_group_create may then be given rccl_unique_id = NULL.
+ *   one process per GPU: every rank calls vlo_tp_p2p_export (64-byte hipIpc handle of its mailbox), the host gathers
+ *       the T handles in rank order (e.g. torch.distributed.all_gather_object) and every rank calls
+ *       vlo_tp_p2p_enable(g, handles) with handles = [T][64 bytes];
+ *   single process (T logical ranks on one device): vlo_tp_p2p_enable(g, NULL).
+ * All ranks must issue the same sequence of steps (they already do: the step is lock-step).  A rank that waits longer
+ * than VLO_TP_P2P_TIMEOUT_MS (default 2000) for a peer raises a sticky error: the stream drains, the next
+ * vlo_tp_llm_step fails with VLO_E_HIP, vlo_tp_p2p_status reports timed_out = 1. */
+int  vlo_tp_p2p_export(vlo_tp_group *g, void *out_handle64);
+int  vlo_tp_p2p_enable(vlo_tp_group *g, const void *handles);
+int  vlo_tp_p2p_status(vlo_tp_group *g, int *enabled, int *timed_out, int *uncached_mailbox);
+/* host-side mailbox geometry of the exchange above (no GPU needed; unit tests): for a group of T ranks, hidden size H,
+ * vocabulary shard Vl, the seq-th exchange of a region (seq counts from 0 per region) and the tag `epoch` of the previous
+ * exchange, out6 = {first granule of the reduce slot, granules between two sources of a reduce slot, first granule of the
+ * gather slot, granules between two sources of a gather slot, mailbox size in granules, the next epoch} */
+int  vlo_debug_p2p_layout(int T, int H, int Vl, unsigned seq, unsigned epoch, int64_t *out6);
+
 /* live kernel timing for bench.py's roofline: when enabled, every `stride`-th launch of the dominant
  * kernel (the gate/up weight-streaming GEMV, gemv16_kernel<KF,SWIGLU>) is bracketed by HIP events on the
  * stream it is launched on.  vlo_profile_read synchronises those events and returns the number of timed

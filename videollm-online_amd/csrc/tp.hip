@@ -13,6 +13,12 @@
 // box — exchanges are a sum / copy kernel), or exactly one in the one-process-per-GPU mode (exchanges are RCCL
 // ncclAllReduce / ncclAllGather on the step's stream, communicator bootstrapped from a unique id that the host
 // broadcasts with torch.distributed).  librccl is dlopen'ed so libvlo.so has no link-time dependency on it.
+//
+// Second exchange implementation, opt-in (vlo_tp_p2p_*): a ONE-SHOT peer-to-peer all-reduce over xGMI fused with the
+// residual add + RMSNorm that consumes it.  SURVEY.md §8e: the messages are 16-180 KB, so a ring all-reduce (14 hops,
+// per-link bound) pays latency 14 times for a wire time of ~1 us; here every rank writes its fp32 partial row straight
+// into a mailbox in EVERY peer's HBM (7 posted writes over 7 distinct links) and then sums the T mailbox rows in rank
+// order — one hop, and bit-identical sums on every rank.  See "p2p exchange" below.
 #include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
@@ -80,10 +86,26 @@ static int rccl_load() {
 }
 
 // ---- group / session ----------------------------------------------------------------------------------------
+struct P2PState {
+    bool allocated = false, enabled = false, uncached = false;
+    int H = 0, Vh = 0;                     // granules per reduce row / per gather row (V_l / 2)
+    size_t gat_base = 0, granules = 0;     // first granule of the gather region; mailbox size in granules
+    unsigned long long *mbox[8] = {};      // the local ranks' own mailboxes (device memory of their GPU), by local index
+    unsigned long long *peer[8][8] = {};   // [local index][global rank] -> that rank's mailbox as addressable from here
+    std::vector<void *> ipc_opened;        // mappings returned by hipIpcOpenMemHandle
+    unsigned epoch = 0;                    // tag of the latest exchange (never 0), advanced in lock-step by every rank
+    unsigned n_reduce = 0, n_gather = 0;   // exchanges issued per mailbox region: slot = count & 1
+    unsigned *err_dev[8] = {};             // per local rank: set by a spin that timed out (later kernels stop waiting)
+    unsigned *err_host = nullptr;          // pinned, device-visible: the host reads it without synchronising
+    long long timeout_ticks = 200000000;   // s_memrealtime ticks (100 MHz): 2 s
+    bool fused = true;                     // one kernel publishes AND collects (one process per GPU only)
+};
+
 struct vlo_tp_group {
     std::vector<vlo_engine *> eng;     // local ranks, consecutive tp_rank values
     int tp_size = 1;
     void *comm = nullptr;              // RCCL communicator (one-process-per-GPU mode)
+    P2PState p2p;
 };
 struct vlo_tp_session {
     vlo_tp_group *g = nullptr;
@@ -182,8 +204,7 @@ int vlo_tp_group_create(vlo_engine **engines, int n_local, const void *rccl_uniq
     vlo_tp_group *g = new vlo_tp_group();
     g->eng.assign(engines, engines + n_local);
     g->tp_size = T;
-    if (n_local == 1 && T > 1) {
-        if (!rccl_unique_id) { delete g; return vlo_fail(VLO_E_INVALID, "one-process-per-GPU groups need the RCCL unique id"); }
+    if (n_local == 1 && T > 1 && rccl_unique_id) {     // no unique id: the p2p exchange must be enabled before the first step
         int rc = rccl_load();
         if (rc) { delete g; return rc; }
         NcclUid id;
@@ -198,9 +219,11 @@ int vlo_tp_group_create(vlo_engine **engines, int n_local, const void *rccl_uniq
     return VLO_OK;
 }
 
+static void p2p_release(vlo_tp_group *g);
 void vlo_tp_group_destroy(vlo_tp_group *g) {
     if (!g) return;
     if (g->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(g->comm);
+    p2p_release(g);
     delete g;
 }
 
@@ -232,6 +255,365 @@ int vlo_tp_session_reset(vlo_tp_session *t) {
 }
 int64_t vlo_tp_session_len(const vlo_tp_session *t) { return t && !t->ss.empty() ? t->ss[0]->len : -1; }
 
+// ---- p2p exchange ------------------------------------------------------------------------------------------------
+// Every rank owns a MAILBOX in its own HBM, mapped by every peer (hipIpc across processes, plain pointers inside one):
+//   reduce region  [2 slots][T sources][16 rows][H]        8-byte granules {tag = epoch, fp32 partial sum}
+//   gather region  [2 slots][T sources][16 rows][V_l / 2]  8-byte granules {tag = epoch, two bf16 logits}
+// A granule is written by ONE naturally aligned 8-byte system-scope store and read by one 8-byte system-scope load, so
+// the data carries its own "ready" flag: no fence, no store ordering and no separate flag are relied upon
+// (cdna_hip_programming.md §6 Guideline 16, form R2 — applied here across GPUs: the mailbox is uncached / fine-grained
+// memory, remote writes land in the owner's HBM, the owner polls with sc0 sc1 loads that no cache level serves).
+// An exchange = every rank PUBLISHES its [m][H] row sums into slot (epoch & 1) of all T mailboxes (its own included),
+// then COLLECTS the T source rows of its own mailbox in rank order 0..T-1 — the same fp32 sum on every rank — and goes
+// straight on with `h += bf16(sum); x = RMSNorm(h) * w` (what add_rmsnorm_kernel does after an RCCL all-reduce).
+// Two slots per region suffice: a rank can only publish the region's exchange k+2 (the slot of k) after collecting k+1,
+// which needs every peer's k+1 granules, which a peer stores (stream order) after it finished collecting k.  Tags are
+// compared for equality with the epoch, a host-side counter that all ranks advance in lock-step, so stale slots never match.  Every spin is bounded
+// (s_memrealtime); a timeout raises a sticky error word and later kernels stop waiting, so the stream always drains.
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned int gu32;
+
+struct P2PPeers { unsigned long long *mbox[8]; };
+
+VLO_DEV void granule_store(unsigned long long *p, unsigned epoch, unsigned value) {
+    __hip_atomic_store((gu64 *)p, ((unsigned long long)epoch << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+VLO_DEV unsigned long long granule_load(const unsigned long long *p) {
+    return __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+VLO_DEV void p2p_timeout(unsigned *err_dev, unsigned *err_host) {
+    __hip_atomic_fetch_or((gu32 *)err_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_or(err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+struct XchgArgs {
+    const float *partial;        // this rank's partial sums [ks][16][ld] (fp32), produced by the preceding GEMV
+    int ks, ld;
+    P2PPeers peers;              // every rank's mailbox, by global rank
+    int T, me;
+    unsigned long long slot_off; // granule offset of [slot][0][0][0] in the reduce region
+    unsigned epoch;
+    int mode;                    // bit 0: publish, bit 1: collect + residual add + RMSNorm
+    unsigned short *h;           // residual stream [16][H] bf16, updated in place
+    const unsigned short *w;     // norm weight
+    unsigned short *x;           // normed rows out [16][ldx]
+    int H, ldx;
+    float eps;
+    unsigned *err_dev, *err_host;
+    long long timeout_ticks;
+};
+
+#define XCHG_THREADS 512
+// grid = m rows; thread t owns the 8-column chunks t, t + 512, ... of its row (one chunk when H = 4096)
+__global__ __launch_bounds__(XCHG_THREADS) void tp_xchg_norm_kernel(XchgArgs a) {
+    __shared__ float sm[16];
+    const int m = blockIdx.x;
+    const int nch = a.H >> 3;
+    const size_t row_off = a.slot_off + (size_t)m * a.H;
+    const size_t src_stride = (size_t)16 * a.H;              // granules between two sources of one slot
+    if (a.mode & 1) {
+        for (int ch = threadIdx.x; ch < nch; ch += XCHG_THREADS) {
+            float d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int s = 0; s < a.ks; ++s) {
+                const float4 *pp = reinterpret_cast<const float4 *>(a.partial + ((size_t)s * 16 + m) * a.ld + ch * 8);
+                const float4 u = pp[0], v = pp[1];
+                d[0] += u.x; d[1] += u.y; d[2] += u.z; d[3] += u.w;
+                d[4] += v.x; d[5] += v.y; d[6] += v.z; d[7] += v.w;
+            }
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                if (p < a.T) {
+                    unsigned long long *dst = a.peers.mbox[p] + row_off + (size_t)a.me * src_stride + ch * 8;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) granule_store(dst + j, a.epoch, __float_as_uint(d[j]));
+                }
+            }
+        }
+    }
+    if (!(a.mode & 2)) return;
+    const unsigned long long *own = a.peers.mbox[a.me] + row_off;
+    const bool dead = __hip_atomic_load((gu32 *)a.err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    const unsigned all = (1u << a.T) - 1u;
+    const long long t0 = wall_clock64();
+    bf16_t *hr = a.h + (size_t)m * a.H;
+    float ss = 0.f;
+    // pass 1: collect, add to the residual stream, accumulate the row's sum of squares
+    for (int ch = threadIdx.x; ch < nch; ch += XCHG_THREADS) {
+        unsigned long long g[8][8];
+        unsigned done = dead ? all : 0u;
+        if (dead) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[p][j] = 0ull;
+        }
+        while (done != all) {
+            // every pending source's 8 granules go in flight together, then the tags are checked
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+                if (p < a.T && !((done >> p) & 1u)) {
+                    const unsigned long long *src = own + (size_t)p * src_stride + ch * 8;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g[p][j] = granule_load(src + j);
+                }
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+                if (p < a.T && !((done >> p) & 1u)) {
+                    bool ok = true;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ok &= (unsigned)(g[p][j] >> 32) == a.epoch;
+                    if (ok) done |= 1u << p;
+                }
+            if (done == all) break;
+            if (wall_clock64() - t0 > a.timeout_ticks) {
+                p2p_timeout(a.err_dev, a.err_host);
+#pragma unroll
+                for (int p = 0; p < 8; ++p)
+                    if (!((done >> p) & 1u))
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) g[p][j] = 0ull;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        float d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int p = 0; p < 8; ++p)                 // rank order: the same fp32 sum on every rank
+            if (p < a.T)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] += __uint_as_float((unsigned)g[p][j]);
+        const uint4 raw = *reinterpret_cast<const uint4 *>(hr + ch * 8);
+        const bf16_t *e = reinterpret_cast<const bf16_t *>(&raw);
+        uint4 o;
+        bf16_t *oe = reinterpret_cast<bf16_t *>(&o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {               // linear output -> bf16, then the bf16 residual add (as add_rmsnorm_kernel)
+            const float hn = rbf(bf2f(e[j]) + rbf(d[j]));
+            oe[j] = f2bf(hn);
+            ss += hn * hn;
+        }
+        *reinterpret_cast<uint4 *>(hr + ch * 8) = o;
+    }
+    ss = block_sum(ss, sm);
+    const float rs = 1.0f / sqrtf(ss / (float)a.H + a.eps);
+    // pass 2: x = w * bf16(h * rs); every thread re-reads the chunks it wrote itself
+    bf16_t *xr = a.x + (size_t)m * a.ldx;
+    for (int ch = threadIdx.x; ch < nch; ch += XCHG_THREADS) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(hr + ch * 8);
+        const uint4 wraw = *reinterpret_cast<const uint4 *>(a.w + ch * 8);
+        const bf16_t *e = reinterpret_cast<const bf16_t *>(&raw), *we = reinterpret_cast<const bf16_t *>(&wraw);
+        uint4 o;
+        bf16_t *oe = reinterpret_cast<bf16_t *>(&o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) oe[j] = f2bf(bf2f(we[j]) * rbf(bf2f(e[j]) * rs));
+        *reinterpret_cast<uint4 *>(xr + ch * 8) = o;
+    }
+}
+
+struct GatherArgs {
+    const unsigned short *local;   // this rank's logits shard [nr][Vl] bf16
+    unsigned short *out;           // [nr][V] bf16
+    P2PPeers peers;
+    int T, me, Vl, V;
+    unsigned long long slot_off;   // granule offset of [slot][0][0][0] in the gather region
+    unsigned epoch;
+    int mode;                      // bit 0: publish, bit 1: collect
+    unsigned *err_dev, *err_host;
+    long long timeout_ticks;
+};
+// grid = (blocks, nr rows); one granule = two adjacent bf16 logits
+__global__ __launch_bounds__(256) void tp_gather_kernel(GatherArgs a) {
+    const int row = blockIdx.y;
+    const int Vh = a.Vl >> 1;
+    const size_t src_stride = (size_t)16 * Vh;
+    const size_t row_off = a.slot_off + (size_t)row * Vh;
+    if (a.mode & 1) {
+        const unsigned *loc = reinterpret_cast<const unsigned *>(a.local + (size_t)row * a.Vl);
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Vh; i += gridDim.x * blockDim.x) {
+            const unsigned v = loc[i];
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+                if (p < a.T) granule_store(a.peers.mbox[p] + row_off + (size_t)a.me * src_stride + i, a.epoch, v);
+        }
+    }
+    if (!(a.mode & 2)) return;
+    const unsigned long long *own = a.peers.mbox[a.me] + row_off;
+    const bool dead = __hip_atomic_load((gu32 *)a.err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    const long long t0 = wall_clock64();
+    const int total = a.T * Vh;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int p = i / Vh, c = i - p * Vh;
+        unsigned long long g = 0ull;
+        if (!dead) {
+            for (;;) {
+                g = granule_load(own + (size_t)p * src_stride + c);
+                if ((unsigned)(g >> 32) == a.epoch) break;
+                if (wall_clock64() - t0 > a.timeout_ticks) {
+                    p2p_timeout(a.err_dev, a.err_host);
+                    g = 0ull;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        reinterpret_cast<unsigned *>(a.out + (size_t)row * a.V + (size_t)p * a.Vl)[c] = (unsigned)g;
+    }
+}
+
+// mailbox layout, in granules (shared by the launch code and vlo_debug_p2p_layout)
+// `seq` = how many exchanges of THAT region were issued before this one: consecutive exchanges of a region alternate slots
+// whatever the other region does in between (the two-slot argument above is per region); the TAG is the group-wide epoch.
+static inline size_t p2p_reduce_slot_off(int T, int H, unsigned seq) { return (size_t)(seq & 1u) * T * 16 * H; }
+static inline size_t p2p_gather_base(int T, int H) { return (size_t)2 * T * 16 * H; }
+static inline size_t p2p_gather_slot_off(int T, int H, int Vh, unsigned seq) { return p2p_gather_base(T, H) + (size_t)(seq & 1u) * T * 16 * Vh; }
+static inline size_t p2p_total_granules(int T, int H, int Vh) { return p2p_gather_base(T, H) + (size_t)2 * T * 16 * Vh; }
+static inline unsigned p2p_next_epoch(unsigned epoch) { return epoch + 1u == 0u ? 1u : epoch + 1u; }   // the tag is never 0
+
+int vlo_debug_p2p_layout(int T, int H, int Vl, unsigned seq, unsigned epoch, int64_t *out6) {
+    if (!out6 || T < 2 || T > 8 || H <= 0 || (H & 7) || Vl <= 0 || (Vl & 1)) return vlo_fail(VLO_E_INVALID, "bad debug_p2p_layout arguments");
+    const int Vh = Vl / 2;
+    out6[0] = (int64_t)p2p_reduce_slot_off(T, H, seq);         // first granule of the reduce slot of the seq-th reduce exchange
+    out6[1] = (int64_t)16 * H;                                 // granules between two sources in a reduce slot (row stride = H)
+    out6[2] = (int64_t)p2p_gather_slot_off(T, H, Vh, seq);     // first granule of the gather slot of the seq-th gather exchange
+    out6[3] = (int64_t)16 * Vh;                                // granules between two sources in a gather slot (row stride = Vl / 2)
+    out6[4] = (int64_t)p2p_total_granules(T, H, Vh);           // mailbox size
+    out6[5] = (int64_t)p2p_next_epoch(epoch);
+    return VLO_OK;
+}
+
+static void p2p_release(vlo_tp_group *g) {
+    P2PState &P = g->p2p;
+    for (void *m : P.ipc_opened) hipIpcCloseMemHandle(m);
+    P.ipc_opened.clear();
+    for (size_t i = 0; i < g->eng.size() && i < 8; ++i) {
+        hipSetDevice(g->eng[i]->device);
+        if (P.mbox[i]) hipFree(P.mbox[i]);
+        if (P.err_dev[i]) hipFree(P.err_dev[i]);
+        P.mbox[i] = nullptr;
+        P.err_dev[i] = nullptr;
+    }
+    if (P.err_host) hipHostFree(P.err_host);
+    P.err_host = nullptr;
+    P.allocated = P.enabled = false;
+}
+
+// mailboxes of the local ranks: uncached device memory (no cache level may serve a poll), zeroed so that no tag matches
+static int p2p_allocate(vlo_tp_group *g) {
+    P2PState &P = g->p2p;
+    if (P.allocated) return VLO_OK;
+    const vlo_engine *e0 = g->eng[0];
+    const int T = g->tp_size;
+    if (T < 2 || T > 8) return vlo_fail(VLO_E_INVALID, "the p2p exchange needs 2 <= tp_size <= 8");
+    if ((e0->cfg.hidden_size & 7) || (e0->V_l & 1)) return vlo_fail(VLO_E_UNSUPPORTED, "p2p exchange: hidden_size % 8 or odd vocabulary shard");
+    P.H = e0->cfg.hidden_size;
+    P.Vh = e0->V_l / 2;
+    P.gat_base = p2p_gather_base(T, P.H);
+    P.granules = p2p_total_granules(T, P.H, P.Vh);
+    if (const char *v = getenv("VLO_TP_P2P_TIMEOUT_MS")) P.timeout_ticks = (long long)atoll(v) * 100000ll;
+    if (const char *v = getenv("VLO_TP_P2P_FUSED")) P.fused = atoi(v) != 0;
+    if (hipHostMalloc((void **)&P.err_host, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess)
+        return vlo_fail(VLO_E_HIP, "p2p exchange: hipHostMalloc of the error word failed");
+    *P.err_host = 0u;
+    P.uncached = true;
+    for (size_t i = 0; i < g->eng.size(); ++i) {
+        TP_TRY(hipSetDevice(g->eng[i]->device));
+        void *m = nullptr;
+        const size_t bytes = P.granules * 8;
+        if (hipExtMallocWithFlags(&m, bytes, hipDeviceMallocUncached) != hipSuccess) {
+            (void)hipGetLastError();
+            P.uncached = false;
+            if (hipExtMallocWithFlags(&m, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+                (void)hipGetLastError();
+                p2p_release(g);
+                return vlo_fail(VLO_E_NOMEM, "p2p exchange: cannot allocate an uncached / fine-grained mailbox");
+            }
+        }
+        P.mbox[i] = (unsigned long long *)m;
+        hipError_t he = hipMemset(m, 0, bytes);
+        if (he == hipSuccess) he = hipMalloc((void **)&P.err_dev[i], 64);
+        if (he == hipSuccess) he = hipMemset(P.err_dev[i], 0, 64);
+        if (he == hipSuccess) he = hipDeviceSynchronize();
+        if (he != hipSuccess) {
+            p2p_release(g);
+            return vlo_fail(VLO_E_HIP, std::string("p2p exchange: mailbox setup: ") + hipGetErrorString(he));
+        }
+    }
+    P.allocated = true;
+    return VLO_OK;
+}
+
+int vlo_tp_p2p_export(vlo_tp_group *g, void *out_handle64) {
+    if (!g || !out_handle64) return vlo_fail(VLO_E_INVALID, "bad tp_p2p_export arguments");
+    if (g->eng.size() != 1) return vlo_fail(VLO_E_STATE, "tp_p2p_export is for one-process-per-GPU groups (single-process groups need no handles)");
+    int rc = p2p_allocate(g);
+    if (rc) return rc;
+    TP_TRY(hipSetDevice(g->eng[0]->device));
+    hipIpcMemHandle_t h;
+    TP_TRY(hipIpcGetMemHandle(&h, g->p2p.mbox[0]));
+    static_assert(sizeof(h) == 64, "hipIpcMemHandle_t is 64 bytes");
+    memcpy(out_handle64, &h, sizeof(h));
+    return VLO_OK;
+}
+
+int vlo_tp_p2p_enable(vlo_tp_group *g, const void *handles) {
+    if (!g) return vlo_fail(VLO_E_INVALID, "null tp group");
+    P2PState &P = g->p2p;
+    if (P.enabled) return VLO_OK;
+    const int T = g->tp_size, R = (int)g->eng.size();
+    int rc = p2p_allocate(g);
+    if (rc) return rc;
+    if (R == T) {                                   // single process: every mailbox is a local allocation
+        for (int i = 0; i < R; ++i)
+            for (int p = 0; p < T; ++p) P.peer[i][p] = P.mbox[p];
+        P.fused = false;                            // the logical ranks share one stream: publish all, then collect all
+    } else {
+        if (!handles) return vlo_fail(VLO_E_INVALID, "one-process-per-GPU groups need the T mailbox handles (vlo_tp_p2p_export of every rank, in rank order)");
+        const int me = g->eng[0]->tp_rank;
+        TP_TRY(hipSetDevice(g->eng[0]->device));
+        int ndev = 0;
+        TP_TRY(hipGetDeviceCount(&ndev));
+        for (int d = 0; d < ndev; ++d) {            // peers' HBM is written over xGMI: peer access to every visible GPU
+            if (d == g->eng[0]->device) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, g->eng[0]->device, d) == hipSuccess && can) {
+                const hipError_t he = hipDeviceEnablePeerAccess(d, 0);
+                if (he != hipSuccess) (void)hipGetLastError();      // already enabled is fine
+            }
+        }
+        for (int p = 0; p < T; ++p) {
+            if (p == me) { P.peer[0][p] = P.mbox[0]; continue; }
+            hipIpcMemHandle_t h;
+            memcpy(&h, (const char *)handles + (size_t)p * sizeof(h), sizeof(h));
+            void *m = nullptr;
+            const hipError_t he = hipIpcOpenMemHandle(&m, h, hipIpcMemLazyEnablePeerAccess);
+            if (he != hipSuccess) {
+                (void)hipGetLastError();
+                for (void *q : P.ipc_opened) hipIpcCloseMemHandle(q);
+                P.ipc_opened.clear();
+                return vlo_fail(VLO_E_HIP, "hipIpcOpenMemHandle(mailbox of rank " + std::to_string(p) + "): " + hipGetErrorString(he));
+            }
+            P.ipc_opened.push_back(m);
+            P.peer[0][p] = (unsigned long long *)m;
+        }
+    }
+    P.enabled = true;
+    return VLO_OK;
+}
+
+int vlo_tp_p2p_status(vlo_tp_group *g, int *enabled, int *timed_out, int *uncached) {
+    if (!g) return vlo_fail(VLO_E_INVALID, "null tp group");
+    if (enabled) *enabled = g->p2p.enabled ? 1 : 0;
+    if (timed_out) *timed_out = (g->p2p.err_host && *(volatile unsigned *)g->p2p.err_host) ? 1 : 0;
+    if (uncached) *uncached = g->p2p.uncached ? 1 : 0;
+    return VLO_OK;
+}
+
+static P2PPeers p2p_peers(const P2PState &P, int local_idx, int T) {
+    P2PPeers pp{};
+    for (int p = 0; p < T; ++p) pp.mbox[p] = P.peer[local_idx][p];
+    return pp;
+}
+
 // ---- exchanges -------------------------------------------------------------------------------------------------
 static int tp_allreduce(vlo_tp_session *t, float *(vlo_session::*buf), size_t count, hipStream_t st) {
     vlo_tp_group *g = t->g;
@@ -252,10 +634,74 @@ static int tp_allreduce(vlo_tp_session *t, float *(vlo_session::*buf), size_t co
     return VLO_OK;
 }
 
+// all-reduce of every local rank's partial sums `buf` [ks][16][H] + `h += bf16(sum); x = RMSNorm(h) * w` on every local rank.
+// RCCL / sum-kernel: the slabs are all-reduced in place, add_rmsnorm_kernel combines them.  p2p: see "p2p exchange".
+static int tp_reduce_norm(vlo_tp_session *t, float *(vlo_session::*buf), int ks, int m, const void *(*norm_w)(const vlo_engine *, int), int layer,
+                          hipStream_t st) {
+    vlo_tp_group *g = t->g;
+    const int R = (int)t->ss.size();
+    const vlo_config &c = g->eng[0]->cfg;
+    const int H = c.hidden_size;
+    P2PState &P = g->p2p;
+    if (!P.enabled) {
+        int rc = tp_allreduce(t, buf, ks == 1 ? (size_t)m * H : (size_t)ks * 16 * H, st);
+        if (rc) return rc;
+        for (int r = 0; r < R; ++r) {
+            vlo_session *s = t->ss[r];
+            TP_TRY(add_rmsnorm_launch(s->h, s->*buf, ks, H, (const unsigned short *)norm_w(s->e, layer), s->x, H, H, c.rms_eps, m, st));
+        }
+        return VLO_OK;
+    }
+    P.epoch = p2p_next_epoch(P.epoch);              // the tag is never 0 (zeroed mailboxes must not match)
+    XchgArgs a{};
+    a.ks = ks; a.ld = H; a.T = g->tp_size;
+    a.slot_off = p2p_reduce_slot_off(g->tp_size, H, P.n_reduce++);
+    a.epoch = P.epoch; a.H = H; a.ldx = H; a.eps = c.rms_eps;
+    a.err_host = P.err_host; a.timeout_ticks = P.timeout_ticks;
+    const int passes = P.fused ? 1 : 2;
+    for (int pass = 0; pass < passes; ++pass)
+        for (int r = 0; r < R; ++r) {
+            vlo_session *s = t->ss[r];
+            a.partial = s->*buf; a.peers = p2p_peers(P, r, g->tp_size); a.me = s->e->tp_rank;
+            a.mode = P.fused ? 3 : (pass == 0 ? 1 : 2);
+            a.h = s->h; a.w = (const unsigned short *)norm_w(s->e, layer); a.x = s->x; a.err_dev = P.err_dev[r];
+            hipLaunchKernelGGL(tp_xchg_norm_kernel, dim3(m), dim3(XCHG_THREADS), 0, st, a);
+            TP_TRY(hipGetLastError());
+        }
+    return VLO_OK;
+}
+static const void *norm_in(const vlo_engine *e, int l) { return e->layers[l].ln_in; }
+static const void *norm_post(const vlo_engine *e, int l) { return e->layers[l].ln_post; }
+static const void *norm_final(const vlo_engine *e, int) { return e->norm_w; }
+
 // logits_local [nr][V_l] of every rank -> logits [nr][V] on every local rank
 static int tp_gather_logits(vlo_tp_session *t, int nr, hipStream_t st) {
     vlo_tp_group *g = t->g;
     const int T = g->tp_size, V = g->eng[0]->cfg.vocab_size, Vl = g->eng[0]->V_l;
+    if (g->p2p.enabled) {
+        P2PState &P = g->p2p;
+        P.epoch = p2p_next_epoch(P.epoch);
+        GatherArgs a{};
+        a.T = T; a.Vl = Vl; a.V = V; a.epoch = P.epoch;
+        a.slot_off = p2p_gather_slot_off(T, P.H, P.Vh, P.n_gather++);
+        a.err_host = P.err_host; a.timeout_ticks = P.timeout_ticks;
+        const int R = (int)t->ss.size();
+        const int passes = P.fused ? 1 : 2;
+        // fused mode spins on the peers' granules inside the publishing kernel: every block must be resident
+        int blocks = (T * P.Vh + 255) / 256;
+        const int cap = 256 / nr > 0 ? 256 / nr : 1;
+        if (blocks > cap) blocks = cap;
+        for (int pass = 0; pass < passes; ++pass)
+            for (int r = 0; r < R; ++r) {
+                vlo_session *s = t->ss[r];
+                a.local = s->logits_local; a.out = s->logits; a.peers = p2p_peers(P, r, T); a.me = s->e->tp_rank;
+                a.mode = P.fused ? 3 : (pass == 0 ? 1 : 2);
+                a.err_dev = P.err_dev[r];
+                hipLaunchKernelGGL(tp_gather_kernel, dim3(blocks, nr), dim3(256), 0, st, a);
+                TP_TRY(hipGetLastError());
+            }
+        return VLO_OK;
+    }
     if (g->comm) {
         vlo_session *s = t->ss[0];
         if (g_rccl.AllGather(s->logits_local, t->gather_tmp, (size_t)nr * Vl * 2, kNcclInt8, g->comm, st) != 0)
@@ -284,17 +730,16 @@ static int tp_chunk(vlo_tp_session *t, const unsigned short *src, int m, bool wa
         if ((rc = ensure_pages(s, s->len + m, st))) return rc;
         TP_TRY(copy_rows_launch(src, s->h, m, H, st));
     }
-    bool have_prev = false;
-    int prev_ks = 0;
+    int ks_d = 1;
     for (int l = 0; l < c.num_layers; ++l) {
-        int ks_o = 1, ks_d = 1;
+        int ks_o = 1;
         for (int r = 0; r < R; ++r) {           // attention half: everything up to the o_proj partial sums
             vlo_session *s = t->ss[r];
             vlo_engine *e = s->e;
             const LayerWeights &L = e->layers[l];
             const KvGeom kv = kv_geom(s);
-            TP_TRY(add_rmsnorm_launch(s->h, have_prev ? s->partial : nullptr, prev_ks, H, (const unsigned short *)L.ln_in, s->x, H, H,
-                                      c.rms_eps, m, st));
+            if (l == 0)                         // later layers: x comes out of the reduce + norm that closed the previous layer
+                TP_TRY(add_rmsnorm_launch(s->h, nullptr, 0, H, (const unsigned short *)L.ln_in, s->x, H, H, c.rms_eps, m, st));
             GemvArgs a = gemv_args(L.qkv, s->x, H, m);
             a.out_bf16 = s->q; a.cos_tab = (const unsigned short *)e->cos_tab; a.sin_tab = (const unsigned short *)e->sin_tab;
             a.kv = kv; a.layer = l; a.num_heads = e->nh_l; a.pos0 = s->len;
@@ -305,12 +750,12 @@ static int tp_chunk(vlo_tp_session *t, const unsigned short *src, int m, bool wa
             TP_TRY(gemv_launch(o, L.o.plan, XSRC_PLAIN, EPI_PARTIAL_F32, st));
             ks_o = L.o.plan.ksplit;
         }
-        if ((rc = tp_allreduce(t, &vlo_session::partial_o, ks_o == 1 ? (size_t)m * H : (size_t)ks_o * 16 * H, st))) return rc;
+        // exchange 1: h += all-reduce(o_proj partials); x = post-attention RMSNorm(h)
+        if ((rc = tp_reduce_norm(t, &vlo_session::partial_o, ks_o, m, norm_post, l, st))) return rc;
         for (int r = 0; r < R; ++r) {           // MLP half
             vlo_session *s = t->ss[r];
             vlo_engine *e = s->e;
             const LayerWeights &L = e->layers[l];
-            TP_TRY(add_rmsnorm_launch(s->h, s->partial_o, ks_o, H, (const unsigned short *)L.ln_post, s->x, H, H, c.rms_eps, m, st));
             GemvArgs a = gemv_args(L.gate_up, s->x, H, m);
             a.out_bf16 = s->act; a.ldo = e->I_l;
             TP_TRY(gemv_launch(a, L.gate_up.plan, XSRC_PLAIN, EPI_SWIGLU, st));
@@ -319,16 +764,16 @@ static int tp_chunk(vlo_tp_session *t, const unsigned short *src, int m, bool wa
             TP_TRY(gemv_launch(d, L.down.plan, XSRC_PLAIN, EPI_PARTIAL_F32, st));
             ks_d = L.down.plan.ksplit;
         }
-        if ((rc = tp_allreduce(t, &vlo_session::partial, ks_d == 1 ? (size_t)m * H : (size_t)ks_d * 16 * H, st))) return rc;
-        have_prev = true;
-        prev_ks = ks_d;
+        // exchange 2: h += all-reduce(down_proj partials); x = the next layer's input RMSNorm(h).  After the last layer it
+        // is the final norm, and only when logits are wanted (h is not read again otherwise).
+        if (l + 1 < c.num_layers && (rc = tp_reduce_norm(t, &vlo_session::partial, ks_d, m, norm_in, l + 1, st))) return rc;
     }
     if (want_last || want_all) {
         const int r0 = want_all ? 0 : m - 1, nr = want_all ? m : 1;
+        if ((rc = tp_reduce_norm(t, &vlo_session::partial, ks_d, m, norm_final, 0, st))) return rc;
         for (int r = 0; r < R; ++r) {
             vlo_session *s = t->ss[r];
             vlo_engine *e = s->e;
-            TP_TRY(add_rmsnorm_launch(s->h, s->partial, prev_ks, H, (const unsigned short *)e->norm_w, s->x, H, H, c.rms_eps, m, st));
             GemvArgs a = gemv_args(e->lm_head, s->x + (size_t)r0 * H, H, nr);
             a.out_bf16 = s->logits_local; a.ldo = e->V_l;
             TP_TRY(gemv_launch(a, e->lm_head.plan, XSRC_PLAIN, EPI_BF16, st));
@@ -346,6 +791,14 @@ static int tp_chunk(vlo_tp_session *t, const unsigned short *src, int m, bool wa
 int vlo_tp_llm_step(vlo_tp_session *t, const void *embeds_dev, int n, void *last_logits_dev, void *all_logits_dev, void *stream) {
     if (!t || !embeds_dev || n <= 0) return vlo_fail(VLO_E_INVALID, "bad tp_llm_step arguments");
     vlo_engine *e0 = t->g->eng[0];
+    {
+        const vlo_tp_group *g = t->g;
+        if (g->tp_size > 1 && g->eng.size() == 1 && !g->comm && !g->p2p.enabled)
+            return vlo_fail(VLO_E_STATE, "one-process-per-GPU group without an exchange: pass the RCCL unique id to vlo_tp_group_create or call vlo_tp_p2p_enable");
+        if (g->p2p.enabled && *(volatile unsigned *)g->p2p.err_host)
+            return vlo_fail(VLO_E_HIP, "p2p exchange timed out waiting for a peer rank (ranks out of step, or a peer's writes are not visible here); "
+                                       "results since then are invalid");
+    }
     TP_TRY(hipSetDevice(e0->device));
     hipStream_t st = (hipStream_t)stream;
     const int H = e0->cfg.hidden_size, V = e0->cfg.vocab_size;

@@ -321,16 +321,28 @@ class TpGroup:
     * ``TpGroup(cfg, tp_size, device=local_rank, rank=r, unique_id=bytes)``: one process per GPU; exchanges are RCCL
       all-reduce / all-gather.  ``unique_id`` comes from ``TpGroup.unique_id()`` on rank 0, broadcast by the caller
       (e.g. ``torch.distributed.broadcast_object_list``).
+    * ``allreduce="p2p"`` (either mode): the exchanges are the one-shot peer-to-peer all-reduce over xGMI fused with the
+      residual add + RMSNorm (include/vlo.h `vlo_tp_p2p_*`) instead of RCCL calls / sum kernels.  One process per GPU:
+      pass ``handle_allgather`` — a callable taking this rank's 64-byte mailbox handle and returning every rank's, in
+      rank order (e.g. built on ``torch.distributed.all_gather_object``); no RCCL unique id is needed then.
     Weights are given in FULL; every rank slices its shard.  ViT, connector and embeddings are replicated."""
 
-    def __init__(self, cfg: EngineConfig, tp_size: int, device: int = 0, rank: int | None = None, unique_id: bytes | None = None):
+    def __init__(self, cfg: EngineConfig, tp_size: int, device: int = 0, rank: int | None = None, unique_id: bytes | None = None,
+                 allreduce: str = "default", handle_allgather=None):
         from dataclasses import replace
         self.cfg = cfg
         self.tp_size = tp_size
         ranks = list(range(tp_size)) if rank is None else [rank]
         self._uid = unique_id
-        if rank is not None and tp_size > 1 and unique_id is None:
-            raise ValueError("one-process-per-GPU TP needs the RCCL unique id")
+        if allreduce not in ("default", "rccl", "p2p"):
+            raise ValueError(f"allreduce must be 'default', 'rccl' or 'p2p', not {allreduce!r}")
+        self.allreduce = "p2p" if allreduce == "p2p" else ("rccl" if rank is not None else "kernel")
+        self._handle_allgather = handle_allgather
+        if rank is not None and tp_size > 1:
+            if self.allreduce == "p2p" and handle_allgather is None:
+                raise ValueError("one-process-per-GPU p2p TP needs handle_allgather (mailbox handles of all ranks)")
+            if self.allreduce == "rccl" and unique_id is None:
+                raise ValueError("one-process-per-GPU TP needs the RCCL unique id")
         self.engines = [Engine(replace(cfg, tp_rank=r, tp_size=tp_size, vit=cfg.vit if i == 0 else None), device)
                         for i, r in enumerate(ranks)]
         self.device = self.engines[0].device
@@ -361,7 +373,23 @@ class TpGroup:
         uid = C.create_string_buffer(self._uid, 128) if self._uid is not None else None
         _C.check(_C.lib().vlo_tp_group_create(arr, len(self.engines), uid, C.byref(g)))
         self._g = g
+        if self.allreduce == "p2p" and self.tp_size > 1:
+            if len(self.engines) == self.tp_size:          # logical ranks of one process: mailboxes are local allocations
+                _C.check(_C.lib().vlo_tp_p2p_enable(g, None))
+            else:
+                mine = C.create_string_buffer(64)
+                _C.check(_C.lib().vlo_tp_p2p_export(g, mine))
+                handles = list(self._handle_allgather(mine.raw))
+                if len(handles) != self.tp_size or any(len(h) != 64 for h in handles):
+                    raise ValueError("handle_allgather must return tp_size handles of 64 bytes, in rank order")
+                _C.check(_C.lib().vlo_tp_p2p_enable(g, C.create_string_buffer(b"".join(handles), 64 * self.tp_size)))
         return self
+
+    def p2p_status(self) -> dict:
+        """{enabled, timed_out, uncached_mailbox} of the peer-to-peer exchange (all 0 when it is not in use)."""
+        en, to, uc = C.c_int(0), C.c_int(0), C.c_int(0)
+        _C.check(_C.lib().vlo_tp_p2p_status(self._g, C.byref(en), C.byref(to), C.byref(uc)))
+        return dict(enabled=en.value, timed_out=to.value, uncached_mailbox=uc.value)
 
     @property
     def weight_bytes(self) -> int:
