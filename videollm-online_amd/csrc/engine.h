@@ -22,6 +22,7 @@ struct PackedLinear {
     void *Wp = nullptr;
     int N = 0, K = 0, NT = 0;
     GemvPlan plan{};
+    GemvPlan plan_whole{};    // same image, K never split across blocks (epilogues that need final sums); == plan when it has ksplit 1
     Gemm64Plan plan64{};      // the 64-token block path over the same packed image (prefill.hip)
 };
 
@@ -75,6 +76,7 @@ struct vlo_session {
     vlo_engine *e = nullptr;
     int64_t len = 0;
     bool has_logits = false;
+    int fused_rows = 0;                          // chunks of <= this many rows take run_chunk_fused (VLO_FUSED_ROWS at creation; 0 = off)
     std::vector<int> pages;
     std::vector<void *> owned;
     unsigned short *h = nullptr, *x = nullptr, *act = nullptr, *attn = nullptr, *q = nullptr, *emb1 = nullptr;

@@ -192,6 +192,7 @@ static int make_linear(vlo_engine *e, PackedLinear *pl, int N, int K, bool allow
     pl->K = K;
     pl->NT = (N + 15) / 16;
     if (gemv_plan(K, allow_ksplit, &pl->plan)) return fail(VLO_E_UNSUPPORTED, "no GEMV plan for K=" + std::to_string(K));
+    if (gemv_plan(K, false, &pl->plan_whole)) return fail(VLO_E_UNSUPPORTED, "no whole-K GEMV plan for K=" + std::to_string(K));
     if (gemm64_plan(K, &pl->plan64)) return fail(VLO_E_UNSUPPORTED, "no block-GEMM plan for K=" + std::to_string(K));
     const size_t bytes = (size_t)pl->NT * 16 * K * 2;
     int rc = dev_alloc(&pl->Wp, bytes);
@@ -404,6 +405,7 @@ int vlo_session_create(vlo_engine *e, int64_t max_tokens_hint, vlo_session **out
         return fail(VLO_E_HIP, "hipHostMalloc failed");
     }
     s->last_logits = s->logits;
+    if (const char *v = getenv("VLO_FUSED_ROWS")) s->fused_rows = std::max(0, std::min(16, atoi(v)));
     HIP_TRY(hipDeviceSynchronize());
     *out = s;
     return VLO_OK;
@@ -553,6 +555,76 @@ GemvArgs gemv_args(const PackedLinear &pl, const unsigned short *x, int ldx, int
     return a;
 }
 
+// Opt-in variant of run_chunk for SHORT chunks (m <= session.fused_rows, VLO_FUSED_ROWS; meant for the n = 1 decode steps),
+// 6 launches per decoder layer and no separate norm kernel at all:
+//   qkv GEMV      [input RMSNorm on the operand load | RoPE + paged KV append]         -> q, K, V^T
+//   attention, combine                                                                 -> attn
+//   o GEMV        [residual add + row sum-of-squares]                                  -> h, sq
+//   gate/up GEMV  [post-attention RMSNorm on the operand load | SwiGLU]                -> act
+//   down GEMV     [WHOLE K per block | residual add + row sum-of-squares]              -> h, sq
+// and the final RMSNorm rides on the lm_head operand load.  Whole-K down-proj re-reads the activation rows once per
+// column tile (m * I * 2 bytes from L2 per block): +10 us per layer at m = 11, which is why run_chunk splits K there and
+// pays an add_rmsnorm launch instead — but nothing at m = 1.  Same rounding points as run_chunk; the fp32 summation
+// order inside the down-proj dot products differs (K chunks walked by one wave vs K slices added by add_rmsnorm).
+static int run_chunk_fused(vlo_session *s, const unsigned short *src, int m, bool want_last, bool want_all, hipStream_t st) {
+    vlo_engine *e = s->e;
+    const vlo_config &c = e->cfg;
+    const int H = c.hidden_size, I = c.intermediate_size, hd = e->head_dim, nh = c.num_heads;
+    int rc;
+    if ((rc = ensure_pages(s, s->len + m, st))) return rc;
+    const KvGeom kv = kv_geom(s);
+    HIP_TRY(prep_rows_launch(src, s->h, s->sq[1], m, H, st));       // h = embeddings, sq[1][0][row] = their sums of squares
+    const float *sq_in = s->sq[1];
+    int sq_parts = 1;
+    for (int l = 0; l < c.num_layers; ++l) {
+        const LayerWeights &L = e->layers[l];
+        {   // qkv, input RMSNorm on load
+            GemvArgs a = gemv_args(L.qkv, s->h, H, m);
+            a.norm_w = (const unsigned short *)L.ln_in; a.sq_in = sq_in; a.sq_in_parts = sq_parts; a.eps = c.rms_eps;
+            a.out_bf16 = s->q; a.cos_tab = (const unsigned short *)e->cos_tab; a.sin_tab = (const unsigned short *)e->sin_tab;
+            a.kv = kv; a.layer = l; a.num_heads = nh; a.pos0 = s->len;
+            HIP_TRY(gemv_launch(a, L.qkv.plan, XSRC_NORM, EPI_ROPE, st));
+        }
+        HIP_TRY(attention_launch(s->q, kv, l, nh, s->len, m, s->part_o, s->part_ml, s->attn, st));
+        {   // o_proj + residual
+            GemvArgs a = gemv_args(L.o, s->attn, nh * hd, m);
+            a.h = s->h; a.ldo = H; a.sq_out = s->sq[0];
+            sq_parts = gemv_grid_x(a, L.o.plan, EPI_RESID);
+            HIP_TRY(gemv_launch(a, L.o.plan, XSRC_PLAIN, EPI_RESID, st));
+            sq_in = s->sq[0];
+        }
+        {   // gate/up + SwiGLU, post-attention RMSNorm on load
+            hipEvent_t ev0 = nullptr, ev1 = nullptr;
+            if (e->prof_stride > 0 && (e->prof_seen++ % e->prof_stride) == 0) prof_acquire(e, &ev0, &ev1);
+            GemvArgs a = gemv_args(L.gate_up, s->h, H, m);
+            a.norm_w = (const unsigned short *)L.ln_post; a.sq_in = sq_in; a.sq_in_parts = sq_parts; a.eps = c.rms_eps;
+            a.out_bf16 = s->act; a.ldo = I;
+            if (ev0) hipEventRecord(ev0, st);
+            HIP_TRY(gemv_launch(a, L.gate_up.plan, XSRC_NORM, EPI_SWIGLU, st));
+            if (ev1) hipEventRecord(ev1, st);
+        }
+        {   // down_proj (whole K) + residual
+            GemvArgs a = gemv_args(L.down, s->act, I, m);
+            a.h = s->h; a.ldo = H; a.sq_out = s->sq[1];
+            sq_parts = gemv_grid_x(a, L.down.plan_whole, EPI_RESID);
+            HIP_TRY(gemv_launch(a, L.down.plan_whole, XSRC_PLAIN, EPI_RESID, st));
+            sq_in = s->sq[1];
+        }
+    }
+    if (want_last || want_all) {
+        // final RMSNorm on the lm_head operand load; only the rows that are read (row r0 of h / of the sq partials = row 0 here)
+        const int r0 = want_all ? 0 : m - 1, nr = want_all ? m : 1;
+        GemvArgs a = gemv_args(e->lm_head, s->h + (size_t)r0 * H, H, nr);
+        a.norm_w = (const unsigned short *)e->norm_w; a.sq_in = sq_in + r0; a.sq_in_parts = sq_parts; a.eps = c.rms_eps;
+        a.out_bf16 = s->logits; a.ldo = c.vocab_size;
+        HIP_TRY(gemv_launch(a, e->lm_head.plan, XSRC_NORM, EPI_BF16, st));
+        s->last_logits = s->logits + (size_t)(nr - 1) * c.vocab_size;
+        s->has_logits = true;
+    }
+    s->len += m;
+    return VLO_OK;
+}
+
 // one chunk of m <= 16 new tokens whose embeddings are at `src`.  Per decoder layer (7 launches):
 //   add_rmsnorm   [+ down-proj split-K combine + residual of the previous layer]      -> x
 //   qkv GEMV      [RoPE + paged KV append in the epilogue]                             -> q, K, V^T
@@ -562,6 +634,7 @@ GemvArgs gemv_args(const PackedLinear &pl, const unsigned short *x, int ldx, int
 //   down GEMV     [K split over blocks, fp32 partials]                                 -> partial
 static int run_chunk(vlo_session *s, const unsigned short *src, int m, bool want_last, bool want_all, hipStream_t st) {
     static const bool fuse_norm = getenv("VLO_FUSE_NORM") ? atoi(getenv("VLO_FUSE_NORM")) != 0 : true;
+    if (m <= s->fused_rows) return run_chunk_fused(s, src, m, want_last, want_all, st);
     vlo_engine *e = s->e;
     const vlo_config &c = e->cfg;
     const int H = c.hidden_size, I = c.intermediate_size, hd = e->head_dim, nh = c.num_heads;
