@@ -497,8 +497,10 @@ static void p2p_release(vlo_tp_group *g) {
     P.allocated = P.enabled = false;
 }
 
-// mailboxes of the local ranks: uncached device memory (no cache level may serve a poll), zeroed so that no tag matches
-static int p2p_allocate(vlo_tp_group *g) {
+// mailboxes of the local ranks: uncached (first choice) or fine-grained device memory — no cache level may serve a poll
+// with stale data while a peer GPU writes the line — zeroed so that no tag matches.  `first_kind` = 0: try uncached, then
+// fine-grained; 1: fine-grained only (the export path retries with it when hipIpc refuses an uncached allocation).
+static int p2p_allocate(vlo_tp_group *g, int first_kind = 0) {
     P2PState &P = g->p2p;
     if (P.allocated) return VLO_OK;
     const vlo_engine *e0 = g->eng[0];
@@ -511,17 +513,20 @@ static int p2p_allocate(vlo_tp_group *g) {
     P.granules = p2p_total_granules(T, P.H, P.Vh);
     if (const char *v = getenv("VLO_TP_P2P_TIMEOUT_MS")) P.timeout_ticks = (long long)atoll(v) * 100000ll;
     if (const char *v = getenv("VLO_TP_P2P_FUSED")) P.fused = atoi(v) != 0;
-    if (hipHostMalloc((void **)&P.err_host, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess)
-        return vlo_fail(VLO_E_HIP, "p2p exchange: hipHostMalloc of the error word failed");
-    *P.err_host = 0u;
-    P.uncached = true;
+    if (!P.err_host) {
+        if (hipHostMalloc((void **)&P.err_host, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess)
+            return vlo_fail(VLO_E_HIP, "p2p exchange: hipHostMalloc of the error word failed");
+        *P.err_host = 0u;
+    }
+    P.uncached = first_kind == 0;
     for (size_t i = 0; i < g->eng.size(); ++i) {
         TP_TRY(hipSetDevice(g->eng[i]->device));
         void *m = nullptr;
         const size_t bytes = P.granules * 8;
-        if (hipExtMallocWithFlags(&m, bytes, hipDeviceMallocUncached) != hipSuccess) {
-            (void)hipGetLastError();
+        if (!P.uncached || hipExtMallocWithFlags(&m, bytes, hipDeviceMallocUncached) != hipSuccess) {
+            if (P.uncached) (void)hipGetLastError();
             P.uncached = false;
+            m = nullptr;
             if (hipExtMallocWithFlags(&m, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
                 (void)hipGetLastError();
                 p2p_release(g);
@@ -545,14 +550,23 @@ static int p2p_allocate(vlo_tp_group *g) {
 int vlo_tp_p2p_export(vlo_tp_group *g, void *out_handle64) {
     if (!g || !out_handle64) return vlo_fail(VLO_E_INVALID, "bad tp_p2p_export arguments");
     if (g->eng.size() != 1) return vlo_fail(VLO_E_STATE, "tp_p2p_export is for one-process-per-GPU groups (single-process groups need no handles)");
-    int rc = p2p_allocate(g);
-    if (rc) return rc;
-    TP_TRY(hipSetDevice(g->eng[0]->device));
+    if (g->p2p.enabled) return vlo_fail(VLO_E_STATE, "the p2p exchange is already enabled");
     hipIpcMemHandle_t h;
-    TP_TRY(hipIpcGetMemHandle(&h, g->p2p.mbox[0]));
     static_assert(sizeof(h) == 64, "hipIpcMemHandle_t is 64 bytes");
-    memcpy(out_handle64, &h, sizeof(h));
-    return VLO_OK;
+    for (int kind = 0; kind < 2; ++kind) {          // uncached first; fine-grained if hipIpc refuses that allocation
+        int rc = p2p_allocate(g, kind);
+        if (rc) return rc;
+        TP_TRY(hipSetDevice(g->eng[0]->device));
+        const hipError_t he = hipIpcGetMemHandle(&h, g->p2p.mbox[0]);
+        if (he == hipSuccess) {
+            memcpy(out_handle64, &h, sizeof(h));
+            return VLO_OK;
+        }
+        (void)hipGetLastError();
+        if (kind == 1 || !g->p2p.uncached) return vlo_fail(VLO_E_HIP, std::string("hipIpcGetMemHandle(mailbox): ") + hipGetErrorString(he));
+        p2p_release(g);
+    }
+    return vlo_fail(VLO_E_HIP, "hipIpcGetMemHandle(mailbox) failed");
 }
 
 int vlo_tp_p2p_enable(vlo_tp_group *g, const void *handles) {
