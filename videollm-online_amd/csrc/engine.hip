@@ -991,17 +991,39 @@ int vlo_session_crop(vlo_session *s, int64_t n_tokens) {
     return VLO_OK;
 }
 
+// device scratch of the test / micro-benchmark entry points: freed on every return path
+struct ScratchBufs {
+    std::vector<void *> ptrs;
+    std::vector<hipEvent_t> events;
+    ~ScratchBufs() {
+        for (void *p : ptrs) hipFree(p);
+        for (hipEvent_t e : events) hipEventDestroy(e);
+    }
+    hipError_t alloc(void **p, size_t bytes) {
+        const hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+        if (e == hipSuccess) ptrs.push_back(*p);
+        return e;
+    }
+    hipError_t event(hipEvent_t *ev) {
+        const hipError_t e = hipEventCreate(ev);
+        if (e == hipSuccess) events.push_back(*ev);
+        return e;
+    }
+};
+
 int vlo_test_gemv(const void *x_dev, const void *W_dev, float *y_dev, int n, int N, int K, void *stream) {
     if (!x_dev || !W_dev || !y_dev || n <= 0 || n > 16 || N <= 0 || (N & 3)) return fail(VLO_E_INVALID, "bad test_gemv arguments");
     hipStream_t st = (hipStream_t)stream;
     GemvPlan plan;
     if (gemv_plan(K, true, &plan)) return fail(VLO_E_UNSUPPORTED, "no GEMV plan for K");
     const int NT = (N + 15) / 16;
+    ScratchBufs sc;
     void *Wp = nullptr, *xp = nullptr;
-    float *P = nullptr;
-    HIP_TRY(hipMalloc(&Wp, (size_t)NT * 16 * K * 2));
-    HIP_TRY(hipMalloc(&xp, (size_t)32 * K * 2));
-    HIP_TRY(hipMalloc((void **)&P, (size_t)plan.ksplit * 16 * NT * 16 * 4));
+    float *P = nullptr, *Y = nullptr;
+    HIP_TRY(sc.alloc(&Wp, (size_t)NT * 16 * K * 2));
+    HIP_TRY(sc.alloc(&xp, (size_t)32 * K * 2));
+    HIP_TRY(sc.alloc((void **)&P, (size_t)plan.ksplit * 16 * NT * 16 * 4));
+    HIP_TRY(sc.alloc((void **)&Y, (size_t)16 * NT * 16 * 4));
     HIP_TRY(hipMemsetAsync(xp, 0, (size_t)32 * K * 2, st));
     HIP_TRY(hipMemcpyAsync(xp, x_dev, (size_t)n * K * 2, hipMemcpyDeviceToDevice, st));
     HIP_TRY(pack_weight_launch(W_dev, Wp, N, K, K, NT, 1, 0, -1, st));
@@ -1009,20 +1031,11 @@ int vlo_test_gemv(const void *x_dev, const void *W_dev, float *y_dev, int n, int
     a.Wp = Wp; a.x = (const unsigned short *)xp; a.out_f32 = P;
     a.K = K; a.ldx = K; a.ldo = NT * 16; a.NT = NT; a.N_valid = N; a.n_rows = n;
     HIP_TRY(gemv_launch(a, plan, XSRC_PLAIN, EPI_PARTIAL_F32, st));
-    // partial layout is [ksplit][16][ldo]; y is [n][N]
-    {
-        // sum into a padded buffer then copy rows (ldo may exceed N)
-        float *Y = nullptr;
-        HIP_TRY(hipMalloc((void **)&Y, (size_t)16 * NT * 16 * 4));
-        hipLaunchKernelGGL(sum_partials_kernel, dim3((n * NT * 16 + 255) / 256), dim3(256), 0, st, P, plan.ksplit, NT * 16, Y, n, NT * 16);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpy2DAsync(y_dev, (size_t)N * 4, Y, (size_t)NT * 16 * 4, (size_t)N * 4, n, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        hipFree(Y);
-    }
-    hipFree(Wp);
-    hipFree(xp);
-    hipFree(P);
+    // partial layout is [ksplit][16][ldo]; y is [n][N]: sum into a padded buffer, then copy the rows (ldo may exceed N)
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((n * NT * 16 + 255) / 256), dim3(256), 0, st, P, plan.ksplit, NT * 16, Y, n, NT * 16);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy2DAsync(y_dev, (size_t)N * 4, Y, (size_t)NT * 16 * 4, (size_t)N * 4, n, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));      // the scratch is freed when `sc` goes out of scope
     return VLO_OK;
 }
 
@@ -1032,28 +1045,29 @@ int vlo_bench_gemv(int N, int K, int n_rows, int epi, int iters, int nbuf, doubl
     if (gemv_plan(K, epi == EPI_PARTIAL_F32, &plan)) return fail(VLO_E_UNSUPPORTED, "no GEMV plan for K");
     const int NT = (N + 15) / 16;
     const size_t wbytes = (size_t)NT * 16 * K * 2;
+    ScratchBufs sc;
     std::vector<void *> Wp(nbuf, nullptr);
     void *x = nullptr, *o32 = nullptr, *o16 = nullptr, *hbuf = nullptr, *sq = nullptr, *nw = nullptr, *tab = nullptr, *kvp = nullptr;
     int *pt = nullptr;
     for (int i = 0; i < nbuf; ++i) {
-        HIP_TRY(hipMalloc(&Wp[i], wbytes));
+        HIP_TRY(sc.alloc(&Wp[i], wbytes));
         HIP_TRY(hipMemset(Wp[i], 0x3c, wbytes));      // 0x3c3c = a small finite bf16
     }
     const size_t wide = (size_t)std::max(K, NT * 16);
-    HIP_TRY(hipMalloc(&x, 32 * wide * 2));
+    HIP_TRY(sc.alloc(&x, 32 * wide * 2));
     HIP_TRY(hipMemset(x, 0x3c, 32 * wide * 2));
-    HIP_TRY(hipMalloc(&hbuf, 32 * wide * 2));
+    HIP_TRY(sc.alloc(&hbuf, 32 * wide * 2));
     HIP_TRY(hipMemset(hbuf, 0x3c, 32 * wide * 2));
-    HIP_TRY(hipMalloc(&nw, wide * 2));
+    HIP_TRY(sc.alloc(&nw, wide * 2));
     HIP_TRY(hipMemset(nw, 0x3c, wide * 2));
-    HIP_TRY(hipMalloc(&sq, 1024 * 16 * 4));
+    HIP_TRY(sc.alloc(&sq, 1024 * 16 * 4));
     HIP_TRY(hipMemset(sq, 0, 1024 * 16 * 4));
-    HIP_TRY(hipMalloc(&o32, (size_t)plan.ksplit * 16 * NT * 16 * 4));
-    HIP_TRY(hipMalloc(&o16, (size_t)16 * NT * 16 * 2));
-    HIP_TRY(hipMalloc(&tab, (size_t)VLO_PAGE_TOKENS * 64 * 2));
+    HIP_TRY(sc.alloc(&o32, (size_t)plan.ksplit * 16 * NT * 16 * 4));
+    HIP_TRY(sc.alloc(&o16, (size_t)16 * NT * 16 * 2));
+    HIP_TRY(sc.alloc(&tab, (size_t)VLO_PAGE_TOKENS * 64 * 2));
     HIP_TRY(hipMemset(tab, 0x3c, (size_t)VLO_PAGE_TOKENS * 64 * 2));
-    HIP_TRY(hipMalloc(&kvp, (size_t)NT * 16 * VLO_PAGE_TOKENS * 2));
-    HIP_TRY(hipMalloc((void **)&pt, 64));
+    HIP_TRY(sc.alloc(&kvp, (size_t)NT * 16 * VLO_PAGE_TOKENS * 2));
+    HIP_TRY(sc.alloc((void **)&pt, 64));
     HIP_TRY(hipMemset(pt, 0, 64));
     GemvArgs a{};
     a.x = (const unsigned short *)x; a.out_f32 = (float *)o32; a.out_bf16 = (unsigned short *)o16;
@@ -1073,8 +1087,8 @@ int vlo_bench_gemv(int N, int K, int n_rows, int epi, int iters, int nbuf, doubl
         a.layer = 0; a.num_heads = nh; a.pos0 = 0;
     }
     hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(sc.event(&e0));
+    HIP_TRY(sc.event(&e1));
     for (int i = 0; i < 3; ++i) { a.Wp = Wp[i % nbuf]; HIP_TRY(gemv_launch(a, plan, xsrc, epi, 0)); }
     HIP_TRY(hipEventRecord(e0, 0));
     for (int i = 0; i < iters; ++i) { a.Wp = Wp[i % nbuf]; HIP_TRY(gemv_launch(a, plan, xsrc, epi, 0)); }
@@ -1083,10 +1097,7 @@ int vlo_bench_gemv(int N, int K, int n_rows, int epi, int iters, int nbuf, doubl
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     *avg_us = (double)ms * 1e3 / iters;
-    for (void *p : Wp) hipFree(p);
-    hipFree(x); hipFree(o32); hipFree(o16); hipFree(hbuf); hipFree(sq); hipFree(nw); hipFree(tab); hipFree(kvp); hipFree(pt);
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    return VLO_OK;
+    return VLO_OK;                         // `sc` frees the scratch and the events
 }
 
 int vlo_debug_read(vlo_session *s, int which, void *dst_dev, int64_t bytes, void *stream) {
