@@ -719,6 +719,7 @@ static int vit_reserve(vlo_engine *e, VitState *v, int B) {
     v->graphs.clear();
     for (void *p : v->ws) hipFree(p);
     v->ws.clear();
+    v->Bcap = 0;                 // nothing usable until every buffer below exists (a failed allocation must not leave stale pointers live)
     const size_t M = (size_t)B * v->S, D = v->D, I = v->I;
     int rc = 0;
     auto A = [&](void **p, size_t bytes) {
@@ -852,7 +853,10 @@ int vit_visual_embed(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_
         VIT_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
         rc = vit_run(e, v->frames_in, B, v->out_stage, st);
         hipError_t ce = hipStreamEndCapture(st, &graph);
-        if (rc) return rc;
+        if (rc) {
+            if (graph) hipGraphDestroy(graph);
+            return rc;
+        }
         VIT_TRY(ce);
         VIT_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
         hipGraphDestroy(graph);
