@@ -1,0 +1,59 @@
+"""Builds tests/hip_emul/_build/libvlo_emul.so: the engine's LLM-path SOURCES (csrc/{gemv,prefill,llm_ops,engine,tp}.hip)
+compiled as host C++ against the HIP-on-threads shim (hip_emul.h).  Test infrastructure only — the product is libvlo.so."""
+import os
+import re
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "videollm-online_amd", "csrc")
+OUT = os.path.join(HERE, "_build")
+SOURCES = ["gemv.hip", "prefill.hip", "llm_ops.hip", "engine.hip", "tp.hip"]
+
+
+def clang():
+    for c in ("/opt/rocm/lib/llvm/bin/clang++", shutil.which("clang++")):
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+def build(force=False):
+    cc = clang()
+    if cc is None:
+        return None
+    os.makedirs(OUT, exist_ok=True)
+    lib = os.path.join(OUT, "libvlo_emul.so")
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, f) for f in ("hip_emul.h", "emul_stubs.cpp", "build_emul.py")]
+    if not force and os.path.exists(lib) and all(os.path.getmtime(d) <= os.path.getmtime(lib) for d in deps):
+        return lib
+    objs, procs = [], []
+    flags = ["-x", "c++", "-std=c++17", "-O1", "-g0", "-fPIC", "-pthread", "-Wno-unused-value", "-Wno-unknown-attributes",
+             "-I", HERE, "-I", CSRC]
+    for s in SOURCES:
+        src = open(os.path.join(CSRC, s)).read()
+        # dynamic shared memory: `extern __shared__ T name[]` refers to an array the harness defines (emul_stubs.cpp)
+        src = re.sub(r"extern\s+__shared__", "extern", src)
+        patched = os.path.join(OUT, s.replace(".hip", "_emul.cpp"))
+        with open(patched, "w") as f:
+            f.write(f'#line 1 "{os.path.join(CSRC, s)}"\n' + src)
+        obj = patched.replace(".cpp", ".o")
+        objs.append(obj)
+        procs.append((s, subprocess.Popen([cc] + flags + ["-c", patched, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    stub_o = os.path.join(OUT, "emul_stubs.o")
+    objs.append(stub_o)
+    procs.append(("emul_stubs.cpp", subprocess.Popen([cc] + flags + ["-c", os.path.join(HERE, "emul_stubs.cpp"), "-o", stub_o],
+                                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"emulated build failed on {s}:\n{out[-6000:]}")
+    r = subprocess.run([cc, "-shared", "-fPIC", "-pthread"] + objs + ["-ldl", "-o", lib], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"emulated link failed:\n{r.stdout[-4000:]}")
+    return lib
+
+
+if __name__ == "__main__":
+    print(build(force=True))

@@ -1,0 +1,153 @@
+"""Drives tests/hip_emul/_build/libvlo_emul.so — the engine's SOURCES compiled for the CPU (build_emul.py) — through the
+same C ABI as the product (include/vlo.h, argument types from videollm_online_amd/_C.py::bind).  "Device" pointers are
+host pointers of torch CPU tensors.  Test infrastructure only: the product's Engine refuses to run without a GPU."""
+import ctypes as C
+
+import torch
+
+from videollm_online_amd import _C
+
+from . import build_emul
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = build_emul.build()
+        if path is None:
+            return None
+        _LIB = _C.bind(C.CDLL(path))      # RTLD_LOCAL: never mixes with libvlo.so's symbols
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(f"libvlo_emul error {rc}: {lib().vlo_last_error().decode()}")
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+_DT = {torch.float32: _C.DT_F32, torch.bfloat16: _C.DT_BF16, torch.float16: _C.DT_F16}
+
+
+class EmulEngine:
+    def __init__(self, spec, kv_pool_tokens=1024, tp_rank=0, tp_size=1):
+        self.spec = spec
+        c = _C.VloConfig()
+        c.abi_version = _C.VLO_ABI_VERSION
+        c.hidden_size, c.intermediate_size, c.num_layers = spec.hidden_size, spec.intermediate_size, spec.num_layers
+        c.num_heads, c.num_kv_heads, c.vocab_size = spec.num_heads, spec.num_kv_heads, spec.vocab_size
+        c.rope_theta, c.rms_eps = spec.rope_theta, spec.rms_eps
+        c.vision_hidden_size, c.frame_num_tokens, c.pool_h, c.pool_w = spec.vision_hidden_size, 10, 3, 3
+        c.kv_pool_tokens, c.tp_rank, c.tp_size = kv_pool_tokens, tp_rank, tp_size
+        h = C.c_void_p()
+        check(lib().vlo_engine_create(C.byref(c), 0, C.byref(h)))
+        self._h = h
+        self.sessions = []
+
+    def load_weights(self, weights, inv_freq=None):
+        for name, t in weights.items():
+            if name.startswith("vision."):
+                continue
+            t = t.detach().contiguous()
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            check(lib().vlo_engine_load_weight(self._h, name.encode(), _ptr(t), _DT[t.dtype], shape, t.dim()))
+        if inv_freq is not None:
+            t = inv_freq.float().contiguous()
+            check(lib().vlo_engine_load_weight(self._h, b"rope.inv_freq", _ptr(t), _C.DT_F32, (C.c_int64 * 1)(t.numel()), 1))
+        check(lib().vlo_engine_finalize(self._h))
+        return self
+
+    def new_session(self):
+        h = C.c_void_p()
+        check(lib().vlo_session_create(self._h, 0, C.byref(h)))
+        self.sessions.append(h)
+        return h
+
+    def session_len(self, s):
+        return int(lib().vlo_session_len(s))
+
+    def llm_step(self, s, embeds, want_all=True):
+        x = embeds.to(torch.bfloat16).contiguous().view(-1, self.spec.hidden_size)
+        n, V = x.shape[0], self.spec.vocab_size
+        last = torch.zeros(V, dtype=torch.bfloat16)
+        allr = torch.zeros(n, V, dtype=torch.bfloat16) if want_all else None
+        check(lib().vlo_llm_step(s, _ptr(x), n, _ptr(last), _ptr(allr) if want_all else None, None))
+        return last, allr
+
+    def embed(self, ids):
+        ids = ids.to(torch.long).contiguous().view(-1)
+        out = torch.zeros(ids.numel(), self.spec.hidden_size, dtype=torch.bfloat16)
+        check(lib().vlo_embed(self._h, _ptr(ids), ids.numel(), _ptr(out), None))
+        return out
+
+    def stream_sample(self, s, threshold, interval_id):
+        tok, p = torch.zeros(1, dtype=torch.long), torch.zeros(1, dtype=torch.float32)
+        check(lib().vlo_stream_sample(s, threshold, interval_id, _ptr(tok), _ptr(p), None))
+        return int(tok), float(p)
+
+    def greedy_generate(self, s, embeds, eos, max_new, force_len=0):
+        x = embeds.to(torch.bfloat16).contiguous().view(-1, self.spec.hidden_size)
+        ids = torch.zeros(max_new, dtype=torch.long)
+        n = C.c_int(0)
+        check(lib().vlo_greedy_generate(s, _ptr(x), x.shape[0], eos, _ptr(ids), max_new, force_len, C.byref(n), None))
+        return ids[:n.value].tolist()
+
+    def close(self):
+        for s in self.sessions:
+            lib().vlo_session_destroy(s)
+        self.sessions = []
+        if self._h:
+            lib().vlo_engine_destroy(self._h)
+            self._h = None
+
+
+class EmulTpGroup:
+    """T logical ranks in one process (the single-process mode of include/vlo.h vlo_tp_*)."""
+
+    def __init__(self, spec, T, weights, inv_freq, p2p=False, kv_pool_tokens=1024):
+        self.spec, self.T = spec, T
+        self.engines = [EmulEngine(spec, kv_pool_tokens, r, T).load_weights(weights, inv_freq) for r in range(T)]
+        arr = (C.c_void_p * T)(*[e._h for e in self.engines])
+        g = C.c_void_p()
+        check(lib().vlo_tp_group_create(arr, T, None, C.byref(g)))
+        self._g = g
+        if p2p:
+            check(lib().vlo_tp_p2p_enable(g, None))
+        self.sessions = []
+
+    def p2p_status(self):
+        en, to, uc = C.c_int(0), C.c_int(0), C.c_int(0)
+        check(lib().vlo_tp_p2p_status(self._g, C.byref(en), C.byref(to), C.byref(uc)))
+        return dict(enabled=en.value, timed_out=to.value, uncached_mailbox=uc.value)
+
+    def new_session(self):
+        h = C.c_void_p()
+        check(lib().vlo_tp_session_create(self._g, 0, C.byref(h)))
+        self.sessions.append(h)
+        return h
+
+    def session_len(self, s):
+        return int(lib().vlo_tp_session_len(s))
+
+    def llm_step(self, s, embeds, want_all=True):
+        x = embeds.to(torch.bfloat16).contiguous().view(-1, self.spec.hidden_size)
+        n, V = x.shape[0], self.spec.vocab_size
+        last = torch.zeros(V, dtype=torch.bfloat16)
+        allr = torch.zeros(n, V, dtype=torch.bfloat16) if want_all else None
+        check(lib().vlo_tp_llm_step(s, _ptr(x), n, _ptr(last), _ptr(allr) if want_all else None, None))
+        return last, allr
+
+    def close(self):
+        for s in self.sessions:
+            lib().vlo_tp_session_destroy(s)
+        self.sessions = []
+        if self._g:
+            lib().vlo_tp_group_destroy(self._g)
+            self._g = None
+        for e in self.engines:
+            e.close()

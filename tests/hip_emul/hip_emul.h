@@ -1,0 +1,213 @@
+// hip_emul.h — HIP-on-threads shim (TEST INFRASTRUCTURE ONLY; never built into, shipped with or imported by the product).
+//
+// Resolved instead of <hip/hip_runtime.h> when a source is compiled with `-x c++ -I tests/hip_emul`: the SOURCE of the
+// engine's kernels and of its host code then becomes a plain host program, so that index arithmetic, epilogue wiring,
+// flag / tag protocols, launch sequencing and rounding points can be exercised in the `-m "not gpu"` suite at toy sizes:
+//   * a kernel launch runs its blocks ONE AT A TIME, every thread of a block is an OS thread;
+//   * `__shared__` is a plain static (static shared memory) — `extern __shared__` arrays are defined by the harness;
+//   * `__syncthreads()` is a barrier over the block, wave shuffles and the 16x16x32 MFMA exchange their operands through a
+//     per-wave buffer between two wave barriers (so they must be called wave-uniformly, as on the hardware);
+//   * device memory is host memory, streams and events do nothing, every call is synchronous.
+// What it cannot show: anything about the GPU memory model (scopes, caches, cross-device visibility), the order in which
+// the matrix core adds its 32 products (fp32, sequential here), timing, occupancy or register pressure.
+#pragma once
+#define VLO_HIP_EMUL 1
+#include <math.h>
+#include <pthread.h>
+#include <sched.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <functional>
+#include <thread>
+#include <vector>
+
+// ---- language ---------------------------------------------------------------------------------------------------------
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+#define address_space(x)                 // __attribute__((address_space(1))) -> no attribute on the host
+
+struct emul_dim3 {
+    unsigned x = 1, y = 1, z = 1;
+    emul_dim3() {}
+    emul_dim3(unsigned a, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+typedef emul_dim3 dim3;
+struct uint2 { unsigned x, y; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(8) ushort4 { unsigned short x, y, z, w; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { return {x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return {x, y, z, w}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
+
+struct emul_wave_ctx {
+    pthread_barrier_t bar;
+    unsigned slot[64];                   // shuffles
+    float A[16 * 32], B[32 * 16];        // MFMA operands
+};
+struct emul_block_ctx {
+    pthread_barrier_t block_bar;
+    std::vector<emul_wave_ctx> waves;
+};
+static thread_local emul_dim3 threadIdx, blockIdx, blockDim, gridDim;
+static thread_local emul_block_ctx *emul_ctx = nullptr;
+
+static inline void __syncthreads() { pthread_barrier_wait(&emul_ctx->block_bar); }
+
+template <class T>
+static inline T emul_shfl_from(T v, int src_lane_of_me /* computed from my lane */) {
+    static_assert(sizeof(T) == 4, "32-bit shuffles only");
+    emul_wave_ctx &W = emul_ctx->waves[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    memcpy(&W.slot[lane], &v, 4);
+    pthread_barrier_wait(&W.bar);
+    T r;
+    memcpy(&r, &W.slot[src_lane_of_me], 4);
+    pthread_barrier_wait(&W.bar);
+    return r;
+}
+template <class T> static inline T __shfl_xor(T v, int lane_mask, int /*width*/ = 64) { return emul_shfl_from(v, (int)((threadIdx.x & 63) ^ lane_mask)); }
+template <class T> static inline T __shfl_up(T v, unsigned delta, int /*width*/ = 64) {
+    const int lane = threadIdx.x & 63;
+    return emul_shfl_from(v, lane >= (int)delta ? lane - (int)delta : lane);
+}
+template <class T> static inline T __shfl(T v, int src, int /*width*/ = 64) { return emul_shfl_from(v, src & 63); }
+
+// v_mfma_f32_16x16x32_{bf16,f16}: D[16x16] = A[16x32] . B[32x16] + C, register maps of csrc/common.cuh:
+//   A[m][k]: lane l holds m = l & 15, k = (l >> 4) * 8 + j      B[k][n]: lane l holds n = l & 15, k = (l >> 4) * 8 + j
+//   D[m][n]: lane l holds n = l & 15, m = (l >> 4) * 4 + r
+template <class V8, class V4>
+static inline V4 emul_mfma_16x16x32(V8 a, V8 b, V4 c) {
+    emul_wave_ctx &W = emul_ctx->waves[threadIdx.x >> 6];
+    const int l = threadIdx.x & 63, i = l & 15, kb = (l >> 4) * 8;
+    for (int j = 0; j < 8; ++j) {
+        W.A[i * 32 + kb + j] = (float)a[j];
+        W.B[(kb + j) * 16 + i] = (float)b[j];
+    }
+    pthread_barrier_wait(&W.bar);
+    V4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int m = (l >> 4) * 4 + r;
+        float s = c[r];
+        for (int k = 0; k < 32; ++k) s += W.A[m * 32 + k] * W.B[k * 16 + i];
+        d[r] = s;
+    }
+    pthread_barrier_wait(&W.bar);
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emul_mfma_16x16x32((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) emul_mfma_16x16x32((a), (b), (c))
+
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+#define __expf(x) expf(x)                // glibc declares __expf but does not export it
+static inline long long wall_clock64() {      // s_memrealtime: a 100 MHz counter
+    return (long long)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10);
+}
+
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
+#define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or((p), (v), (order))
+#define __builtin_amdgcn_s_sleep(x) sched_yield()
+#define __builtin_nontemporal_load(p) (*(p))
+
+// ---- kernel launches --------------------------------------------------------------------------------------------------
+// `body` = the kernel call with its arguments bound.  blockDim.x OS threads are created per launch and walk the blocks of
+// the grid together, one block at a time (static shared memory is a process-wide static).
+static inline void emul_launch(emul_dim3 grid, emul_dim3 block, const std::function<void()> &body) {
+    const unsigned nt = block.x * block.y * block.z, nw = (nt + 63) / 64;
+    if (nt == 0 || grid.x * grid.y * grid.z == 0) return;
+    emul_block_ctx ctx;
+    pthread_barrier_t end_bar;
+    pthread_barrier_init(&ctx.block_bar, nullptr, nt);
+    pthread_barrier_init(&end_bar, nullptr, nt);
+    ctx.waves = std::vector<emul_wave_ctx>(nw);
+    for (unsigned w = 0; w < nw; ++w) pthread_barrier_init(&ctx.waves[w].bar, nullptr, (w + 1) * 64 <= nt ? 64 : nt - w * 64);
+    std::vector<std::thread> ts;
+    ts.reserve(nt);
+    for (unsigned t = 0; t < nt; ++t)
+        ts.emplace_back([&, t]() {
+            threadIdx = emul_dim3(t);            // 1-D blocks only (all of this tree's kernels)
+            blockDim = block;
+            gridDim = grid;
+            emul_ctx = &ctx;
+            for (unsigned bz = 0; bz < grid.z; ++bz)
+                for (unsigned by = 0; by < grid.y; ++by)
+                    for (unsigned bx = 0; bx < grid.x; ++bx) {
+                        blockIdx = emul_dim3(bx, by, bz);
+                        body();
+                        pthread_barrier_wait(&end_bar);      // the block is over: its shared memory may be reused
+                    }
+        });
+    for (auto &th : ts) th.join();
+    pthread_barrier_destroy(&ctx.block_bar);
+    pthread_barrier_destroy(&end_bar);
+    for (auto &w : ctx.waves) pthread_barrier_destroy(&w.bar);
+}
+#define hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, ...) \
+    emul_launch(emul_dim3(grid), emul_dim3(block), [=]() { kernel(__VA_ARGS__); })
+
+// ---- runtime API (device memory = host memory, one "device", everything synchronous) -------------------------------------
+typedef enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotSupported = 801 } hipError_t;
+typedef void *hipStream_t;
+typedef struct emul_event { std::chrono::steady_clock::time_point t; } *hipEvent_t;
+typedef enum { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 } hipMemcpyKind;
+typedef struct { char reserved[64]; } hipIpcMemHandle_t;
+#define hipHostMallocDefault 0x0
+#define hipHostMallocPortable 0x1
+#define hipHostMallocMapped 0x2
+#define hipDeviceMallocFinegrained 0x1
+#define hipDeviceMallocUncached 0x3
+#define hipIpcMemLazyEnablePeerAccess 0x1
+typedef enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 } hipFuncAttribute;
+
+static inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "emulated HIP runtime error"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipDeviceCanAccessPeer(int *can, int, int) { *can = 0; return hipSuccess; }
+static inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
+static inline hipError_t hipMalloc(void **p, size_t bytes) {
+    *p = aligned_alloc(256, (bytes + 255) / 256 * 256 + 256);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+static inline hipError_t hipExtMallocWithFlags(void **p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }
+static inline hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }
+static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpy2DAsync(void *d, size_t dpitch, const void *s, size_t spitch, size_t width, size_t height, hipMemcpyKind,
+                                          hipStream_t) {
+    for (size_t r = 0; r < height; ++r) memmove((char *)d + r * dpitch, (const char *)s + r * spitch, width);
+    return hipSuccess;
+}
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new emul_event(); return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return hipSuccess;
+}
+static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
+static inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t *, void *) { return hipErrorNotSupported; }
+static inline hipError_t hipIpcOpenMemHandle(void **, hipIpcMemHandle_t, unsigned) { return hipErrorNotSupported; }
+static inline hipError_t hipIpcCloseMemHandle(void *) { return hipSuccess; }

@@ -53,7 +53,13 @@ def lib():
             raise RuntimeError(f"{LIB_PATH} not found and could not be built ({ex}).  Build it with "
                                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950).  "
                                "The engine has no non-HIP path.") from ex
-    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    L = bind(C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL))
+    _lib = L
+    return L
+
+
+def bind(L):
+    """Declare the argument / return types of every include/vlo.h entry point on a loaded library and check its ABI version."""
     vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
     L.vlo_abi_version.restype = i32
     L.vlo_last_error.restype = C.c_char_p
@@ -114,7 +120,6 @@ def lib():
     L.vlo_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     if L.vlo_abi_version() != VLO_ABI_VERSION:
         raise RuntimeError("libvlo.so ABI version mismatch — rebuild")
-    _lib = L
     return L
 
 
