@@ -2,6 +2,7 @@
 same C ABI as the product (include/vlo.h, argument types from videollm_online_amd/_C.py::bind).  "Device" pointers are
 host pointers of torch CPU tensors.  Test infrastructure only: the product's Engine refuses to run without a GPU."""
 import ctypes as C
+import os
 
 import torch
 
@@ -18,7 +19,8 @@ def lib():
         path = build_emul.build()
         if path is None:
             return None
-        _LIB = _C.bind(C.CDLL(path))      # RTLD_LOCAL: never mixes with libvlo.so's symbols
+        # private symbol scope: never mixes with libvlo.so (same symbol names) when both are loaded in one process
+        _LIB = _C.bind(C.CDLL(path, mode=os.RTLD_LOCAL | getattr(os, "RTLD_DEEPBIND", 0)))
     return _LIB
 
 

@@ -34,11 +34,12 @@ def emul():
     out_dir = os.path.join(EMUL, "_build")
     os.makedirs(out_dir, exist_ok=True)
     lib = os.path.join(out_dir, "libp2p_emul.so")
-    cmd = [cc, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-DXCHG_THREADS=64", "-I", EMUL,
+    # -Bsymbolic: libvlo.so (RTLD_GLOBAL, loaded by other tests of the session) exports host stubs with the kernels' names
+    cmd = [cc, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-Wl,-Bsymbolic", "-DXCHG_THREADS=64", "-I", EMUL,
            "-I", os.path.join(ROOT, "videollm-online_amd", "csrc"), os.path.join(EMUL, "p2p_harness.cpp"), "-o", lib]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
-    L = C.CDLL(lib)
+    L = C.CDLL(lib, mode=os.RTLD_LOCAL | getattr(os, "RTLD_DEEPBIND", 0))
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
     L.emul_p2p_exchange.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, u64, u64, C.c_uint32, C.c_float, C.c_longlong, i32, vp]
     L.emul_p2p_gather.argtypes = [i32, i32, i32, vp, vp, vp, u64, u64, C.c_uint32, C.c_longlong, i32, vp]
