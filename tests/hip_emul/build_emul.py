@@ -51,7 +51,7 @@ def build(force=False):
             raise RuntimeError(f"emulated build failed on {s}:\n{out[-6000:]}")
     # -Bsymbolic: the library binds its internal references to ITSELF even when libvlo.so (same symbol names, RTLD_GLOBAL)
     # is already loaded in the process
-    r = subprocess.run([cc, "-shared", "-fPIC", "-pthread", "-Wl,-Bsymbolic"] + objs + ["-ldl", "-o", lib], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    r = subprocess.run([cc, "-shared", "-fPIC", "-pthread", "-Wl,-Bsymbolic"] + objs + ["-ldl", "-lrt", "-o", lib], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"emulated link failed:\n{r.stdout[-4000:]}")
     return lib

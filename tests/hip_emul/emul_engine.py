@@ -99,6 +99,32 @@ class EmulEngine:
         check(lib().vlo_greedy_generate(s, _ptr(x), x.shape[0], eos, _ptr(ids), max_new, force_len, C.byref(n), None))
         return ids[:n.value].tolist()
 
+    def fork(self, s, n_tokens):
+        h = C.c_void_p()
+        check(lib().vlo_session_fork(s, n_tokens, C.byref(h), None))
+        self.sessions.append(h)
+        return h
+
+    def crop(self, s, n_tokens):
+        check(lib().vlo_session_crop(s, n_tokens))
+
+    def joint_embed(self, ids, frame_rows, v_id):
+        ids = ids.to(torch.long).contiguous().view(-1)
+        rows = frame_rows.to(torch.bfloat16).contiguous().view(-1, self.spec.hidden_size)
+        out = torch.zeros(ids.numel(), self.spec.hidden_size, dtype=torch.bfloat16)
+        check(lib().vlo_joint_embed(self._h, _ptr(ids), ids.numel(), v_id, _ptr(rows), rows.shape[0], _ptr(out), None))
+        return out
+
+    def logit_rows(self, logits, labels, interval_id):
+        logits = logits.contiguous()
+        n = logits.shape[0]
+        labels = labels.to(torch.long).contiguous()
+        o = dict(lse=torch.zeros(n), argmax=torch.zeros(n, dtype=torch.long), label_logit=torch.zeros(n), p_interval=torch.zeros(n),
+                 p_argmax=torch.zeros(n, dtype=torch.long))
+        check(lib().vlo_logit_rows(self._h, _ptr(logits), n, _ptr(labels), interval_id, _ptr(o["lse"]), _ptr(o["argmax"]),
+                                   _ptr(o["label_logit"]), _ptr(o["p_interval"]), _ptr(o["p_argmax"]), None))
+        return o
+
     def close(self):
         for s in self.sessions:
             lib().vlo_session_destroy(s)
@@ -153,3 +179,33 @@ class EmulTpGroup:
             self._g = None
         for e in self.engines:
             e.close()
+
+
+class EmulTpRank:
+    """ONE rank of a one-process-per-GPU group (include/vlo.h: n_local = 1) with the peer-to-peer exchange and no RCCL.
+    ``exchange`` takes this rank's 64-byte mailbox handle and returns every rank's, in rank order."""
+
+    def __init__(self, spec, T, rank, weights, inv_freq, exchange, kv_pool_tokens=1024):
+        self.spec, self.T, self.rank = spec, T, rank
+        self.engine = EmulEngine(spec, kv_pool_tokens, rank, T).load_weights(weights, inv_freq)
+        arr = (C.c_void_p * 1)(self.engine._h)
+        g = C.c_void_p()
+        check(lib().vlo_tp_group_create(arr, 1, None, C.byref(g)))
+        self._g = g
+        mine = C.create_string_buffer(64)
+        check(lib().vlo_tp_p2p_export(g, mine))
+        handles = exchange(mine.raw)
+        check(lib().vlo_tp_p2p_enable(g, C.create_string_buffer(b"".join(handles), 64 * T)))
+        h = C.c_void_p()
+        check(lib().vlo_tp_session_create(g, 0, C.byref(h)))
+        self._s = h
+
+    p2p_status = EmulTpGroup.p2p_status
+
+    def llm_step(self, embeds, want_all=True):
+        return EmulTpGroup.llm_step(self, self._s, embeds, want_all)
+
+    def close(self):
+        lib().vlo_tp_session_destroy(self._s)
+        lib().vlo_tp_group_destroy(self._g)
+        self.engine.close()

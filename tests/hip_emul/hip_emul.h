@@ -19,8 +19,18 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <fcntl.h>
+#include <stdio.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
 #include <chrono>
 #include <functional>
+#include <map>
+#include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -183,9 +193,41 @@ static inline hipError_t hipMalloc(void **p, size_t bytes) {
     *p = aligned_alloc(256, (bytes + 255) / 256 * 256 + 256);
     return *p ? hipSuccess : hipErrorOutOfMemory;
 }
-static inline hipError_t hipExtMallocWithFlags(void **p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }
+// Uncached / fine-grained allocations (the p2p mailboxes) live in POSIX shared memory so that hipIpc can be emulated
+// ACROSS PROCESSES: the "handle" is the shm object's name.
+struct emul_shm_entry { std::string name; size_t bytes; bool owner; };
+inline std::map<void *, emul_shm_entry> emul_shm_registry;
+inline std::mutex emul_shm_mu;
+static inline hipError_t hipExtMallocWithFlags(void **p, size_t bytes, unsigned) {
+    static std::atomic<int> counter{0};
+    char name[64];
+    snprintf(name, sizeof(name), "/vlo_emul_%d_%d", (int)getpid(), counter++);
+    const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0) return hipErrorOutOfMemory;
+    if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); shm_unlink(name); return hipErrorOutOfMemory; }
+    void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { shm_unlink(name); return hipErrorOutOfMemory; }
+    std::lock_guard<std::mutex> g(emul_shm_mu);
+    emul_shm_registry[m] = {name, bytes, true};
+    *p = m;
+    return hipSuccess;
+}
 static inline hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }
-static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipFree(void *p) {
+    {
+        std::lock_guard<std::mutex> g(emul_shm_mu);
+        auto it = emul_shm_registry.find(p);
+        if (it != emul_shm_registry.end()) {
+            munmap(p, it->second.bytes);
+            if (it->second.owner) shm_unlink(it->second.name.c_str());
+            emul_shm_registry.erase(it);
+            return hipSuccess;
+        }
+    }
+    free(p);
+    return hipSuccess;
+}
 static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
@@ -208,6 +250,28 @@ static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t
     return hipSuccess;
 }
 static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
-static inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t *, void *) { return hipErrorNotSupported; }
-static inline hipError_t hipIpcOpenMemHandle(void **, hipIpcMemHandle_t, unsigned) { return hipErrorNotSupported; }
-static inline hipError_t hipIpcCloseMemHandle(void *) { return hipSuccess; }
+static inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t *h, void *p) {
+    std::lock_guard<std::mutex> g(emul_shm_mu);
+    auto it = emul_shm_registry.find(p);
+    if (it == emul_shm_registry.end() || it->second.name.size() >= sizeof(h->reserved)) return hipErrorInvalidValue;
+    memset(h->reserved, 0, sizeof(h->reserved));
+    memcpy(h->reserved, it->second.name.c_str(), it->second.name.size());
+    return hipSuccess;
+}
+static inline hipError_t hipIpcOpenMemHandle(void **p, hipIpcMemHandle_t h, unsigned) {
+    char name[65];
+    memcpy(name, h.reserved, 64);
+    name[64] = 0;
+    const int fd = shm_open(name, O_RDWR, 0600);
+    if (fd < 0) return hipErrorInvalidValue;
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return hipErrorInvalidValue; }
+    void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return hipErrorInvalidValue;
+    std::lock_guard<std::mutex> g(emul_shm_mu);
+    emul_shm_registry[m] = {name, (size_t)st.st_size, false};
+    *p = m;
+    return hipSuccess;
+}
+static inline hipError_t hipIpcCloseMemHandle(void *p) { return hipFree(p); }

@@ -125,3 +125,111 @@ def test_tensor_parallel_logical_ranks(E, p2p):
     if p2p:
         assert grp.p2p_status()["timed_out"] == 0
     grp.close()
+
+
+def _rank_worker(rank, T, conns, q, lens):
+    """one emulated 'GPU process': its own copy of the emulated library (statics, thread pool), mailboxes in POSIX shm"""
+    os.environ["VLO_TP_P2P_TIMEOUT_MS"] = "900000"       # emulated ranks take seconds per step: waiting is not a failure here
+    from tests.hip_emul import emul_engine as E
+    spec = TINY
+    w = O.init_llm_weights(spec, seed=6)
+    toks = O.default_tokens(spec)
+    ref = O.LlamaOracle(spec, w, torch.bfloat16)
+
+    def exchange(mine):                                  # all-gather of the handles over pipes, rank order
+        for c in conns:
+            c.send((rank, mine))
+        got = dict([(rank, mine)] + [c.recv() for c in conns])
+        return [got[r] for r in range(T)]
+
+    r = E.EmulTpRank(spec, T, rank, w, O.rope_inv_freq(spec.head_dim, spec.rope_theta), exchange)
+    outs = [r.llm_step(x)[1].float().numpy() for x in _steps(spec, ref, toks, 3, lens)]
+    q.put((rank, outs, r.p2p_status()))
+    r.close()
+
+
+def test_p2p_between_processes(E):
+    """One process per rank, as on a multi-GPU node: mailbox export / open (hipIpc emulated over POSIX shared memory), the
+    FUSED publish + collect kernel running concurrently in both ranks, a group without any RCCL communicator."""
+    import torch.multiprocessing as mp
+    T = 2
+    lens = [11, 1] + ([19] if FULL else [])
+    ctx = mp.get_context("spawn")
+    a, b = ctx.Pipe()
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_rank_worker, args=(0, T, [a], q, lens)), ctx.Process(target=_rank_worker, args=(1, T, [b], q, lens))]
+    [p.start() for p in ps]
+    res = {}
+    for _ in range(T):
+        rank, outs, st = q.get(timeout=900)
+        res[rank] = (outs, st)
+    [p.join(120) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    spec = TINY
+    w = O.init_llm_weights(spec, seed=6)
+    toks = O.default_tokens(spec)
+    ref, gold = O.LlamaOracle(spec, w, torch.bfloat16), O.LlamaOracle(spec, w, torch.float32)
+    rc = gc = None
+    for i, x in enumerate(_steps(spec, ref, toks, 3, lens)):
+        rl, rc = ref.forward(x, rc)
+        gl, gc = gold.forward(x, gc)
+        o0, o1 = torch.from_numpy(res[0][0][i]), torch.from_numpy(res[1][0][i])
+        assert torch.equal(o0, o1), "both ranks must hold the same logits (same sum order on every rank)"
+        _three_way("tiny tp2 p2p, 2 processes", i, o0, rl, gl)
+    assert all(res[r][1]["enabled"] == 1 and res[r][1]["timed_out"] == 0 for r in range(T))
+
+
+@pytest.mark.skipif(not FULL, reason="longer emulation cases: VLO_EMUL_FULL=1")
+def test_block_path_generation_and_evaluation_surface(E):
+    """The 64-token block path (run_block / gemm64_kernel) for a 40-token first step, greedy generation, the streaming
+    sampler, KV fork / crop, joint_embed and the per-row logit statistics of stream_evaluate."""
+    spec = TINY
+    w = O.init_llm_weights(spec, seed=9)
+    toks = O.default_tokens(spec, n_start=30)
+    ref, gold = O.LlamaOracle(spec, w, torch.bfloat16), O.LlamaOracle(spec, w, torch.float32)
+    eng = E.EmulEngine(spec).load_weights(w, O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+    s = eng.new_session()
+    g = torch.Generator().manual_seed(4)
+    frame = torch.randn(10, spec.hidden_size, generator=g).bfloat16()
+    # joint_embed == embedding rows with the placeholder rows replaced, in order
+    v_id = spec.vocab_size
+    ids = torch.tensor(toks.start_ids + [v_id] * 10)
+    x = eng.joint_embed(ids, frame, v_id)
+    assert torch.equal(x, torch.cat([ref.embed(torch.tensor(toks.start_ids)), frame]))
+    assert torch.equal(eng.embed(torch.tensor(toks.start_ids)), ref.embed(torch.tensor(toks.start_ids)))
+    rl, rc = ref.forward(x, None)
+    gl, gc = gold.forward(x, None)
+    last, allr = eng.llm_step(s, x)                                     # 40 rows: one 64-token block
+    assert eng.session_len(s) == 40 and torch.equal(last, allr[-1])
+    _three_way("tiny block path", 0, allr, rl, gl)
+    # per-row statistics of the teacher-forced logits vs torch on the SAME logits
+    labels = torch.randint(0, spec.vocab_size, (40,), generator=g)
+    st = eng.logit_rows(allr, labels, toks.interval_id)
+    lf = allr.float()
+    assert torch.allclose(st["lse"], torch.logsumexp(lf, -1), atol=2e-3)
+    assert torch.equal(st["argmax"], lf.argmax(-1))
+    assert torch.equal(st["label_logit"], lf.gather(1, labels[:, None])[:, 0])
+    sm = allr.softmax(-1)                                               # bf16 softmax, as the reference computes it
+    assert torch.allclose(st["p_interval"], sm[:, toks.interval_id].float(), atol=4e-3)
+    # KV fork keeps a prefix, crop forgets a suffix; both continue exactly like the oracle's cache of that length
+    f = eng.fork(s, 35)
+    assert eng.session_len(f) == 35 and eng.session_len(s) == 40
+    x2 = ref.embed(torch.tensor([17, 23, 5]))
+
+    def prefix(cache, n):                                               # what trim_past_key_values(past, 0, n) keeps
+        c = O.KVCacheOracle(spec.num_layers)
+        c.k, c.v = [k[:, :n] for k in cache.k], [v[:, :n] for v in cache.v]
+        return c
+
+    rl_f, _ = ref.forward(x2, prefix(rc, 35))
+    gl_f, _ = gold.forward(x2, prefix(gc, 35))
+    lf2, af2 = eng.llm_step(f, x2)
+    eng.crop(s, 35)
+    ls2, as2 = eng.llm_step(s, x2)
+    assert torch.equal(af2, as2), "a forked prefix and a cropped session of the same length must continue identically"
+    _three_way("tiny fork(35)", 1, af2, rl_f, gl_f)
+    # greedy generation through the C loop (forced length: random weights never emit EOS on their own schedule)
+    out = eng.greedy_generate(s, ref.embed(torch.tensor(toks.stream_generation_ids)), toks.eos_token_id, 6, force_len=4)
+    assert len(out) == 4 and out[-1] == toks.eos_token_id and toks.eos_token_id not in out[:-1]
+    assert eng.session_len(s) == 38 + len(toks.stream_generation_ids) + 3
+    eng.close()
