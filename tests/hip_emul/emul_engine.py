@@ -36,6 +36,20 @@ def _ptr(t):
 _DT = {torch.float32: _C.DT_F32, torch.bfloat16: _C.DT_BF16, torch.float16: _C.DT_F16}
 
 
+def test_gemv(x, W):
+    """y[n,N] f32 = x[n,K] @ W[N,K]^T through the packed MFMA GEMV of the emulated library (include/vlo.h vlo_test_gemv)."""
+    x, W = x.to(torch.bfloat16).contiguous(), W.to(torch.bfloat16).contiguous()
+    y = torch.zeros(x.shape[0], W.shape[0], dtype=torch.float32)
+    check(lib().vlo_test_gemv(_ptr(x), _ptr(W), _ptr(y), x.shape[0], W.shape[0], W.shape[1], None))
+    return y
+
+
+def gemv_plan(K, allow_ksplit):
+    out = (C.c_int * 4)()
+    check(lib().vlo_debug_gemv_plan(K, int(allow_ksplit), out))
+    return tuple(out)
+
+
 class EmulEngine:
     def __init__(self, spec, kv_pool_tokens=1024, tp_rank=0, tp_size=1):
         self.spec = spec

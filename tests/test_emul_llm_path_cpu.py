@@ -233,3 +233,16 @@ def test_block_path_generation_and_evaluation_surface(E):
     assert len(out) == 4 and out[-1] == toks.eos_token_id and toks.eos_token_id not in out[:-1]
     assert eng.session_len(s) == 38 + len(toks.stream_generation_ids) + 3
     eng.close()
+
+
+@pytest.mark.parametrize("K,N,n,plan", [(1792, 48, 11, (4, 14, 1, 1)), (704, 32, 3, (2, 11, 1, 1)), (512, 64, 16, (8, 2, 1, 1))])
+def test_gemv_plans_in_emulation(E, K, N, n, plan):
+    """The weight-streaming GEMV on reduction lengths whose (waves, fragments) combination is rare: K = 1792 is the
+    Llama-3-8B down-proj shard at TP = 8 (4 waves x 14 fragments, one K slice)."""
+    assert E.gemv_plan(K, True) == plan
+    g = torch.Generator().manual_seed(K)
+    x = torch.randn(n, K, generator=g).bfloat16()
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16()
+    y = E.test_gemv(x, W)
+    want = x.float() @ W.float().T
+    assert torch.allclose(y, want, rtol=1e-4, atol=1e-4), (y - want).abs().max()

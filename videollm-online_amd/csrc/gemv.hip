@@ -353,16 +353,21 @@ int gemv_plan(int K, bool allow_ksplit, GemvPlan *p) {
     if (K <= 0 || (K & 31)) return -1;
     const int KFtot = K >> 5;
     const int force_ks = allow_ksplit ? env_int("VLO_GEMV_KSPLIT", 0) : 0;
+    // the combination that keeps the most weight bytes in flight per CU (NW x KF KiB) wins, earlier entries on ties: every
+    // model shape gets the same plan as a first-match walk of the list except K = 1792 (Llama-3-8B down-proj at TP = 8),
+    // which would otherwise stream with 1 KiB per wave and seven K slices instead of 4 waves x 14 KiB and one
+    const NwKf *best = nullptr;
     for (const NwKf &c : kCombos) {
         if (KFtot % (c.nw * c.kf)) continue;
-        const int rest = KFtot / (c.nw * c.kf);       // = KC * ksplit
-        if (rest > 16) continue;
-        int ks = allow_ksplit ? rest : 1;            // K slices across blocks (fp32 partial outputs) vs chunks inside a wave
-        if (allow_ksplit && force_ks > 0 && rest % force_ks == 0) ks = force_ks;
-        p->NW = c.nw; p->KF = c.kf; p->ksplit = ks; p->KC = rest / ks;
-        return 0;
+        if (KFtot / (c.nw * c.kf) > 16) continue;
+        if (!best || c.nw * c.kf > best->nw * best->kf) best = &c;
     }
-    return -1;
+    if (!best) return -1;
+    const int rest = KFtot / (best->nw * best->kf);   // = KC * ksplit
+    int ks = allow_ksplit ? rest : 1;                // K slices across blocks (fp32 partial outputs) vs chunks inside a wave
+    if (allow_ksplit && force_ks > 0 && rest % force_ks == 0) ks = force_ks;
+    p->NW = best->nw; p->KF = best->kf; p->ksplit = ks; p->KC = rest / ks;
+    return 0;
 }
 
 // groups of two column tiles, or single tiles when that balances better over the CUs (pairs are mandatory for the
