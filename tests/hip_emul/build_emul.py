@@ -19,10 +19,16 @@ def clang():
     return None
 
 
-def build(force=False):
+def build(force=False, sanitize=None):
+    """sanitize: None, or a -fsanitize= list such as "address,undefined" / "thread" (VLO_EMUL_SANITIZE): the kernels' index
+    arithmetic and their use of shared memory then run under the sanitizer (LD_PRELOAD its runtime for python)."""
     cc = clang()
     if cc is None:
         return None
+    sanitize = sanitize or os.environ.get("VLO_EMUL_SANITIZE") or None
+    global OUT
+    if sanitize:
+        OUT = os.path.join(HERE, "_build", "san_" + sanitize.replace(",", "_"))
     os.makedirs(OUT, exist_ok=True)
     lib = os.path.join(OUT, "libvlo_emul.so")
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, f) for f in ("hip_emul.h", "emul_stubs.cpp", "build_emul.py")]
@@ -31,6 +37,8 @@ def build(force=False):
     objs, procs = [], []
     flags = ["-x", "c++", "-std=c++17", "-O1", "-g0", "-fPIC", "-pthread", "-Wno-unused-value", "-Wno-unknown-attributes",
              "-I", HERE, "-I", CSRC]
+    san = ["-fsanitize=" + sanitize, "-fno-omit-frame-pointer", "-g"] if sanitize else []
+    flags = [f for f in flags if not (san and f == "-g0")] + san
     for s in SOURCES:
         src = open(os.path.join(CSRC, s)).read()
         # dynamic shared memory: `extern __shared__ T name[]` refers to an array the harness defines (emul_stubs.cpp)
@@ -51,7 +59,7 @@ def build(force=False):
             raise RuntimeError(f"emulated build failed on {s}:\n{out[-6000:]}")
     # -Bsymbolic: the library binds its internal references to ITSELF even when libvlo.so (same symbol names, RTLD_GLOBAL)
     # is already loaded in the process
-    r = subprocess.run([cc, "-shared", "-fPIC", "-pthread", "-Wl,-Bsymbolic"] + objs + ["-ldl", "-lrt", "-o", lib], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    r = subprocess.run([cc, "-shared", "-fPIC", "-pthread", "-Wl,-Bsymbolic"] + san + objs + ["-ldl", "-lrt", "-o", lib], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"emulated link failed:\n{r.stdout[-4000:]}")
     return lib

@@ -19,8 +19,8 @@ def lib():
         path = build_emul.build()
         if path is None:
             return None
-        # private symbol scope: never mixes with libvlo.so (same symbol names) when both are loaded in one process
-        _LIB = _C.bind(C.CDLL(path, mode=os.RTLD_LOCAL | getattr(os, "RTLD_DEEPBIND", 0)))
+        # built with -Bsymbolic: never binds to libvlo.so (same symbol names) when both are loaded in one process
+        _LIB = _C.bind(C.CDLL(path, mode=os.RTLD_LOCAL))
     return _LIB
 
 

@@ -39,7 +39,7 @@ def emul():
            "-I", os.path.join(ROOT, "videollm-online_amd", "csrc"), os.path.join(EMUL, "p2p_harness.cpp"), "-o", lib]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
-    L = C.CDLL(lib, mode=os.RTLD_LOCAL | getattr(os, "RTLD_DEEPBIND", 0))
+    L = C.CDLL(lib, mode=os.RTLD_LOCAL)
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
     L.emul_p2p_exchange.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, u64, u64, C.c_uint32, C.c_float, C.c_longlong, i32, vp]
     L.emul_p2p_gather.argtypes = [i32, i32, i32, vp, vp, vp, u64, u64, C.c_uint32, C.c_longlong, i32, vp]
