@@ -1,5 +1,5 @@
-"""Builds tests/hip_emul/_build/libvlo_emul.so: the engine's LLM-path SOURCES (csrc/{gemv,prefill,llm_ops,engine,tp}.hip)
-compiled as host C++ against the HIP-on-threads shim (hip_emul.h).  Test infrastructure only — the product is libvlo.so."""
+"""Builds tests/hip_emul/_build/libvlo_emul.so: the engine's SOURCES (csrc/{gemv,prefill,llm_ops,vit,engine,tp}.hip)
+compiled as host C++ against the HIP-on-threads shim (hip_emul.h); csrc/vit.hip as well.  Test infrastructure only — the product is libvlo.so."""
 import os
 import re
 import shutil
@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "videollm-online_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
-SOURCES = ["gemv.hip", "prefill.hip", "llm_ops.hip", "engine.hip", "tp.hip"]
+SOURCES = ["gemv.hip", "prefill.hip", "llm_ops.hip", "vit.hip", "engine.hip", "tp.hip"]
 
 
 def clang():
@@ -43,6 +43,8 @@ def build(force=False, sanitize=None):
         src = open(os.path.join(CSRC, s)).read()
         # dynamic shared memory: `extern __shared__ T name[]` refers to an array the harness defines (emul_stubs.cpp)
         src = re.sub(r"extern\s+__shared__", "extern", src)
+        # GPU assembly (explicit s_waitcnt around direct-to-LDS loads): the emulated loads are synchronous
+        src = re.sub(r'asm volatile\("s_waitcnt[^"]*"\s*:::\s*"memory"\);', ";", src)
         patched = os.path.join(OUT, s.replace(".hip", "_emul.cpp"))
         with open(patched, "w") as f:
             f.write(f'#line 1 "{os.path.join(CSRC, s)}"\n' + src)

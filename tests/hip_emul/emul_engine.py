@@ -51,14 +51,21 @@ def gemv_plan(K, allow_ksplit):
 
 
 class EmulEngine:
-    def __init__(self, spec, kv_pool_tokens=1024, tp_rank=0, tp_size=1):
-        self.spec = spec
+    def __init__(self, spec, kv_pool_tokens=1024, tp_rank=0, tp_size=1, vit=None):
+        self.spec, self.vit = spec, vit
         c = _C.VloConfig()
+        if vit is not None:
+            c.has_vit = 1
+            c.vit_hidden_size, c.vit_intermediate_size = vit.hidden_size, vit.intermediate_size
+            c.vit_num_layers, c.vit_num_heads = vit.num_layers, vit.num_heads
+            c.vit_image_size, c.vit_patch_size, c.vit_ln_eps = vit.image_size, vit.patch_size, vit.ln_eps
         c.abi_version = _C.VLO_ABI_VERSION
         c.hidden_size, c.intermediate_size, c.num_layers = spec.hidden_size, spec.intermediate_size, spec.num_layers
         c.num_heads, c.num_kv_heads, c.vocab_size = spec.num_heads, spec.num_kv_heads, spec.vocab_size
         c.rope_theta, c.rms_eps = spec.rope_theta, spec.rms_eps
         c.vision_hidden_size, c.frame_num_tokens, c.pool_h, c.pool_w = spec.vision_hidden_size, 10, 3, 3
+        if vit is not None:
+            c.frame_num_tokens, (c.pool_h, c.pool_w) = vit.frame_num_tokens, vit.pooled
         c.kv_pool_tokens, c.tp_rank, c.tp_size = kv_pool_tokens, tp_rank, tp_size
         h = C.c_void_p()
         check(lib().vlo_engine_create(C.byref(c), 0, C.byref(h)))
@@ -67,7 +74,7 @@ class EmulEngine:
 
     def load_weights(self, weights, inv_freq=None):
         for name, t in weights.items():
-            if name.startswith("vision."):
+            if name.startswith("vision.") and self.vit is None:
                 continue
             t = t.detach().contiguous()
             shape = (C.c_int64 * t.dim())(*t.shape)
@@ -112,6 +119,19 @@ class EmulEngine:
         n = C.c_int(0)
         check(lib().vlo_greedy_generate(s, _ptr(x), x.shape[0], eos, _ptr(ids), max_new, force_len, C.byref(n), None))
         return ids[:n.value].tolist()
+
+    def visual_embed(self, frames_u8, stream=None):
+        """uint8 [B,3,R,R] -> bf16 [B * frame_num_tokens, H]; stream = a non-null fake handle takes the captured-graph path"""
+        f = frames_u8.contiguous()
+        out = torch.zeros(f.shape[0] * self.vit.frame_num_tokens, self.spec.hidden_size, dtype=torch.bfloat16)
+        check(lib().vlo_visual_embed(self._h, _ptr(f), f.shape[0], _ptr(out), stream))
+        return out
+
+    def vision_tokens(self, frames_u8):
+        f = frames_u8.contiguous()
+        out = torch.zeros(f.shape[0], self.vit.frame_num_tokens, self.vit.hidden_size, dtype=torch.bfloat16)
+        check(lib().vlo_vision_tokens(self._h, _ptr(f), f.shape[0], _ptr(out), None))
+        return out
 
     def fork(self, s, n_tokens):
         h = C.c_void_p()

@@ -129,13 +129,34 @@ static inline long long wall_clock64() {      // s_memrealtime: a 100 MHz counte
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
 #define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or((p), (v), (order))
+static inline float atomicAdd(float *p, float v) {          // relaxed fp32 atomic add (CAS loop)
+    unsigned *u = reinterpret_cast<unsigned *>(p), old = __atomic_load_n(u, __ATOMIC_RELAXED);
+    for (;;) {
+        const unsigned want = __float_as_uint(__uint_as_float(old) + v);
+        if (__atomic_compare_exchange_n(u, &old, want, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return __uint_as_float(old);
+    }
+}
+static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 #define __builtin_amdgcn_s_sleep(x) sched_yield()
 #define __builtin_nontemporal_load(p) (*(p))
+
+// direct-to-LDS load: every lane's `size` bytes land at the wave-uniform LDS base + lane * size
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) memcpy((char *)(l) + (threadIdx.x & 63) * (size), (const void *)(g), (size))
+
+// ---- stream capture / graphs: launches and copies issued while the host thread captures are recorded, a graph launch replays them
+struct emul_graph { std::vector<std::function<void()>> ops; };
+typedef emul_graph *hipGraph_t;
+typedef emul_graph *hipGraphExec_t;
+inline thread_local emul_graph *emul_capturing = nullptr;
 
 // ---- kernel launches --------------------------------------------------------------------------------------------------
 // `body` = the kernel call with its arguments bound.  blockDim.x OS threads are created per launch and walk the blocks of
 // the grid together, one block at a time (static shared memory is a process-wide static).
 static inline void emul_launch(emul_dim3 grid, emul_dim3 block, const std::function<void()> &body) {
+    if (emul_capturing) {
+        emul_capturing->ops.push_back([grid, block, body]() { emul_launch(grid, block, body); });
+        return;
+    }
     const unsigned nt = block.x * block.y * block.z, nw = (nt + 63) / 64;
     if (nt == 0 || grid.x * grid.y * grid.z == 0) return;
     emul_block_ctx ctx;
@@ -230,12 +251,40 @@ static inline hipError_t hipFree(void *p) {
 }
 static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
-static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) {
+    if (emul_capturing) emul_capturing->ops.push_back([=]() { memset(p, v, n); });
+    else memset(p, v, n);
+    return hipSuccess;
+}
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
-static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) {
+    if (emul_capturing) emul_capturing->ops.push_back([=]() { memmove(d, s, n); });
+    else memmove(d, s, n);
+    return hipSuccess;
+}
 static inline hipError_t hipMemcpy2DAsync(void *d, size_t dpitch, const void *s, size_t spitch, size_t width, size_t height, hipMemcpyKind,
                                           hipStream_t) {
-    for (size_t r = 0; r < height; ++r) memmove((char *)d + r * dpitch, (const char *)s + r * spitch, width);
+    auto op = [=]() { for (size_t r = 0; r < height; ++r) memmove((char *)d + r * dpitch, (const char *)s + r * spitch, width); };
+    if (emul_capturing) emul_capturing->ops.push_back(op);
+    else op();
+    return hipSuccess;
+}
+typedef enum { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamCaptureModeRelaxed = 2 } hipStreamCaptureMode;
+static inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) {
+    if (emul_capturing) return hipErrorInvalidValue;
+    emul_capturing = new emul_graph();
+    return hipSuccess;
+}
+static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *g) {
+    *g = emul_capturing;
+    emul_capturing = nullptr;
+    return *g ? hipSuccess : hipErrorInvalidValue;
+}
+static inline hipError_t hipGraphInstantiate(hipGraphExec_t *e, hipGraph_t g, void *, void *, size_t) { *e = new emul_graph(*g); return hipSuccess; }
+static inline hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return hipSuccess; }
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t e) { delete e; return hipSuccess; }
+static inline hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) {
+    for (auto &op : e->ops) op();
     return hipSuccess;
 }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }

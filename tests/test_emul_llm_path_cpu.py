@@ -246,3 +246,44 @@ def test_gemv_plans_in_emulation(E, K, N, n, plan):
     y = E.test_gemv(x, W)
     want = x.float() @ W.float().T
     assert torch.allclose(y, want, rtol=1e-4, atol=1e-4), (y - want).abs().max()
+
+
+@pytest.mark.parametrize("B", [1, 3] if FULL else [1])
+def test_vision_tower_and_connector(E, B):
+    """csrc/vit.hip on the toy tower (96x96 frames, 36 patches): fused uint8 preprocessing + patch embed, encoder layers
+    (fp16 MFMA GEMMs through XOR-swizzled LDS, attention, LayerNorms), MAP head, CLS + 3x3 pooling, connector — eager and
+    as the captured-and-replayed graph — with the tolerance of tests/test_gpu_vit.py."""
+    spec, vspec = O.LLM_SPECS["toy"], O.VIT_SPECS["toy"]
+    w = O.init_llm_weights(spec, seed=3)
+    vw = O.init_vit_weights(vspec, seed=1)
+    frames = O.synthetic_frames(B, vspec.image_size, seed=1234)
+    gold_llm, ref_llm = O.LlamaOracle(spec, w, torch.float32), O.LlamaOracle(spec, w, torch.bfloat16)
+    gold = gold_llm.visual_embed(vw, vspec, frames)
+    ref = ref_llm.visual_embed(vw, vspec, frames)
+    amp = ref_llm.visual_embed(vw, vspec, frames, mm_dtype=torch.float16)        # the reference's GPU numerics, emulated
+    eng = E.EmulEngine(spec, vit=vspec).load_weights({**w, **vw}, O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+    out = eng.visual_embed(frames)
+    assert out.shape == (B * vspec.frame_num_tokens, spec.hidden_size)
+    scale = gold.abs().max().item()
+    e = (out.float() - gold).abs().max().item()
+    a = (amp.float() - gold).abs().max().item()
+    r = (ref.float() - gold).abs().max().item()
+    print(f"[emul vit toy B={B}] engine err {e:.4g}  fp16-autocast-emulation err {a:.4g}  cpu-ref err {r:.4g}  scale {scale:.3g}")
+    assert e <= 2.0 * max(a, r) + 2 * 2 ** -8 * scale
+    # the captured graph replays the same launches: bit-identical, also on the second replay with other frames in between
+    import ctypes
+    fake_stream = ctypes.c_void_p(0x10)
+    g1 = eng.visual_embed(frames, stream=fake_stream)
+    assert torch.equal(g1, out)
+    if FULL:
+        other = O.synthetic_frames(B, vspec.image_size, seed=99)
+        g2 = eng.visual_embed(other, stream=fake_stream)
+        assert not torch.equal(g2, out)
+        assert torch.equal(eng.visual_embed(frames, stream=fake_stream), out)
+        # pre-connector tokens (offline feature extraction, vlo_vision_tokens) against the oracle's encode
+        tok = eng.vision_tokens(frames)
+        assert tok.shape == (B, vspec.frame_num_tokens, vspec.hidden_size)
+        want = O.siglip_vision_encode(vw, vspec, frames)
+        assert (tok.float() - want.float()).abs().max().item() <= 2.0 * (O.siglip_vision_encode(vw, vspec, frames, mm_dtype=torch.float16).float()
+                                                                        - want.float()).abs().max().item() + 2 * 2 ** -8 * want.abs().max().item()
+    eng.close()

@@ -3,7 +3,7 @@
 # ThreadSanitizer: out-of-bounds or misaligned accesses in a kernel's index arithmetic, undefined behaviour, and data
 # races between the threads of a block (a missing __syncthreads, two lanes writing one LDS word) show up as reports.
 #
-#   bash tools/emul_sanitize.sh            # ~10 minutes on 8 cores
+#   bash tools/emul_sanitize.sh            # ~25 minutes on 8 cores (two sanitized builds of every kernel source)
 #
 # Reports that mention only libtorch / libgomp frames (the oracle's OpenMP threads are not instrumented) are noise.
 set -u
