@@ -287,3 +287,36 @@ def test_vision_tower_and_connector(E, B):
         assert (tok.float() - want.float()).abs().max().item() <= 2.0 * (O.siglip_vision_encode(vw, vspec, frames, mm_dtype=torch.float16).float()
                                                                         - want.float()).abs().max().item() + 2 * 2 ** -8 * want.abs().max().item()
     eng.close()
+
+
+@pytest.mark.skipif(not FULL, reason="longer emulation cases: VLO_EMUL_FULL=1")
+def test_tensor_parallel_four_ranks_p2p_and_fused_decode(E, monkeypatch):
+    """T = 4 logical ranks (one kv head each) through the peer-to-peer exchange, and on a plain engine VLO_FUSED_ROWS = 1
+    (the setting meant for the bench: only the decode steps take the fused pipeline) mixed with a block-path first step."""
+    spec = O.LlmSpec(256, 384, 2, 4, 4, 512, 10000.0, 1e-5, vision_hidden_size=128)
+    w = O.init_llm_weights(spec, seed=12)
+    toks = O.default_tokens(spec, n_start=20)
+    ref, gold = O.LlamaOracle(spec, w, torch.bfloat16), O.LlamaOracle(spec, w, torch.float32)
+    inv = O.rope_inv_freq(spec.head_dim, spec.rope_theta)
+    grp = E.EmulTpGroup(spec, 4, w, inv, p2p=True)
+    ts = grp.new_session()
+    eng = E.EmulEngine(spec).load_weights(w, inv)
+    monkeypatch.setenv("VLO_FUSED_ROWS", "1")
+    fs = eng.new_session()
+    monkeypatch.delenv("VLO_FUSED_ROWS")
+    g = torch.Generator().manual_seed(5)
+    first = torch.cat([ref.embed(torch.tensor(toks.start_ids)), torch.randn(10, spec.hidden_size, generator=g).bfloat16()])   # 30 rows
+    steps = [first, ref.embed(torch.tensor([17])), ref.embed(torch.tensor([29])),
+             torch.cat([ref.embed(torch.tensor([toks.interval_id])), torch.randn(10, spec.hidden_size, generator=g).bfloat16()])]
+    rc = gc = None
+    for i, x in enumerate(steps):
+        rl, rc = ref.forward(x, rc)
+        gl, gc = gold.forward(x, gc)
+        _, at = grp.llm_step(ts, x)
+        _, af = eng.llm_step(fs, x)
+        assert grp.session_len(ts) == eng.session_len(fs) == len(rc)
+        _three_way("tp4 p2p", i, at, rl, gl)
+        _three_way("fused<=1 after block path", i, af, rl, gl)
+    assert grp.p2p_status() == dict(enabled=1, timed_out=0, uncached_mailbox=grp.p2p_status()["uncached_mailbox"])
+    grp.close()
+    eng.close()
