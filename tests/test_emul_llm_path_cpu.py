@@ -22,6 +22,10 @@ TINY = O.LlmSpec(128, 192, 2, 2, 2, 256, 10000.0, 1e-5, vision_hidden_size=128) 
 
 @pytest.fixture(scope="module")
 def E():
+    import resource
+    soft, _ = resource.getrlimit(resource.RLIMIT_NPROC)
+    if soft != resource.RLIM_INFINITY and soft < 4096:
+        pytest.skip(f"the emulation runs every GPU thread of a block as an OS thread (up to 1024): RLIMIT_NPROC = {soft}")
     from tests.hip_emul import emul_engine
     if emul_engine.lib() is None:
         pytest.skip("no clang++ to build the emulated library")
