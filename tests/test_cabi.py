@@ -46,6 +46,8 @@ def test_product_path_has_no_oracle_or_cpu_fallback():
             if f.endswith((".py", ".hip", ".h", ".cuh")):
                 s = open(os.path.join(dp, f)).read()
                 assert "oracle" not in s.replace("no oracle", ""), f"{f} references the oracle"
+                # the CPU emulation of the kernels (tests/hip_emul/) is test infrastructure: the product never builds, loads or mentions it
+                assert "hip_emul" not in s and "libvlo_emul" not in s and "VLO_HIP_EMUL" not in s, f"{f} references the test-only emulation"
 
 
 def test_engine_refuses_to_run_without_gpu():

@@ -1,6 +1,6 @@
 // tp_p2p.cuh — device side of the one-shot peer-to-peer tensor-parallel exchange (host side and the protocol description:
-// tp.hip "p2p exchange"; C ABI: include/vlo.h vlo_tp_p2p_*).  Kept in a header of its own so that the kernel SOURCE can also
-// be executed by the CPU test harness (tests/hip_emul/: HIP-on-threads shim, test infrastructure only).
+// tp.hip "p2p exchange"; C ABI: include/vlo.h vlo_tp_p2p_*).  Kept in a header of its own: the unit tests compile these two
+// kernels on their own.
 #pragma once
 #include "common.cuh"
 
