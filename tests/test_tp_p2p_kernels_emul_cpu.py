@@ -138,13 +138,17 @@ def test_silent_rank_times_out_and_error_word_is_sticky(emul):
     rc = emul.emul_p2p_exchange(T, m, H, ks, _ptr(partials), _ptr(h), _ptr(w), _ptr(x), _ptr(mbox), lay["total"], lay["red_off"],
                                 9, 1e-5, 200_000, 2, _ptr(err))
     assert rc != 0 and err.all()
-    # results after a timeout are invalid by contract; what IS guaranteed: the block that waited adds the sources it has
-    # (the missing one counts as zero), blocks that start after the sticky word is up do not wait and add nothing
+    # results after a timeout are invalid by contract; what IS guaranteed, per 8-column chunk (one thread's unit of work): a
+    # thread that waited adds the sources that arrived (the missing one counts as zero), a thread that started after the
+    # sticky word went up does not wait and adds nothing
     eh, _ = _expected(partials, h0, w, m, 1e-5, {0, 1, 3})
+    waited = 0
     for r in range(T):
-        assert np.array_equal(h[r, 0], eh[0]), "the first block of a rank waits, times out, and sums what arrived"
-        for row in range(1, m):
-            assert np.array_equal(h[r, row], eh[row]) or np.array_equal(h[r, row], h0[row])
+        got, want, before = (a.reshape(-1, 8) for a in (h[r, :m], eh, h0[:m]))
+        as_sum, untouched = (got == want).all(-1), (got == before).all(-1)
+        assert (as_sum | untouched).all()
+        waited += int(as_sum.sum())
+    assert waited > 0, "somebody must have waited for the timeout"
     # with the sticky word set nothing waits any more: the next exchange returns at once and adds nothing
     h2 = h.copy()
     rc = emul.emul_p2p_exchange(T, m, H, ks, _ptr(partials), _ptr(h2), _ptr(w), _ptr(x), _ptr(mbox), lay["total"], lay["red_off"],
