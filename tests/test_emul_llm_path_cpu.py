@@ -52,9 +52,13 @@ def _steps(spec, ref, toks, seed, lens):
     return out
 
 
+TINY_GQA = O.LlmSpec(128, 192, 2, 2, 1, 256, 10000.0, 1e-5, vision_hidden_size=128)  # 2 query heads share one kv head
+
+
 def test_default_pipeline_matches_oracle(E):
-    """run_chunk as shipped (7 launches per layer) on the 'toy' model (4 heads over 2 kv heads: the 2-heads-per-wave attention)."""
-    spec = O.LLM_SPECS["toy"]
+    """run_chunk as shipped (7 launches per layer) with grouped-query attention (the 2-heads-per-wave attention kernel);
+    VLO_EMUL_FULL: on the 'toy' model (4 heads over 2 kv heads, 512-thread GEMV blocks)."""
+    spec = O.LLM_SPECS["toy"] if FULL else TINY_GQA
     w = O.init_llm_weights(spec, seed=3)
     toks = O.default_tokens(spec)
     ref, gold = O.LlamaOracle(spec, w, torch.bfloat16), O.LlamaOracle(spec, w, torch.float32)
@@ -66,7 +70,7 @@ def test_default_pipeline_matches_oracle(E):
         gl, gc = gold.forward(x, gc)
         last, allr = eng.llm_step(s, x)
         assert eng.session_len(s) == len(rc) and torch.equal(last, allr[-1])
-        _three_way("toy default", i, allr, rl, gl)
+        _three_way("default pipeline", i, allr, rl, gl)
     tok, p = eng.stream_sample(s, 0.725, toks.interval_id)
     rt, rp = O.stream_sample(rl[-1].clone(), toks.interval_id, 0.725)
     top2 = rl[-1].float().topk(2).values
@@ -274,12 +278,12 @@ def test_vision_tower_and_connector(E, B):
     r = (ref.float() - gold).abs().max().item()
     print(f"[emul vit toy B={B}] engine err {e:.4g}  fp16-autocast-emulation err {a:.4g}  cpu-ref err {r:.4g}  scale {scale:.3g}")
     assert e <= 2.0 * max(a, r) + 2 * 2 ** -8 * scale
-    # the captured graph replays the same launches: bit-identical, also on the second replay with other frames in between
-    import ctypes
-    fake_stream = ctypes.c_void_p(0x10)
-    g1 = eng.visual_embed(frames, stream=fake_stream)
-    assert torch.equal(g1, out)
     if FULL:
+        # the captured graph replays the same launches: bit-identical, also on the second replay with other frames in between
+        import ctypes
+        fake_stream = ctypes.c_void_p(0x10)
+        g1 = eng.visual_embed(frames, stream=fake_stream)
+        assert torch.equal(g1, out)
         other = O.synthetic_frames(B, vspec.image_size, seed=99)
         g2 = eng.visual_embed(other, stream=fake_stream)
         assert not torch.equal(g2, out)
