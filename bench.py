@@ -412,6 +412,16 @@ def main():
         enc.synchronize()
         vit_ms = e0.elapsed_time(e1) / 8 / B
     final_len = len(li.past_key_values)
+    # tensor-parallel runs: latency of ONE exchange (all-reduce of [n, H] fp32 + residual add + RMSNorm) at the frame-step and the
+    # decode-step size, every rank in lock-step — the number the xGMI all-reduce discussion of SURVEY.md §8e is about
+    tp_exchange_us = None
+    if tp:
+        try:
+            xs = eng.new_session()
+            tp_exchange_us = {f"n{m}": round(eng.bench_exchange(xs, m, 200), 2) for m in (11, 1)}
+            xs.close()
+        except Exception as ex:
+            tp_exchange_us = {"error": repr(ex)}
 
     elapsed = reduce_elapsed_max(dist, elapsed, device="cuda" if backend == "nccl" else "cpu")
     fps = aggregate_fps(K, 1 if tp else world, elapsed)        # TP: the ranks share ONE stream of K frames
@@ -444,7 +454,8 @@ def main():
                                    f"(16-token response every 10th frame + t=0 query), random-init weights at true shapes",
                        "frames": K, "final_kv_tokens": final_len, "llm_steps": llm_steps, "prefetch_encode": not args.no_prefetch, "prefetch_frames": args.prefetch_frames,
                        "parallelism": f"tp{world}" if tp else f"replicas{world}",
-                       **({"tp_exchange": dict(kind=args.tp_allreduce, **(eng.p2p_status() if args.tp_allreduce == "p2p" else {}))} if tp else {})},
+                       **({"tp_exchange": dict(kind=args.tp_allreduce, us_per_exchange=tp_exchange_us,
+                                                **(eng.p2p_status() if args.tp_allreduce == "p2p" else {}))} if tp else {})},
             "encode_stage": {"batch": max(1, args.prefetch_frames), "ms_per_frame": round(vit_ms, 4),
                              "tflops": round(VIT_GFLOP_PER_FRAME / vit_ms, 1), "mfma_peak_tflops": MFMA_PEAK_TFLOPS,
                              "frac_of_mfma_peak": round(VIT_GFLOP_PER_FRAME / vit_ms / MFMA_PEAK_TFLOPS, 4),

@@ -216,6 +216,10 @@ int  vlo_tp_greedy_generate(vlo_tp_session *t, const void *embeds_dev, int m, in
 int  vlo_tp_p2p_export(vlo_tp_group *g, void *out_handle64);
 int  vlo_tp_p2p_enable(vlo_tp_group *g, const void *handles);
 int  vlo_tp_p2p_status(vlo_tp_group *g, int *enabled, int *timed_out, int *uncached_mailbox);
+/* micro-benchmark of ONE tensor-parallel exchange (all-reduce of [m][hidden] fp32 partial sums + residual add + RMSNorm, what a
+ * decoder layer issues twice), `iters` back to back on `stream`, average microseconds; RCCL or peer-to-peer, whichever the group
+ * uses.  Every rank of the group makes the same call.  The session's residual stream is scratch afterwards (reset it). */
+int  vlo_tp_bench_exchange(vlo_tp_session *t, int m, int iters, double *avg_us, void *stream);
 /* host-side mailbox geometry of the exchange above (no GPU needed; unit tests): for a group of T ranks, hidden size H,
  * vocabulary shard Vl, the seq-th exchange of a region (seq counts from 0 per region) and the tag `epoch` of the previous
  * exchange, out6 = {first granule of the reduce slot, granules between two sources of a reduce slot, first granule of the

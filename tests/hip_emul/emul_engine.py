@@ -196,6 +196,11 @@ class EmulTpGroup:
     def session_len(self, s):
         return int(lib().vlo_tp_session_len(s))
 
+    def bench_exchange(self, s, m, iters):
+        us = C.c_double(-1)
+        check(lib().vlo_tp_bench_exchange(s, m, iters, C.byref(us), None))
+        return us.value
+
     def llm_step(self, s, embeds, want_all=True):
         x = embeds.to(torch.bfloat16).contiguous().view(-1, self.spec.hidden_size)
         n, V = x.shape[0], self.spec.vocab_size

@@ -132,6 +132,11 @@ def test_tensor_parallel_logical_ranks(E, p2p):
         _three_way(f"tiny tp2 {'p2p' if p2p else 'sum'}", i, allr, rl, gl)
     if p2p:
         assert grp.p2p_status()["timed_out"] == 0
+    # the exchange micro-benchmark bench.py reports for tensor-parallel runs: runs, returns a time, leaves the group usable
+    xs = grp.new_session()
+    assert grp.bench_exchange(xs, 3, 2) >= 0.0
+    if p2p:
+        assert grp.p2p_status()["timed_out"] == 0
     grp.close()
 
 

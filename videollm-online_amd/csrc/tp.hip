@@ -642,6 +642,41 @@ int vlo_tp_llm_step(vlo_tp_session *t, const void *embeds_dev, int n, void *last
     return VLO_OK;
 }
 
+// `iters` back-to-back exchanges of m rows (all-reduce of the [m][H] fp32 partial sums + residual add + RMSNorm, exactly what a
+// decoder layer issues twice) on the session's own buffers, timed with HIP events on `stream`: the latency of ONE exchange in
+// microseconds, RCCL or peer-to-peer whichever the group uses.  Every rank of the group must make the same call (lock-step,
+// like a step).  The session's residual stream is scratch afterwards: reset the session before stepping it again.
+int vlo_tp_bench_exchange(vlo_tp_session *t, int m, int iters, double *avg_us, void *stream) {
+    if (!t || m <= 0 || m > 16 || iters <= 0 || !avg_us) return vlo_fail(VLO_E_INVALID, "bad tp_bench_exchange arguments");
+    vlo_tp_group *g = t->g;
+    vlo_engine *e0 = g->eng[0];
+    TP_TRY(hipSetDevice(e0->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t H = e0->cfg.hidden_size;
+    for (vlo_session *s : t->ss) {            // finite inputs: partial sums of zeros, a residual stream of zeros
+        TP_TRY(hipMemsetAsync(s->partial, 0, (size_t)16 * H * 4, st));
+        TP_TRY(hipMemsetAsync(s->h, 0, (size_t)16 * H * 2, st));
+    }
+    hipEvent_t e0v = nullptr, e1v = nullptr;
+    TP_TRY(hipEventCreate(&e0v));
+    if (hipEventCreate(&e1v) != hipSuccess) { hipEventDestroy(e0v); return vlo_fail(VLO_E_HIP, "hipEventCreate failed"); }
+    int rc = VLO_OK;
+    for (int i = 0; i < 3 && !rc; ++i) rc = tp_reduce_norm(t, &vlo_session::partial, 1, m, norm_final, 0, st);   // warm-up
+    hipError_t he = rc ? hipSuccess : hipEventRecord(e0v, st);
+    for (int i = 0; i < iters && !rc && he == hipSuccess; ++i) rc = tp_reduce_norm(t, &vlo_session::partial, 1, m, norm_final, 0, st);
+    if (!rc && he == hipSuccess) he = hipEventRecord(e1v, st);
+    if (!rc && he == hipSuccess) he = hipEventSynchronize(e1v);
+    float ms = 0.f;
+    if (!rc && he == hipSuccess) he = hipEventElapsedTime(&ms, e0v, e1v);
+    hipEventDestroy(e0v);
+    hipEventDestroy(e1v);
+    if (rc) return rc;
+    if (he != hipSuccess) return vlo_fail(VLO_E_HIP, std::string("tp_bench_exchange: ") + hipGetErrorString(he));
+    if (g->p2p.enabled && *(volatile unsigned *)g->p2p.err_host) return vlo_fail(VLO_E_HIP, "p2p exchange timed out during tp_bench_exchange");
+    *avg_us = (double)ms * 1e3 / iters;
+    return VLO_OK;
+}
+
 int vlo_tp_stream_sample(vlo_tp_session *t, float threshold, int interval_id, int64_t *tok_dev, float *p_interval_dev, void *stream) {
     if (!t || !tok_dev) return vlo_fail(VLO_E_INVALID, "bad tp_stream_sample arguments");
     vlo_session *s = t->ss[0];

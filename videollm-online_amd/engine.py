@@ -437,6 +437,13 @@ class TpGroup:
                                                  C.byref(n), _stream_handle(stream)))
         return n.value
 
+    def bench_exchange(self, session: TpSession, m: int, iters: int = 200, stream=None) -> float:
+        """microseconds of ONE exchange of m rows (all-reduce + residual add + RMSNorm), timed over ``iters`` back-to-back ones;
+        every rank must call it; the session is scratch afterwards (reset it)."""
+        us = C.c_double(0)
+        _C.check(_C.lib().vlo_tp_bench_exchange(session._h, m, iters, C.byref(us), _stream_handle(stream)))
+        return us.value
+
     def close(self):
         if self._g:
             _C.lib().vlo_tp_group_destroy(self._g)
