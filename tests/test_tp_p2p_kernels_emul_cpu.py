@@ -35,7 +35,13 @@ def emul():
     os.makedirs(out_dir, exist_ok=True)
     lib = os.path.join(out_dir, "libp2p_emul.so")
     # -Bsymbolic: libvlo.so (RTLD_GLOBAL, loaded by other tests of the session) exports host stubs with the kernels' names
-    cmd = [cc, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-Wl,-Bsymbolic", "-DXCHG_THREADS=64", "-I", EMUL,
+    san = os.environ.get("VLO_EMUL_SANITIZE")                  # e.g. address,undefined or thread (tools/emul_sanitize.sh)
+    extra = ["-fsanitize=" + san, "-fno-omit-frame-pointer", "-g"] if san else []
+    if san:
+        out_dir = os.path.join(out_dir, "san_" + san.replace(",", "_"))
+        os.makedirs(out_dir, exist_ok=True)
+        lib = os.path.join(out_dir, "libp2p_emul.so")
+    cmd = [cc, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-Wl,-Bsymbolic", "-DXCHG_THREADS=64", *extra, "-I", EMUL,
            "-I", os.path.join(ROOT, "videollm-online_amd", "csrc"), os.path.join(EMUL, "p2p_harness.cpp"), "-o", lib]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
