@@ -333,3 +333,28 @@ def test_tensor_parallel_four_ranks_p2p_and_fused_decode(E, monkeypatch):
     assert grp.p2p_status() == dict(enabled=1, timed_out=0, uncached_mailbox=grp.p2p_status()["uncached_mailbox"])
     grp.close()
     eng.close()
+
+
+@pytest.mark.skipif(not FULL, reason="longer emulation cases: VLO_EMUL_FULL=1")
+@pytest.mark.parametrize("n", [17, 64, 65, 81])
+def test_step_chunking_boundaries(E, n):
+    """vlo_llm_step's split of a long input: blocks of 64 tokens through the block path, a tail of <= 16 through the 16-row
+    pipeline (17 = one block of 17; 64 = one full block; 65 = block + 1-row chunk; 81 = block + block of 17)."""
+    spec = TINY_GQA
+    w = O.init_llm_weights(spec, seed=20 + n)
+    ref, gold = O.LlamaOracle(spec, w, torch.bfloat16), O.LlamaOracle(spec, w, torch.float32)
+    eng = E.EmulEngine(spec).load_weights(w, O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+    s = eng.new_session()
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, spec.hidden_size, generator=g).bfloat16()
+    rl, rc = ref.forward(x, None)
+    gl, gc = gold.forward(x, None)
+    last, allr = eng.llm_step(s, x)
+    assert eng.session_len(s) == n and torch.equal(last, allr[-1])
+    _three_way(f"chunking n={n}", 0, allr, rl, gl)
+    x2 = torch.randn(3, spec.hidden_size, generator=g).bfloat16()          # and the cache it left behind is usable
+    rl2, _ = ref.forward(x2, rc)
+    gl2, _ = gold.forward(x2, gc)
+    _, a2 = eng.llm_step(s, x2)
+    _three_way(f"chunking n={n} + 3", 1, a2, rl2, gl2)
+    eng.close()
