@@ -3,7 +3,8 @@
 // Resolved instead of <hip/hip_runtime.h> when a source is compiled with `-x c++ -I tests/hip_emul`: the SOURCE of the
 // engine's kernels and of its host code then becomes a plain host program, so that index arithmetic, epilogue wiring,
 // flag / tag protocols, launch sequencing and rounding points can be exercised in the `-m "not gpu"` suite at toy sizes:
-//   * a kernel launch runs its blocks ONE AT A TIME, every thread of a block is an OS thread;
+//   * a kernel launch runs its blocks ONE AT A TIME, every thread of a block is an OS thread; a COOPERATIVE launch
+//     (hipLaunchCooperativeKernel) runs every block in its own forked process, concurrently, so grid barriers work;
 //   * `__shared__` is a plain static (static shared memory) — `extern __shared__` arrays are defined by the harness;
 //   * `__syncthreads()` is a barrier over the block, wave shuffles and the 16x16x32 MFMA exchange their operands through a
 //     per-wave buffer between two wave barriers (so they must be called wave-uniformly, as on the hardware);
@@ -23,6 +24,7 @@
 #include <stdio.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -32,6 +34,8 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 // ---- language ---------------------------------------------------------------------------------------------------------
@@ -42,6 +46,9 @@
 #define __launch_bounds__(...)
 #define __shared__ static
 #define address_space(x)                 // __attribute__((address_space(1))) -> no attribute on the host
+
+typedef enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotSupported = 801 } hipError_t;
+typedef void *hipStream_t;
 
 struct emul_dim3 {
     unsigned x = 1, y = 1, z = 1;
@@ -129,6 +136,7 @@ static inline long long wall_clock64() {      // s_memrealtime: a 100 MHz counte
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
 #define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or((p), (v), (order))
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), (order))
 static inline float atomicAdd(float *p, float v) {          // relaxed fp32 atomic add (CAS loop)
     unsigned *u = reinterpret_cast<unsigned *>(p), old = __atomic_load_n(u, __ATOMIC_RELAXED);
     for (;;) {
@@ -186,12 +194,60 @@ static inline void emul_launch(emul_dim3 grid, emul_dim3 block, const std::funct
     pthread_barrier_destroy(&end_bar);
     for (auto &w : ctx.waves) pthread_barrier_destroy(&w.bar);
 }
+// Cooperative launches: the blocks must make progress TOGETHER (grid barriers, flags between blocks), so every block runs in
+// its own forked process (own static shared memory, own thread set) over the shared "device" memory.
+inline hipError_t emul_coop_error = hipSuccess;
+static inline void emul_launch_concurrent(emul_dim3 grid, emul_dim3 block, const std::function<void()> &body) {
+    fflush(nullptr);
+    std::vector<pid_t> kids;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                const pid_t pid = fork();
+                if (pid == 0) {
+                    // this process is block (bx, by, bz): one block, the usual thread-per-lane execution
+                    const unsigned nt = block.x, nw = (nt + 63) / 64;
+                    emul_block_ctx ctx;
+                    pthread_barrier_init(&ctx.block_bar, nullptr, nt);
+                    ctx.waves = std::vector<emul_wave_ctx>(nw);
+                    for (unsigned w = 0; w < nw; ++w) pthread_barrier_init(&ctx.waves[w].bar, nullptr, (w + 1) * 64 <= nt ? 64 : nt - w * 64);
+                    std::vector<std::thread> ts;
+                    for (unsigned t = 0; t < nt; ++t)
+                        ts.emplace_back([&, t]() {
+                            threadIdx = emul_dim3(t);
+                            blockIdx = emul_dim3(bx, by, bz);
+                            blockDim = block;
+                            gridDim = grid;
+                            emul_ctx = &ctx;
+                            body();
+                        });
+                    for (auto &th : ts) th.join();
+                    _exit(0);
+                }
+                if (pid < 0) { emul_coop_error = hipErrorOutOfMemory; break; }
+                kids.push_back(pid);
+            }
+    for (pid_t k : kids) {
+        int st = 0;
+        if (waitpid(k, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) emul_coop_error = hipErrorInvalidValue;
+    }
+}
+template <class... A, size_t... I>
+static inline void emul_call_unpacked(void (*f)(A...), void **params, std::index_sequence<I...>) {
+    f(*reinterpret_cast<std::remove_reference_t<A> *>(params[I])...);
+}
+template <class... A>
+static inline hipError_t hipLaunchCooperativeKernel(void (*f)(A...), emul_dim3 grid, emul_dim3 block, void **params, unsigned, void *) {
+    emul_launch_concurrent(grid, block, [=]() { emul_call_unpacked(f, params, std::index_sequence_for<A...>{}); });
+    const hipError_t e = emul_coop_error;
+    emul_coop_error = hipSuccess;
+    return e;
+}
+
 #define hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, ...) \
     emul_launch(emul_dim3(grid), emul_dim3(block), [=]() { kernel(__VA_ARGS__); })
 
 // ---- runtime API (device memory = host memory, one "device", everything synchronous) -------------------------------------
-typedef enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotSupported = 801 } hipError_t;
-typedef void *hipStream_t;
 typedef struct emul_event { std::chrono::steady_clock::time_point t; } *hipEvent_t;
 typedef enum { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 } hipMemcpyKind;
 typedef struct { char reserved[64]; } hipIpcMemHandle_t;
@@ -210,15 +266,21 @@ static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; 
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipDeviceCanAccessPeer(int *can, int, int) { *can = 0; return hipSuccess; }
 static inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
-static inline hipError_t hipMalloc(void **p, size_t bytes) {
-    *p = aligned_alloc(256, (bytes + 255) / 256 * 256 + 256);
-    return *p ? hipSuccess : hipErrorOutOfMemory;
-}
-// Uncached / fine-grained allocations (the p2p mailboxes) live in POSIX shared memory so that hipIpc can be emulated
-// ACROSS PROCESSES: the "handle" is the shm object's name.
+// Every "device" allocation is a MAP_SHARED mapping: the block-processes of a cooperative launch (emul_launch_concurrent) and
+// their parent see one memory.  Uncached / fine-grained allocations (the p2p mailboxes) are NAMED shared memory objects so
+// that hipIpc can be emulated ACROSS independent processes: the "handle" is the object's name.
 struct emul_shm_entry { std::string name; size_t bytes; bool owner; };
 inline std::map<void *, emul_shm_entry> emul_shm_registry;
 inline std::mutex emul_shm_mu;
+static inline hipError_t hipMalloc(void **p, size_t bytes) {
+    const size_t n = (bytes + 4095) / 4096 * 4096 + 4096;
+    void *m = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) return hipErrorOutOfMemory;
+    std::lock_guard<std::mutex> g(emul_shm_mu);
+    emul_shm_registry[m] = {"", n, true};
+    *p = m;
+    return hipSuccess;
+}
 static inline hipError_t hipExtMallocWithFlags(void **p, size_t bytes, unsigned) {
     static std::atomic<int> counter{0};
     char name[64];
@@ -241,15 +303,14 @@ static inline hipError_t hipFree(void *p) {
         auto it = emul_shm_registry.find(p);
         if (it != emul_shm_registry.end()) {
             munmap(p, it->second.bytes);
-            if (it->second.owner) shm_unlink(it->second.name.c_str());
+            if (it->second.owner && !it->second.name.empty()) shm_unlink(it->second.name.c_str());
             emul_shm_registry.erase(it);
             return hipSuccess;
         }
     }
-    free(p);
-    return hipSuccess;
+    return p ? hipErrorInvalidValue : hipSuccess;
 }
-static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostFree(void *p) { return hipFree(p); }
 static inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) {
     if (emul_capturing) emul_capturing->ops.push_back([=]() { memset(p, v, n); });
@@ -302,7 +363,7 @@ static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int
 static inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t *h, void *p) {
     std::lock_guard<std::mutex> g(emul_shm_mu);
     auto it = emul_shm_registry.find(p);
-    if (it == emul_shm_registry.end() || it->second.name.size() >= sizeof(h->reserved)) return hipErrorInvalidValue;
+    if (it == emul_shm_registry.end() || it->second.name.empty() || it->second.name.size() >= sizeof(h->reserved)) return hipErrorInvalidValue;
     memset(h->reserved, 0, sizeof(h->reserved));
     memcpy(h->reserved, it->second.name.c_str(), it->second.name.size());
     return hipSuccess;

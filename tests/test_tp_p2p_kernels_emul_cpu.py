@@ -179,3 +179,23 @@ def test_gather_kernel_source(emul, T, nr, Vl, blocks, seq):
     for r in range(T):
         assert np.array_equal(out[r], want)
     assert (mbox[:, :lay["gat_off"]] == 0).all() if seq == 0 else True     # the reduce region is not touched
+
+
+def test_shim_cooperative_launch_runs_blocks_concurrently():
+    """hipLaunchCooperativeKernel in the shim: one forked process per block over shared "device" memory — a hand-rolled grid
+    barrier completes and every block reads what its neighbour published in the same round (tests/hip_emul/coop_selftest.cpp)."""
+    cc = _clang()
+    if cc is None:
+        pytest.skip("no clang++")
+    out_dir = os.path.join(EMUL, "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    lib = os.path.join(out_dir, "libcoop_selftest.so")
+    r = subprocess.run([cc, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-Wl,-Bsymbolic", "-I", EMUL,
+                        os.path.join(EMUL, "coop_selftest.cpp"), "-lrt", "-o", lib], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    L = C.CDLL(lib, mode=os.RTLD_LOCAL)
+    blocks, threads, rounds = 6, 64, 5
+    out = np.zeros(rounds * blocks, dtype=np.uint32)
+    assert L.coop_selftest(blocks, threads, rounds, _ptr(out)) == 0
+    want = np.array([[r * 1000 + (b + 1) % blocks for b in range(blocks)] for r in range(rounds)], dtype=np.uint32)
+    assert np.array_equal(out.reshape(rounds, blocks), want)
