@@ -85,256 +85,14 @@ VLO_DEV float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b
 
 template <int KF, int NW, int XSRC, int EPI>
 __global__ __launch_bounds__(NW * 64) void gemv16_kernel(GemvArgs a) {
-    constexpr int CTG = 2;
     extern __shared__ __attribute__((aligned(16))) float4 red[];      // [2][NW][CTG][64] float4, then scratch
-    float *scratch = reinterpret_cast<float *>(red + 2 * NW * CTG * 64);   // rs[16] | tmp[NW*4][16]
-    float *rs_lds = scratch;
-    float *tmp_lds = scratch + 16;
-    const int lane = threadIdx.x & 63;
-    const int w = threadIdx.x >> 6;
-    const int m16 = lane & 15, qd = lane >> 4;
-    const int KFtot = a.K >> 5;
-    const int kfw0 = (blockIdx.y * NW + w) * a.KC * KF;       // first fragment of this wave's K range
-
-    // ---- group -> tiles -----------------------------------------------------------------
-    const int hd = a.kv.head_dim;
-    const int tph = (EPI == EPI_ROPE) ? hd / 16 : 2;           // tiles per head
-    const int hp = tph / 2;                                    // rotary pairs of tiles per head
-    // a.CT == 1: one tile per group (narrow outputs such as o_proj: NT = 256 tiles -> 256 blocks instead of 128)
-    const bool single = (EPI != EPI_ROPE && a.CT == 1);
-    const int ngroups = (EPI == EPI_ROPE) ? a.NT / 2 : (single ? a.NT : (a.NT + 1) / 2);
-    auto tile_a = [&](int g) { return (EPI == EPI_ROPE) ? (g / hp) * tph + (g % hp) : (single ? g : 2 * g); };
-    auto tile_b = [&](int g) { return (EPI == EPI_ROPE) ? (g / hp) * tph + (g % hp) + hp : (single ? a.NT : 2 * g + 1); };
-
-    const frag_ab *wbase = reinterpret_cast<const frag_ab *>(a.Wp) + (size_t)kfw0 * 64 + lane;
-    const size_t tile_stride = (size_t)KFtot * 64;
-    auto item_ptr = [&](int tile, int c) { return wbase + (size_t)tile * tile_stride + (size_t)c * KF * 64; };
-
-    // ---- first weight fragments go in flight before anything else ---------------------------
-    frag_ab wr[KF];
-    int g = blockIdx.x;
-    if (g < ngroups) {
-        const frag_ab *wp = item_ptr(tile_a(g), 0);
-#pragma unroll
-        for (int kf = 0; kf < KF; ++kf) wr[kf] = __builtin_nontemporal_load(wp + kf * 64);
-    }
-
-    // ---- XSRC_NORM: rs[m] = rsqrt(mean(h[m]^2) + eps) from the producer's partial sums --------
-    if (XSRC == XSRC_NORM) {
-        const int t = threadIdx.x, m = t & 15, sl = t >> 4, nsl = NW * 4;
-        float s = 0.f;
-        for (int p = sl; p < a.sq_in_parts; p += nsl) s += a.sq_in[p * 16 + m];
-        tmp_lds[sl * 16 + m] = s;
-        __syncthreads();
-        if (t < 16) {
-            float tot = 0.f;
-            for (int i = 0; i < nsl; ++i) tot += tmp_lds[i * 16 + t];
-            rs_lds[t] = (t < a.n_rows) ? 1.0f / sqrtf(tot / (float)a.K + a.eps) : 0.f;
-        }
-        __syncthreads();
-    }
-
-    // ---- activation fragments of one K chunk (B operand): x[m = lane&15][k .. k+8] -------------
-    frag_ab xf[KF];
-    auto load_x = [&](int c) {
-        const size_t k0 = (size_t)(kfw0 + c * KF) * 32 + qd * 8;
-        const bf16_t *xr = a.x + (size_t)m16 * a.ldx + k0;
-        if (XSRC == XSRC_NORM) {
-            const float rsm = rs_lds[m16];
-#pragma unroll
-            for (int kf = 0; kf < KF; ++kf) {
-                frag_ab hv = {0, 0, 0, 0, 0, 0, 0, 0}, o;
-                if (m16 < a.n_rows) hv = *reinterpret_cast<const frag_ab *>(xr + kf * 32);
-                const frag_ab wv = *reinterpret_cast<const frag_ab *>(a.norm_w + k0 + kf * 32);
-                unsigned pk[4];
-#pragma unroll
-                for (int j = 0; j < 8; j += 2) {     // weight * (x * rsqrt(var + eps)).to(bf16)   (HF :66-67)
-                    const unsigned t2 = pack2bf(bf2f((bf16_t)hv[j]) * rsm, bf2f((bf16_t)hv[j + 1]) * rsm);
-                    pk[j >> 1] = pack2bf(bf2f((bf16_t)wv[j]) * __uint_as_float(t2 << 16),
-                                         bf2f((bf16_t)wv[j + 1]) * __uint_as_float(t2 & 0xffff0000u));
-                }
-                o = __builtin_bit_cast(frag_ab, make_uint4(pk[0], pk[1], pk[2], pk[3]));
-                xf[kf] = o;
-            }
-        } else {
-#pragma unroll
-            for (int kf = 0; kf < KF; ++kf) {
-                frag_ab z = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (m16 < a.n_rows) z = *reinterpret_cast<const frag_ab *>(xr + kf * 32);
-                xf[kf] = z;
-            }
-        }
-    };
-    if (a.KC == 1) load_x(0);
-
-    float sq_acc = 0.f;                    // EPI_RESID: this wave's running sum of squares for row lane&15
-    int buf = 0;
-    for (; g < ngroups; g += gridDim.x) {
-        const int tA = tile_a(g), tB = tile_b(g);
-        const bool hasB = tB < a.NT;
-        const int gn = g + gridDim.x;
-        float4 *rb = red + (size_t)buf * NW * CTG * 64;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < a.KC; ++c) {
-            if (a.KC > 1) load_x(c);
-            // item (c, A); next item is (c, B) | (c+1, A) | (next group, 0, A) | none
-            {
-                const frag_ab *np = hasB ? item_ptr(tB, c)
-                                         : (c + 1 < a.KC ? item_ptr(tA, c + 1) : (gn < ngroups ? item_ptr(tile_a(gn), 0) : nullptr));
-                if (np) {
-#pragma unroll
-                    for (int kf = 0; kf < KF; ++kf) {
-                        acc0 = mfma_bf16(wr[kf], xf[kf], acc0);
-                        wr[kf] = __builtin_nontemporal_load(np + kf * 64);
-                    }
-                } else {
-#pragma unroll
-                    for (int kf = 0; kf < KF; ++kf) acc0 = mfma_bf16(wr[kf], xf[kf], acc0);
-                }
-            }
-            if (hasB) {
-                const frag_ab *np = c + 1 < a.KC ? item_ptr(tA, c + 1) : (gn < ngroups ? item_ptr(tile_a(gn), 0) : nullptr);
-                if (np) {
-#pragma unroll
-                    for (int kf = 0; kf < KF; ++kf) {
-                        acc1 = mfma_bf16(wr[kf], xf[kf], acc1);
-                        wr[kf] = __builtin_nontemporal_load(np + kf * 64);
-                    }
-                } else {
-#pragma unroll
-                    for (int kf = 0; kf < KF; ++kf) acc1 = mfma_bf16(wr[kf], xf[kf], acc1);
-                }
-            }
-        }
-        rb[(w * CTG + 0) * 64 + lane] = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
-        rb[(w * CTG + 1) * 64 + lane] = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
-        __syncthreads();
-
-        // ---- cross-wave reduction + epilogue ------------------------------------------------
-        if (EPI == EPI_ROPE) {
-            // both tiles of the group are needed by the same lane (rotary pair): one wave
-            if (threadIdx.x < 64) {
-                const int l = lane;
-                float4 sA = make_float4(0, 0, 0, 0), sB = make_float4(0, 0, 0, 0);
-#pragma unroll
-                for (int ww = 0; ww < NW; ++ww) {
-                    sA = f4add(sA, rb[(ww * CTG + 0) * 64 + l]);
-                    sB = f4add(sB, rb[(ww * CTG + 1) * 64 + l]);
-                }
-                const int m = l & 15;
-                if (m < a.n_rows) {
-                    const float va[4] = {sA.x, sA.y, sA.z, sA.w}, vb[4] = {sB.x, sB.y, sB.z, sB.w};
-                    {
-                        const int half = hd >> 1, nh = a.num_heads, nkv = a.kv.num_kv_heads;
-                        const int head = g / hp, i = (g % hp) * 16 + (l >> 4) * 4;   // column inside the head, < half
-                        const long long pos = a.pos0 + m;
-                        const int page = a.kv.page_table[pos / VLO_PAGE_TOKENS];
-                        const int tok = (int)(pos % VLO_PAGE_TOKENS);
-                        if (head < nh + nkv) {
-                            bf16_t *dst = (head < nh)
-                                ? a.out_bf16 + (size_t)m * nh * hd + (size_t)head * hd
-                                : a.kv.k_pool + (size_t)a.layer * a.kv.layer_stride + (size_t)page * a.kv.page_elems +
-                                      ((size_t)(head - nh) * VLO_PAGE_TOKENS + tok) * hd;
-                            const ushort4 c4 = *reinterpret_cast<const ushort4 *>(a.cos_tab + pos * half + i);
-                            const ushort4 s4 = *reinterpret_cast<const ushort4 *>(a.sin_tab + pos * half + i);
-                            const bf16_t cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
-                            bf16_t lo[4], hi[4];
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float x1 = rbf(va[r]), x2 = rbf(vb[r]);      // projection output is bf16
-                                const float c = bf2f(cc[r]), s = bf2f(ss[r]);
-                                // q*cos + rotate_half(q)*sin, each product and the sum rounded to bf16 (:157-158)
-                                lo[r] = f2bf(rbf(x1 * c) + rbf(-x2 * s));
-                                hi[r] = f2bf(rbf(x2 * c) + rbf(x1 * s));
-                            }
-                            *reinterpret_cast<ushort4 *>(dst + i) = *reinterpret_cast<const ushort4 *>(lo);
-                            *reinterpret_cast<ushort4 *>(dst + half + i) = *reinterpret_cast<const ushort4 *>(hi);
-                        } else {
-                            bf16_t *dst = a.kv.vt_pool + (size_t)a.layer * a.kv.layer_stride + (size_t)page * a.kv.page_elems +
-                                          ((size_t)(head - nh - nkv) * hd) * VLO_PAGE_TOKENS + tok;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                dst[(size_t)(i + r) * VLO_PAGE_TOKENS] = f2bf(va[r]);
-                                dst[(size_t)(half + i + r) * VLO_PAGE_TOKENS] = f2bf(vb[r]);
-                            }
-                        }
-                    }
-                }
-            }
-        } else {
-            for (int t = threadIdx.x; t < CTG * 64; t += NW * 64) {
-                const int ct = t >> 6, l = t & 63;
-                const int tile = ct ? tB : tA;
-                float4 s = make_float4(0, 0, 0, 0);
-#pragma unroll
-                for (int ww = 0; ww < NW; ++ww) s = f4add(s, rb[(ww * CTG + ct) * 64 + l]);
-                const int m = l & 15;
-                const int col = tile * 16 + (l >> 4) * 4;
-                const bool live = (m < a.n_rows) && (tile < a.NT);
-                if (EPI == EPI_SWIGLU) {
-                    // tile = 8 gate rows (fragment rows 0..7, lanes 0..31) + the 8 up rows of the same columns (lanes 32..63)
-                    if (live && l < 32) {
-                        float4 u = make_float4(0, 0, 0, 0);
-#pragma unroll
-                        for (int ww = 0; ww < NW; ++ww) u = f4add(u, rb[(ww * CTG + ct) * 64 + l + 32]);
-                        const float gv[4] = {s.x, s.y, s.z, s.w}, uv[4] = {u.x, u.y, u.z, u.w};
-                        bf16_t o[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = f2bf(silu_bf16(rbf(gv[r])) * rbf(uv[r]));
-                        *reinterpret_cast<ushort4 *>(a.out_bf16 + (size_t)m * a.ldo + tile * 8 + (l >> 4) * 4) = *reinterpret_cast<const ushort4 *>(o);
-                    }
-                } else if (EPI == EPI_RESID) {
-                    float sq = 0.f;
-                    if (live) {
-                        bf16_t *hp4 = a.h + (size_t)m * a.ldo + col;
-                        const ushort4 hv = *reinterpret_cast<const ushort4 *>(hp4);
-                        const bf16_t hh[4] = {hv.x, hv.y, hv.z, hv.w};
-                        const float sv[4] = {s.x, s.y, s.z, s.w};
-                        bf16_t o[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {      // Linear output -> bf16, then the bf16 residual add
-                            const float hn = rbf(bf2f(hh[r]) + rbf(sv[r]));
-                            o[r] = f2bf(hn);
-                            sq += hn * hn;
-                        }
-                        *reinterpret_cast<ushort4 *>(hp4) = *reinterpret_cast<const ushort4 *>(o);
-                    }
-                    sq += __shfl_xor(sq, 16, 64);
-                    sq += __shfl_xor(sq, 32, 64);
-                    sq_acc += sq;                          // meaningful in lanes 0..15 (row = lane)
-                } else if (live) {
-                    if (EPI == EPI_PARTIAL_F32) {
-                        *reinterpret_cast<float4 *>(a.out_f32 + ((size_t)blockIdx.y * 16 + m) * a.ldo + col) = s;
-                    } else if (col < a.N_valid) {          // N padded to 16 at pack time; N_valid % 4 == 0
-                        if (a.bias) {
-                            const ushort4 b = *reinterpret_cast<const ushort4 *>(a.bias + col);
-                            s.x += bf2f(b.x); s.y += bf2f(b.y); s.z += bf2f(b.z); s.w += bf2f(b.w);
-                        }
-                        ushort4 o;
-                        if (EPI == EPI_BF16_GELU_ERF) {
-                            o.x = f2bf(gelu_python_bf16(rbf(s.x))); o.y = f2bf(gelu_python_bf16(rbf(s.y)));
-                            o.z = f2bf(gelu_python_bf16(rbf(s.z))); o.w = f2bf(gelu_python_bf16(rbf(s.w)));
-                        } else {
-                            o.x = f2bf(s.x); o.y = f2bf(s.y); o.z = f2bf(s.z); o.w = f2bf(s.w);
-                        }
-                        *reinterpret_cast<ushort4 *>(a.out_bf16 + (size_t)m * a.ldo + col) = o;
-                    }
-                }
-            }
-        }
-        buf ^= 1;
-    }
-    if (EPI == EPI_RESID) {
-        // deterministic block total of the row sums of squares -> sq_out[blockIdx.x][16]
-        __syncthreads();
-        if (lane < 16) tmp_lds[w * 16 + lane] = sq_acc;
-        __syncthreads();
-        if (threadIdx.x < 16) {
-            float tot = 0.f;
-            for (int ww = 0; ww < NW; ++ww) tot += tmp_lds[ww * 16 + threadIdx.x];
-            a.sq_out[(size_t)blockIdx.x * 16 + threadIdx.x] = tot;
-        }
-    }
+#define VLO_GEMV_BX blockIdx.x
+#define VLO_GEMV_BY blockIdx.y
+#define VLO_GEMV_GX gridDim.x
+#include "gemv_body.inc"
+#undef VLO_GEMV_BX
+#undef VLO_GEMV_BY
+#undef VLO_GEMV_GX
 }
 
 // ------------------------------------------------------------------------------------

@@ -133,187 +133,18 @@ template <int HD, int HPW>
 __global__ __launch_bounds__(512) void attn_chunk_kernel(const bf16_t *__restrict__ q, KvGeom kv, int layer, int nh, int G, int KS,
                                                          int64_t pos0, int n, int chunk, float scale,
                                                          float *__restrict__ part_o, float *__restrict__ part_ml) {
-    constexpr int NKK = HD / 32, NDT = HD / 16;
     extern __shared__ __attribute__((aligned(16))) float4 lds_o[];        // [(KS-1)*NHG][HPW][NDT][64] float4, then m/l
-    const int NHG = G / HPW;
-    float *lds_ml = reinterpret_cast<float *>(lds_o + (size_t)(KS - 1) * NHG * HPW * NDT * 64);   // [(KS-1)*NHG][HPW][16][2]
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int hg = w % NHG, ks = w / NHG;
-    const int split = blockIdx.x, kvh = blockIdx.y;
-    // blockIdx.z = 16-query sub-chunk of a longer block of new tokens (block path): queries z*16 .. z*16+n-1
-    {
-        const int z = blockIdx.z;
-        q += (size_t)z * 16 * nh * HD;
-        pos0 += 16 * z;
-        n = min(16, n - 16 * z);
-        part_o += (size_t)z * gridDim.x * nh * 16 * HD;
-        part_ml += (size_t)z * gridDim.x * nh * 16 * 2;
-    }
-    const int L = (int)(pos0 + n);
-    const int c0 = split * chunk, c1 = min(L, c0 + chunk);
-    const int head0 = kvh * G + hg * HPW;
-    const int qrow = lane & 15, qd = lane >> 4;
-
-    frag_ab qf[HPW][NKK];
-#pragma unroll
-    for (int h = 0; h < HPW; ++h)
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) {
-            frag_ab z = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (qrow < n) z = *reinterpret_cast<const frag_ab *>(q + (size_t)qrow * nh * HD + (size_t)(head0 + h) * HD + kk * 32 + qd * 8);
-            qf[h][kk] = z;
-        }
-    f32x4 O[HPW][NDT];
-    float mrun[HPW], lrun[HPW];
-#pragma unroll
-    for (int h = 0; h < HPW; ++h) {
-        mrun[h] = -INFINITY;
-        lrun[h] = 0.f;
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) O[h][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    const int qpos = (int)pos0 + min(qrow, n - 1);
-    const bf16_t *kbase = kv.k_pool + (size_t)layer * kv.layer_stride;
-    const bf16_t *vbase = kv.vt_pool + (size_t)layer * kv.layer_stride;
-
-    // K fragments are fetched one 32-key block AHEAD (register double buffer), so the HBM latency of block i+1 hides
-    // behind the MFMAs / softmax of block i; V^T fragments of the current block are issued first thing in the
-    // iteration and are only needed after QK^T + softmax.
-    auto load_k = [&](int kt0, frag_ab (&dst)[2][NKK]) {
-        const int page = kv.page_table[kt0 / VLO_PAGE_TOKENS];
-        const bf16_t *kp = kbase + (size_t)page * kv.page_elems + ((size_t)kvh * VLO_PAGE_TOKENS + kt0 % VLO_PAGE_TOKENS) * HD;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk)
-                dst[t][kk] = *reinterpret_cast<const frag_ab *>(kp + (size_t)(t * 16 + qrow) * HD + kk * 32 + qd * 8);
-    };
-    frag_ab kf[2][NKK], kn[2][NKK];
-    const int kfirst = c0 + ks * 32;
-    if (kfirst < c1) load_k(kfirst, kf);
-    for (int kt0 = kfirst; kt0 < c1; kt0 += KS * 32) {
-        const int page = kv.page_table[kt0 / VLO_PAGE_TOKENS];
-        const int tok0 = kt0 % VLO_PAGE_TOKENS;
-        const bf16_t *vp = vbase + (size_t)page * kv.page_elems + ((size_t)kvh * HD) * VLO_PAGE_TOKENS + tok0;
-        frag_ab vf[NDT];
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            const bf16_t *vr = vp + (size_t)(dt * 16 + qrow) * VLO_PAGE_TOKENS + qd * 4;
-            const uint2 lo = *reinterpret_cast<const uint2 *>(vr);
-            const uint2 hi = *reinterpret_cast<const uint2 *>(vr + 16);
-            vf[dt] = __builtin_bit_cast(frag_ab, make_uint4(lo.x, lo.y, hi.x, hi.y));
-        }
-        const bool more = kt0 + KS * 32 < c1;
-        if (more) load_k(kt0 + KS * 32, kn);
-        const int kb = kt0 + qd * 4;
-#pragma unroll
-        for (int h = 0; h < HPW; ++h) {
-            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-                s0 = mfma_bf16(kf[0][kk], qf[h][kk], s0);
-                s1 = mfma_bf16(kf[1][kk], qf[h][kk], s1);
-            }
-            float v[8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = (kb + r <= qpos) ? s0[r] * scale : -INFINITY;
-                v[4 + r] = (kb + 16 + r <= qpos) ? s1[r] * scale : -INFINITY;
-            }
-            float tmax = v[0];
-#pragma unroll
-            for (int j = 1; j < 8; ++j) tmax = fmaxf(tmax, v[j]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(mrun[h], tmax);
-            const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __expf(mrun[h] - m_safe);
-            mrun[h] = m_new;
-            float psum = 0.f;
-            float p[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                p[j] = __expf(v[j] - m_safe);
-                psum += p[j];
-            }
-            const uint4 pk = make_uint4(pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7]));
-            const frag_ab pb = __builtin_bit_cast(frag_ab, pk);
-            lrun[h] = lrun[h] * alpha + psum;
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                f32x4 o = O[h][dt];
-                o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
-                O[h][dt] = mfma_bf16(vf[dt], pb, o);
-            }
-        }
-        if (more) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int kk = 0; kk < NKK; ++kk) kf[t][kk] = kn[t][kk];
-        }
-    }
-#pragma unroll
-    for (int h = 0; h < HPW; ++h) {
-        lrun[h] += __shfl_xor(lrun[h], 16, 64);
-        lrun[h] += __shfl_xor(lrun[h], 32, 64);
-    }
-    // ---- merge the KS key sub-splits through LDS; waves with ks == 0 keep their state in registers
-    if (KS > 1) {
-        if (ks > 0) {
-            const int slot = (ks - 1) * NHG + hg;
-#pragma unroll
-            for (int h = 0; h < HPW; ++h) {
-                if (qd == 0) {
-                    lds_ml[((slot * HPW + h) * 16 + qrow) * 2] = mrun[h];
-                    lds_ml[((slot * HPW + h) * 16 + qrow) * 2 + 1] = lrun[h];
-                }
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-                    const f32x4 o = O[h][dt];
-                    lds_o[((size_t)(slot * HPW + h) * NDT + dt) * 64 + lane] = make_float4(o[0], o[1], o[2], o[3]);
-                }
-            }
-        }
-        __syncthreads();
-        if (ks > 0) return;
-#pragma unroll
-        for (int h = 0; h < HPW; ++h) {
-            float M = mrun[h];
-            for (int k2 = 1; k2 < KS; ++k2) M = fmaxf(M, lds_ml[((((k2 - 1) * NHG + hg) * HPW + h) * 16 + qrow) * 2]);
-            const float Ms = (M == -INFINITY) ? 0.f : M;
-            const float w0 = __expf(mrun[h] - Ms);             // -inf -> 0
-            float l = lrun[h] * w0;
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) { O[h][dt][0] *= w0; O[h][dt][1] *= w0; O[h][dt][2] *= w0; O[h][dt][3] *= w0; }
-            for (int k2 = 1; k2 < KS; ++k2) {
-                const int slot = (k2 - 1) * NHG + hg;
-                const float mk = lds_ml[((slot * HPW + h) * 16 + qrow) * 2];
-                const float wk = __expf(mk - Ms);
-                l += lds_ml[((slot * HPW + h) * 16 + qrow) * 2 + 1] * wk;
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-                    const float4 o = lds_o[((size_t)(slot * HPW + h) * NDT + dt) * 64 + lane];
-                    O[h][dt][0] += o.x * wk; O[h][dt][1] += o.y * wk; O[h][dt][2] += o.z * wk; O[h][dt][3] += o.w * wk;
-                }
-            }
-            mrun[h] = M;
-            lrun[h] = l;
-        }
-    }
-#pragma unroll
-    for (int h = 0; h < HPW; ++h) {
-        const size_t row = ((size_t)split * nh + head0 + h) * 16 + qrow;
-        if (qd == 0) {
-            part_ml[row * 2] = mrun[h];
-            part_ml[row * 2 + 1] = lrun[h];
-        }
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            const f32x4 o = O[h][dt];
-            *reinterpret_cast<float4 *>(part_o + row * HD + dt * 16 + qd * 4) = make_float4(o[0], o[1], o[2], o[3]);
-        }
-    }
+#define VLO_ATTN_BX blockIdx.x
+#define VLO_ATTN_BY blockIdx.y
+#define VLO_ATTN_BZ blockIdx.z
+#define VLO_ATTN_GX gridDim.x
+#define VLO_ATTN_EXIT return
+#include "attn_body.inc"
+#undef VLO_ATTN_BX
+#undef VLO_ATTN_BY
+#undef VLO_ATTN_BZ
+#undef VLO_ATTN_GX
+#undef VLO_ATTN_EXIT
 }
 
 // grid = (nh, n); block = 256 threads = (256 / HD) split-lanes x HD columns
