@@ -146,6 +146,7 @@ static inline float atomicAdd(float *p, float v) {          // relaxed fp32 atom
 }
 static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 #define __builtin_amdgcn_s_sleep(x) sched_yield()
+#define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(order)
 #define __builtin_nontemporal_load(p) (*(p))
 
 // direct-to-LDS load: every lane's `size` bytes land at the wave-uniform LDS base + lane * size
@@ -264,6 +265,8 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+struct hipDeviceProp_t { int multiProcessorCount; };
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 4; return hipSuccess; }
 static inline hipError_t hipDeviceCanAccessPeer(int *can, int, int) { *can = 0; return hipSuccess; }
 static inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 // Every "device" allocation is a MAP_SHARED mapping: the block-processes of a cooperative launch (emul_launch_concurrent) and

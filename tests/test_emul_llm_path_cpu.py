@@ -358,3 +358,32 @@ def test_step_chunking_boundaries(E, n):
     _, a2 = eng.llm_step(s, x2)
     _three_way(f"chunking n={n} + 3", 1, a2, rl2, gl2)
     eng.close()
+
+
+PERSIST_SPEC = O.LlmSpec(256, 512, 2, 4, 2, 512, 10000.0, 1e-5, vision_hidden_size=128)     # every projection plans 8 waves
+
+
+@pytest.mark.parametrize("blocks", [3] if not FULL else [3, 7])
+def test_persistent_layer_kernel_is_bit_identical(E, blocks, monkeypatch):
+    """VLO_PERSISTENT (csrc/layer.hip): one cooperative launch per decoder layer, its resident blocks walking the same virtual
+    grids with the same kernel bodies between grid barriers (the emulation runs every block in its own process, so the
+    barriers are real).  Same engine, two sessions: the logits must equal the launch-per-phase pipeline's bit for bit."""
+    spec = PERSIST_SPEC
+    w = O.init_llm_weights(spec, seed=31)
+    toks = O.default_tokens(spec)
+    ref, gold = O.LlamaOracle(spec, w, torch.bfloat16), O.LlamaOracle(spec, w, torch.float32)
+    eng = E.EmulEngine(spec).load_weights(w, O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+    monkeypatch.setenv("VLO_PERSISTENT", str(blocks))
+    ps = eng.new_session()
+    monkeypatch.delenv("VLO_PERSISTENT")
+    ds = eng.new_session()
+    rc = gc = None
+    for i, x in enumerate(_steps(spec, ref, toks, 8, [11, 1] + ([16, 3] if FULL else []))):
+        rl, rc = ref.forward(x, rc)
+        gl, gc = gold.forward(x, gc)
+        lp, ap = eng.llm_step(ps, x)
+        ld, ad = eng.llm_step(ds, x)
+        assert eng.session_len(ps) == eng.session_len(ds) == len(rc)
+        _three_way(f"persistent x{blocks}", i, ap, rl, gl)
+        assert torch.equal(ap, ad) and torch.equal(lp, ld), f"step {i}: persistent and launch-per-phase logits differ"
+    eng.close()

@@ -77,6 +77,9 @@ struct vlo_session {
     int64_t len = 0;
     bool has_logits = false;
     int fused_rows = 0;                          // chunks of <= this many rows take run_chunk_fused (VLO_FUSED_ROWS at creation; 0 = off)
+    int persistent_blocks = 0;                   // > 0: 16-row chunks run one persistent launch per layer on this many blocks (VLO_PERSISTENT)
+    unsigned *bar = nullptr;                     // persistent layer kernel: [0] barrier counter, [1] sticky time-out word
+    unsigned bar_issued = 0;                     // arrivals every block has made so far (host-side count, wraps)
     std::vector<int> pages;
     std::vector<void *> owned;
     unsigned short *h = nullptr, *x = nullptr, *act = nullptr, *attn = nullptr, *q = nullptr, *emb1 = nullptr;

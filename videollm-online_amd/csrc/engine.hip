@@ -19,6 +19,7 @@
 #include "common.cuh"
 #include "engine.h"
 #include "gemv.h"
+#include "layer.h"
 #include "llm_ops.h"
 #include "vit.h"
 
@@ -406,6 +407,28 @@ int vlo_session_create(vlo_engine *e, int64_t max_tokens_hint, vlo_session **out
     }
     s->last_logits = s->logits;
     if (const char *v = getenv("VLO_FUSED_ROWS")) s->fused_rows = std::max(0, std::min(16, atoi(v)));
+    if (const char *v = getenv("VLO_PERSISTENT")) {
+        // opt-in: one persistent launch per decoder layer (layer.hip).  The value is the number of resident blocks; 1 means
+        // "one per CU of this device".  Only for models whose four projections all plan 8 waves and an instantiated shape.
+        int nb = atoi(v);
+        if (nb == 1) {
+            hipDeviceProp_t prop;
+            nb = hipGetDeviceProperties(&prop, e->device) == hipSuccess ? prop.multiProcessorCount : 256;
+        }
+        const LayerWeights &L0 = e->layers[0];
+        const int G = c.num_heads / c.num_kv_heads, hpw = (G % 2 == 0) ? 2 : 1;
+        const bool ok = nb > 0 && e->tp_size == 1 && L0.qkv.plan.NW == 8 && L0.o.plan.NW == 8 && L0.gate_up.plan.NW == 8 && L0.down.plan.NW == 8 &&
+                        L0.qkv.plan.KF == L0.o.plan.KF && L0.qkv.plan.KF == L0.gate_up.plan.KF &&
+                        layer_kernel_supports(L0.qkv.plan.KF, L0.down.plan.KF, hd, hpw);
+        if (ok) {
+            A((void **)&s->bar, 256);
+            if (rc) {
+                vlo_session_destroy(s);
+                return rc;
+            }
+            s->persistent_blocks = nb;
+        }
+    }
     HIP_TRY(hipDeviceSynchronize());
     *out = s;
     return VLO_OK;
@@ -625,6 +648,74 @@ static int run_chunk_fused(vlo_session *s, const unsigned short *src, int m, boo
     return VLO_OK;
 }
 
+// Opt-in variant of run_chunk (VLO_PERSISTENT): the same seven phases per decoder layer inside ONE persistent launch
+// (layer.hip), resident blocks walking the same virtual grids with the same kernel bodies between grid barriers — the
+// logits are bit-identical to run_chunk's.  Stage P0 of DESIGN.md §7 item 1 (structure only, no cross-phase prefetch yet).
+static int run_chunk_persistent(vlo_session *s, const unsigned short *src, int m, bool want_last, bool want_all, hipStream_t st) {
+    vlo_engine *e = s->e;
+    const vlo_config &c = e->cfg;
+    const int H = c.hidden_size, I = c.intermediate_size, hd = e->head_dim, nh = c.num_heads;
+    int rc;
+    {
+        unsigned err = 0;
+        HIP_TRY(hipMemcpyAsync(&err, s->bar + 1, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (err) return fail(VLO_E_HIP, "persistent layer kernel: a grid barrier timed out (are all blocks resident?)");
+    }
+    if ((rc = ensure_pages(s, s->len + m, st))) return rc;
+    const KvGeom kv = kv_geom(s);
+    HIP_TRY(copy_rows_launch(src, s->h, m, H, st));
+    AttnGeom ag;
+    HIP_TRY(attention_geometry(kv, nh, s->len, m, &ag));
+    const float *prev = nullptr;
+    int prev_ks = 0;
+    for (int l = 0; l < c.num_layers; ++l) {
+        const LayerWeights &W = e->layers[l];
+        LayerArgs L{};
+        size_t lds = ag.lds_bytes, lb = 0;
+        int gy = 0;
+        L.qkv = gemv_args(W.qkv, s->x, H, m);
+        L.qkv.out_bf16 = s->q; L.qkv.cos_tab = (const unsigned short *)e->cos_tab; L.qkv.sin_tab = (const unsigned short *)e->sin_tab;
+        L.qkv.kv = kv; L.qkv.layer = l; L.qkv.num_heads = nh; L.qkv.pos0 = s->len;
+        HIP_TRY(gemv_prepare(&L.qkv, W.qkv.plan, EPI_ROPE, &L.qkv_gx, &gy, &lb));
+        lds = std::max(lds, lb);
+        L.o = gemv_args(W.o, s->attn, nh * hd, m);
+        L.o.h = s->h; L.o.ldo = H; L.o.sq_out = s->sq[0];
+        HIP_TRY(gemv_prepare(&L.o, W.o.plan, EPI_RESID, &L.o_gx, &gy, &lb));
+        lds = std::max(lds, lb);
+        L.gu = gemv_args(W.gate_up, s->h, H, m);
+        L.gu.norm_w = (const unsigned short *)W.ln_post; L.gu.sq_in = s->sq[0]; L.gu.sq_in_parts = L.o_gx; L.gu.eps = c.rms_eps;
+        L.gu.out_bf16 = s->act; L.gu.ldo = I;
+        HIP_TRY(gemv_prepare(&L.gu, W.gate_up.plan, EPI_SWIGLU, &L.gu_gx, &gy, &lb));
+        lds = std::max(lds, lb);
+        L.down = gemv_args(W.down, s->act, I, m);
+        L.down.out_f32 = s->partial; L.down.ldo = H;
+        HIP_TRY(gemv_prepare(&L.down, W.down.plan, EPI_PARTIAL_F32, &L.down_gx, &L.down_gy, &lb));
+        lds = std::max(lds, lb);
+        L.h = s->h; L.prev = prev; L.prev_ks = prev_ks; L.ln_in = (const unsigned short *)W.ln_in; L.x = s->x; L.H = H; L.m = m; L.eps = c.rms_eps;
+        L.q = s->q; L.kv = kv; L.layer = l; L.nh = nh; L.G = ag.G; L.KS = ag.KS; L.chunk = ag.chunk; L.nsplit = ag.nsplit;
+        L.attn_threads = ag.nhg * ag.KS * 64; L.pos0 = s->len; L.scale = ag.scale;
+        L.part_o = s->part_o; L.part_ml = s->part_ml; L.attn_out = s->attn;
+        L.bar_counter = s->bar; L.bar_err = s->bar + 1; L.bar_base = s->bar_issued;
+        L.bar_timeout_ticks = 200000000;              // 2 s of the 100 MHz counter
+        HIP_TRY(layer_launch(L, W.qkv.plan.KF, W.down.plan.KF, hd, ag.hpw, s->persistent_blocks, lds, st));
+        s->bar_issued += (unsigned)layer_barriers_per_launch() * (unsigned)s->persistent_blocks;
+        prev = s->partial;
+        prev_ks = W.down.plan.ksplit;
+    }
+    if (want_last || want_all) {
+        HIP_TRY(add_rmsnorm_launch(s->h, prev, prev_ks, H, (const unsigned short *)e->norm_w, s->x, H, H, c.rms_eps, m, st));
+        const int r0 = want_all ? 0 : m - 1, nr = want_all ? m : 1;
+        GemvArgs a = gemv_args(e->lm_head, s->x + (size_t)r0 * H, H, nr);
+        a.out_bf16 = s->logits; a.ldo = c.vocab_size;
+        HIP_TRY(gemv_launch(a, e->lm_head.plan, XSRC_PLAIN, EPI_BF16, st));
+        s->last_logits = s->logits + (size_t)(nr - 1) * c.vocab_size;
+        s->has_logits = true;
+    }
+    s->len += m;
+    return VLO_OK;
+}
+
 // one chunk of m <= 16 new tokens whose embeddings are at `src`.  Per decoder layer (7 launches):
 //   add_rmsnorm   [+ down-proj split-K combine + residual of the previous layer]      -> x
 //   qkv GEMV      [RoPE + paged KV append in the epilogue]                             -> q, K, V^T
@@ -635,6 +726,7 @@ static int run_chunk_fused(vlo_session *s, const unsigned short *src, int m, boo
 static int run_chunk(vlo_session *s, const unsigned short *src, int m, bool want_last, bool want_all, hipStream_t st) {
     static const bool fuse_norm = getenv("VLO_FUSE_NORM") ? atoi(getenv("VLO_FUSE_NORM")) != 0 : true;
     if (m <= s->fused_rows) return run_chunk_fused(s, src, m, want_last, want_all, st);
+    if (s->persistent_blocks > 0) return run_chunk_persistent(s, src, m, want_last, want_all, st);
     vlo_engine *e = s->e;
     const vlo_config &c = e->cfg;
     const int H = c.hidden_size, I = c.intermediate_size, hd = e->head_dim, nh = c.num_heads;

@@ -53,6 +53,9 @@ int gemv_plan(int K, bool allow_ksplit, GemvPlan *p);
 // grid.x the launch will use (= number of sq_out partial rows an EPI_RESID launch writes)
 int gemv_grid_x(const GemvArgs &a, const GemvPlan &p, int epi);
 hipError_t gemv_launch(GemvArgs a, const GemvPlan &p, int xsrc, int epi, hipStream_t st);
+// what gemv_launch does before it launches: validates, fills the launch-dependent fields of `a` (CT, KC) and returns the grid
+// and the dynamic LDS size — for callers that run the kernel body themselves (layer.hip)
+hipError_t gemv_prepare(GemvArgs *a, const GemvPlan &p, int epi, int *grid_x, int *grid_y, size_t *lds_bytes);
 // source tiles [0,NT) of row-major W[N_valid][K] (row stride ldw elements) -> packed tiles t*tile_stride + tile_offset of Wp
 // half = -1: 16-row tiles; half = 0/1: 8-row interleave of two matrices into one tile (gate / up)
 hipError_t pack_weight_launch(const void *W, void *Wp, int N_valid, int K, int ldw, int NT, int tile_stride, int tile_offset,

@@ -179,13 +179,23 @@ static hipError_t launch_variant(const GemvArgs &a, int xsrc, int epi, dim3 grid
     return hipErrorInvalidValue;
 }
 
-hipError_t gemv_launch(GemvArgs a, const GemvPlan &p, int xsrc, int epi, hipStream_t st) {
+hipError_t gemv_prepare(GemvArgs *a, const GemvPlan &p, int epi, int *grid_x, int *grid_y, size_t *lds_bytes) {
     if (epi != EPI_PARTIAL_F32 && p.ksplit != 1) return hipErrorInvalidValue;
-    if (epi == EPI_ROPE && ((a.NT & 1) || (a.kv.head_dim != 64 && a.kv.head_dim != 128))) return hipErrorInvalidValue;
-    a.CT = single_tile_groups(a, p, epi) ? 1 : 2;
-    a.KC = p.KC;
-    dim3 grid(gemv_grid_x(a, p, epi), p.ksplit);
-    const size_t lds = (size_t)2 * p.NW * 2 * 64 * sizeof(float4) + (16 + (size_t)p.NW * 4 * 16) * sizeof(float);
+    if (epi == EPI_ROPE && ((a->NT & 1) || (a->kv.head_dim != 64 && a->kv.head_dim != 128))) return hipErrorInvalidValue;
+    a->CT = single_tile_groups(*a, p, epi) ? 1 : 2;
+    a->KC = p.KC;
+    *grid_x = gemv_grid_x(*a, p, epi);
+    *grid_y = p.ksplit;
+    *lds_bytes = (size_t)2 * p.NW * 2 * 64 * sizeof(float4) + (16 + (size_t)p.NW * 4 * 16) * sizeof(float);
+    return hipSuccess;
+}
+
+hipError_t gemv_launch(GemvArgs a, const GemvPlan &p, int xsrc, int epi, hipStream_t st) {
+    int gx = 0, gy = 0;
+    size_t lds = 0;
+    const hipError_t pe = gemv_prepare(&a, p, epi, &gx, &gy, &lds);
+    if (pe != hipSuccess) return pe;
+    dim3 grid(gx, gy);
 #define VLO_CASE(NW_, KF_) \
     if (p.NW == NW_ && p.KF == KF_) return launch_variant<KF_, NW_>(a, xsrc, epi, grid, lds, st);
     VLO_CASE(8, 16) VLO_CASE(8, 14) VLO_CASE(8, 11) VLO_CASE(8, 8) VLO_CASE(8, 4) VLO_CASE(8, 2) VLO_CASE(8, 1)

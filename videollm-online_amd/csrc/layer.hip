@@ -1,0 +1,215 @@
+// layer.hip — one decoder layer of the 16-row Llama step as ONE persistent launch (opt-in: VLO_PERSISTENT=1).
+//
+// Stage P0 of DESIGN.md §7 item 1: the seven phases of run_chunk's layer
+//     add_rmsnorm -> qkv GEMV [RoPE + KV append] -> chunk attention -> combine -> o GEMV [residual, sum of squares]
+//     -> gate/up GEMV [RMSNorm on load, SwiGLU] -> down GEMV [K-split partials]
+// run inside one kernel whose resident blocks (one per CU) walk the SAME virtual grids with the SAME kernel bodies
+// (gemv_body.inc, attn_body.inc, rmsnorm_body.inc are included textually here and in the stand-alone kernels), separated by
+// grid barriers.  Results are bit-identical to the launch-per-phase pipeline by construction; this stage adds nothing but
+// the structure — the point of the structure, streaming the next phase's weights through the barrier, is the next stage.
+//
+// Grid barrier: one monotonic counter; every block arrives once per barrier and waits for base + k * gridDim.x.  Memory
+// hand-off follows cdna_hip_programming.md §6 Guideline 16: every wave drains its stores, block barrier, ONE lane does the
+// agent-scope release fence (+ the asm wait the compiler may not drop), the relaxed arrive, a relaxed sc1 poll with
+// s_sleep, ONE agent-scope acquire fence, block barrier, then plain loads.  The spin is bounded (s_memrealtime).
+#include <stdlib.h>
+
+#include "common.cuh"
+#include "gemv.h"
+#include "layer.h"
+#include "llm_ops.h"
+
+typedef __attribute__((address_space(1))) unsigned int lgu32;
+
+VLO_DEV void grid_barrier(unsigned *counter, unsigned target, unsigned *err, long long timeout_ticks) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every wave: its global stores have left the CU
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the write-back is complete before the arrival is visible
+        __hip_atomic_fetch_add((lgu32 *)counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long t0 = wall_clock64();
+        while ((int)(__hip_atomic_load((lgu32 *)counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            if (wall_clock64() - t0 > timeout_ticks) {             // a block that is not resident, or a dead peer: do not hang
+                __hip_atomic_fetch_or((lgu32 *)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+// ---- the phase bodies, from the same text as the stand-alone kernels ------------------------------------------------------
+// (rounding points follow the reference's bf16 CPU path — see gemv.hip / llm_ops.hip)
+VLO_DEV float silu_bf16(float g) { return rbf(g / (1.0f + __expf(-g))); }
+VLO_DEV float gelu_python_bf16(float x) {
+    const float a = rbf(x * 0.5f);
+    const float t = rbf(x / 1.4142135623730951f);
+    const float e = rbf(erff(t));
+    const float s = rbf(1.0f + e);
+    return rbf(a * s);
+}
+VLO_DEV float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+template <int KF, int NW, int XSRC, int EPI>
+VLO_DEV void gemv16_dev(const GemvArgs &a, const int vbx, const int vby, const int vgx, float4 *red) {
+#define VLO_GEMV_BX vbx
+#define VLO_GEMV_BY vby
+#define VLO_GEMV_GX vgx
+#include "gemv_body.inc"
+#undef VLO_GEMV_BX
+#undef VLO_GEMV_BY
+#undef VLO_GEMV_GX
+}
+
+template <int HD, int HPW>
+VLO_DEV void attn_chunk_dev(const bf16_t *q, KvGeom kv, int layer, int nh, int G, int KS, int64_t pos0, int n, int chunk, float scale,
+                            float *part_o, float *part_ml, const int vbx, const int vby, const int vgx, float4 *lds_o) {
+    do {                                                           // VLO_ATTN_EXIT leaves the body, not the kernel
+#define VLO_ATTN_BX vbx
+#define VLO_ATTN_BY vby
+#define VLO_ATTN_BZ 0
+#define VLO_ATTN_GX vgx
+#define VLO_ATTN_EXIT break
+#include "attn_body.inc"
+#undef VLO_ATTN_BX
+#undef VLO_ATTN_BY
+#undef VLO_ATTN_BZ
+#undef VLO_ATTN_GX
+#undef VLO_ATTN_EXIT
+    } while (0);
+}
+
+#define RMS_THREADS 512
+#define RMS_MAXCH 2
+VLO_DEV void add_rmsnorm_dev(bf16_t *h, const float *partial, int ksplit, int partial_ld, const bf16_t *w, bf16_t *x, int H, int ldx,
+                             float eps, const int row) {
+#define VLO_RMS_ROW row
+#include "rmsnorm_body.inc"
+#undef VLO_RMS_ROW
+}
+
+// attn_combine_kernel's arithmetic (llm_ops.hip) for TWO (head, query row) items at a time: threads 0..255 take item `it0`,
+// threads 256..511 item `it0 + 1`; the loop trip count is uniform over the block (the barriers inside are block-wide)
+VLO_DEV void combine_dev(const float *part_o, const float *part_ml, int nsplit, int nh, int HD, int m, bf16_t *out, int bid, int nblocks) {
+    __shared__ float wgt[2][VLO_MAX_SPLITS];
+    __shared__ float red2[2][256];
+    __shared__ float Ltot[2];
+    const int half = threadIdx.x >> 8, t = threadIdx.x & 255;
+    const int items = nh * m;
+    for (int it0 = bid * 2; it0 < items; it0 += nblocks * 2) {
+        const int it = it0 + half;
+        const bool live = it < items;
+        const int head = live ? it % nh : 0, qrow = live ? it / nh : 0;
+        if (t < 64) {                                  // one wave per half: softmax weights of the splits
+            float ms = -INFINITY, ls = 0.f;
+            if (live && t < nsplit) {
+                const size_t row = ((size_t)t * nh + head) * 16 + qrow;
+                ms = part_ml[row * 2];
+                ls = part_ml[row * 2 + 1];
+            }
+            const float M = wave_max(ms);
+            const float wv = (ms == -INFINITY) ? 0.f : __expf(ms - M);
+            const float Ls = wave_sum(ls * wv);
+            if (t < nsplit) wgt[half][t] = wv;
+            if (t == 0) Ltot[half] = Ls;
+        }
+        __syncthreads();
+        const int d = t % HD, ql = t / HD, nql = 256 / HD;
+        float acc = 0.f;
+        if (live)
+            for (int s = ql; s < nsplit; s += nql) acc += part_o[(((size_t)s * nh + head) * 16 + qrow) * HD + d] * wgt[half][s];
+        red2[half][t] = acc;
+        __syncthreads();
+        if (live && ql == 0) {
+            for (int k2 = 1; k2 < nql; ++k2) acc += red2[half][k2 * HD + d];
+            out[(size_t)qrow * nh * HD + (size_t)head * HD + d] = f2bf(acc / Ltot[half]);
+        }
+        __syncthreads();                               // wgt / red2 / Ltot are rewritten by the next pair of items
+    }
+}
+
+template <int KFH, int KFI, int HD, int HPW>
+__global__ __launch_bounds__(512) void llm_layer_kernel(LayerArgs L) {
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];
+    const int nb = gridDim.x, bid = blockIdx.x;
+    unsigned target = L.bar_base;
+#define VLO_BARRIER() grid_barrier(L.bar_counter, target += (unsigned)nb, L.bar_err, L.bar_timeout_ticks)
+    // phase 0: h (+)= bf16(sum of the previous layer's down-proj slices); x = RMSNorm(h) * w_in
+    for (int vb = bid; vb < L.m; vb += nb) {
+        add_rmsnorm_dev(L.h, L.prev, L.prev_ks, L.H, L.ln_in, L.x, L.H, L.H, L.eps, vb);
+        __syncthreads();
+    }
+    VLO_BARRIER();
+    // phase 1: q, k, v = x W^T; RoPE; K / V^T appended to the session's pages
+    for (int vb = bid; vb < L.qkv_gx; vb += nb) {
+        gemv16_dev<KFH, 8, XSRC_PLAIN, EPI_ROPE>(L.qkv, vb, 0, L.qkv_gx, lds);
+        __syncthreads();
+    }
+    VLO_BARRIER();
+    // phase 2: split-KV attention partials, virtual grid (nsplit, kv heads)
+    {
+        const int items = L.nsplit * L.kv.num_kv_heads;
+        for (int vb = bid; vb < items; vb += nb) {
+            // the attention body is written for (head groups x key sub-splits) waves; surplus waves of this block only keep
+            // the body's one block barrier (the key sub-split merge) company
+            if ((int)threadIdx.x < L.attn_threads)
+                attn_chunk_dev<HD, HPW>(L.q, L.kv, L.layer, L.nh, L.G, L.KS, L.pos0, L.m, L.chunk, L.scale, L.part_o, L.part_ml,
+                                        vb % L.nsplit, vb / L.nsplit, L.nsplit, lds);
+            else if (L.KS > 1)
+                __syncthreads();
+            __syncthreads();
+        }
+    }
+    VLO_BARRIER();
+    // phase 3: merge the splits
+    combine_dev(L.part_o, L.part_ml, L.nsplit, L.nh, HD, L.m, L.attn_out, bid, nb);
+    VLO_BARRIER();
+    // phase 4: h += bf16(attn W_o^T), row sums of squares of the new h
+    for (int vb = bid; vb < L.o_gx; vb += nb) {
+        gemv16_dev<KFH, 8, XSRC_PLAIN, EPI_RESID>(L.o, vb, 0, L.o_gx, lds);
+        __syncthreads();
+    }
+    VLO_BARRIER();
+    // phase 5: act = silu(gate) * up, post-attention RMSNorm on the operand load
+    for (int vb = bid; vb < L.gu_gx; vb += nb) {
+        gemv16_dev<KFH, 8, XSRC_NORM, EPI_SWIGLU>(L.gu, vb, 0, L.gu_gx, lds);
+        __syncthreads();
+    }
+    VLO_BARRIER();
+    // phase 6: down-proj K-slice partials (combined by the next layer's phase 0, or by add_rmsnorm after the last layer)
+    for (int vb = bid; vb < L.down_gx * L.down_gy; vb += nb) {
+        gemv16_dev<KFI, 8, XSRC_PLAIN, EPI_PARTIAL_F32>(L.down, vb % L.down_gx, vb / L.down_gx, L.down_gx, lds);
+        __syncthreads();
+    }
+#undef VLO_BARRIER
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------------------
+int layer_barriers_per_launch(void) { return 6; }
+
+template <int KFH, int KFI, int HD, int HPW>
+static hipError_t launch_one(LayerArgs &L, int nblocks, size_t lds, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void *)llm_layer_kernel<KFH, KFI, HD, HPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    void *params[] = {&L};
+    return hipLaunchCooperativeKernel(llm_layer_kernel<KFH, KFI, HD, HPW>, dim3(nblocks), dim3(512), params, (unsigned)lds, st);
+}
+
+bool layer_kernel_supports(int kf_h, int kf_i, int head_dim, int hpw) {
+    return (kf_h == 16 && kf_i == 14 && head_dim == 128 && hpw == 2) ||      // Llama-3-8B
+           (kf_h == 8 && kf_i == 11 && head_dim == 64 && hpw == 2) ||        // TinyLlama-1.1B
+           (kf_h == 1 && kf_i == 2 && head_dim == 64 && hpw == 2);           // 256 / 512-wide test model (tests/hip_emul)
+}
+
+hipError_t layer_launch(LayerArgs &L, int kf_h, int kf_i, int head_dim, int hpw, int nblocks, size_t lds, hipStream_t st) {
+    if (kf_h == 16 && kf_i == 14 && head_dim == 128 && hpw == 2) return launch_one<16, 14, 128, 2>(L, nblocks, lds, st);
+    if (kf_h == 8 && kf_i == 11 && head_dim == 64 && hpw == 2) return launch_one<8, 11, 64, 2>(L, nblocks, lds, st);
+    if (kf_h == 1 && kf_i == 2 && head_dim == 64 && hpw == 2) return launch_one<1, 2, 64, 2>(L, nblocks, lds, st);
+    return hipErrorInvalidValue;
+}

@@ -25,64 +25,9 @@
 __global__ __launch_bounds__(RMS_THREADS) void add_rmsnorm_kernel(bf16_t *__restrict__ h, const float *__restrict__ partial,
                                                                   int ksplit, int partial_ld, const bf16_t *__restrict__ w,
                                                                   bf16_t *__restrict__ x, int H, int ldx, float eps) {
-    __shared__ float sm[16];
-    const int m = blockIdx.x;
-    bf16_t *hr = h + (size_t)m * H;
-    float v[RMS_MAXCH][8];
-    float ss = 0.f;
-    const int nch = H >> 3;
-#pragma unroll
-    for (int c = 0; c < RMS_MAXCH; ++c) {
-        const int ch = threadIdx.x + c * RMS_THREADS;
-        if (ch < nch) {
-            const uint4 raw = *reinterpret_cast<const uint4 *>(hr + ch * 8);
-            const bf16_t *e = reinterpret_cast<const bf16_t *>(&raw);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[c][j] = bf2f(e[j]);
-            if (partial) {
-                float d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int s = 0; s < ksplit; ++s) {
-                    const float4 *pp = reinterpret_cast<const float4 *>(partial + ((size_t)s * 16 + m) * partial_ld + ch * 8);
-                    const float4 a = pp[0], b = pp[1];
-                    d[0] += a.x; d[1] += a.y; d[2] += a.z; d[3] += a.w;
-                    d[4] += b.x; d[5] += b.y; d[6] += b.z; d[7] += b.w;
-                }
-                uint4 o;
-                bf16_t *oe = reinterpret_cast<bf16_t *>(&o);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {          // linear output -> bf16, then bf16 residual add
-                    v[c][j] = rbf(v[c][j] + rbf(d[j]));
-                    oe[j] = f2bf(v[c][j]);
-                }
-                *reinterpret_cast<uint4 *>(hr + ch * 8) = o;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ss += v[c][j] * v[c][j];
-        }
-    }
-    // norm weights are fetched BEFORE the block-wide reduction so their latency hides behind its two barriers
-    uint4 wraw[RMS_MAXCH];
-#pragma unroll
-    for (int c = 0; c < RMS_MAXCH; ++c) {
-        const int ch = threadIdx.x + c * RMS_THREADS;
-        wraw[c] = (ch < nch) ? *reinterpret_cast<const uint4 *>(w + ch * 8) : make_uint4(0, 0, 0, 0);
-    }
-    ss = block_sum(ss, sm);
-    const float rs = 1.0f / sqrtf(ss / (float)H + eps);
-    bf16_t *xr = x + (size_t)m * ldx;
-#pragma unroll
-    for (int c = 0; c < RMS_MAXCH; ++c) {
-        const int ch = threadIdx.x + c * RMS_THREADS;
-        if (ch < nch) {
-            const bf16_t *we = reinterpret_cast<const bf16_t *>(&wraw[c]);
-            uint4 o;
-            bf16_t *oe = reinterpret_cast<bf16_t *>(&o);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) oe[j] = f2bf(bf2f(we[j]) * rbf(v[c][j] * rs));   // weight * x.to(bf16)
-            bf16_t *dst = ldx ? xr + ch * 8 : x + vlo_pack64_elem(m, ch * 8);            // ldx == 0: packed-64 (block path)
-            *reinterpret_cast<uint4 *>(dst) = o;
-        }
-    }
+#define VLO_RMS_ROW blockIdx.x
+#include "rmsnorm_body.inc"
+#undef VLO_RMS_ROW
 }
 
 hipError_t add_rmsnorm_launch(unsigned short *h, const float *partial, int ksplit, int partial_ld, const unsigned short *w,
@@ -189,8 +134,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restri
     }
 }
 
-hipError_t attention_launch(const unsigned short *q, KvGeom kv, int layer, int num_heads, int64_t pos0, int n,
-                            float *part_o, float *part_ml, unsigned short *out, hipStream_t st, int pack_row0) {
+hipError_t attention_geometry(const KvGeom &kv, int num_heads, int64_t pos0, int n, AttnGeom *g) {
     const int nkv = kv.num_kv_heads, hd = kv.head_dim, G = num_heads / nkv;
     const int L = (int)(pos0 + n);
     const int hpw = (G % 2 == 0) ? 2 : 1;
@@ -215,10 +159,23 @@ hipError_t attention_launch(const unsigned short *q, KvGeom kv, int layer, int n
     if (target < 1) target = 1;
     int chunk = (L + target - 1) / target;
     chunk = (chunk + 31) & ~31;
-    const int nsplit = (L + chunk - 1) / chunk;
-    const float scale = 1.0f / sqrtf((float)hd);
+    g->G = G; g->KS = KS; g->hpw = hpw; g->nhg = nhg; g->nz = nz; g->chunk = chunk;
+    g->nsplit = (L + chunk - 1) / chunk;
+    g->scale = 1.0f / sqrtf((float)hd);
+    g->lds_bytes = (size_t)(KS - 1) * nhg * hpw * ((size_t)(hd / 16) * 64 * 16 + 16 * 2 * 4);
+    return hipSuccess;
+}
+
+hipError_t attention_launch(const unsigned short *q, KvGeom kv, int layer, int num_heads, int64_t pos0, int n,
+                            float *part_o, float *part_ml, unsigned short *out, hipStream_t st, int pack_row0) {
+    AttnGeom ag;
+    const hipError_t ge = attention_geometry(kv, num_heads, pos0, n, &ag);
+    if (ge != hipSuccess) return ge;
+    const int nkv = kv.num_kv_heads, hd = kv.head_dim, G = ag.G, hpw = ag.hpw, nhg = ag.nhg, KS = ag.KS, nz = ag.nz, chunk = ag.chunk,
+              nsplit = ag.nsplit;
+    const float scale = ag.scale;
     dim3 grid(nsplit, nkv, nz), block(nhg * KS * 64);
-    const size_t lds = (size_t)(KS - 1) * nhg * hpw * ((size_t)(hd / 16) * 64 * 16 + 16 * 2 * 4);
+    const size_t lds = ag.lds_bytes;
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute((const void *)attn_chunk_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
