@@ -204,7 +204,7 @@ static hipError_t launch_one(LayerArgs &L, int nblocks, size_t lds, hipStream_t 
 bool layer_kernel_supports(int kf_h, int kf_i, int head_dim, int hpw) {
     return (kf_h == 16 && kf_i == 14 && head_dim == 128 && hpw == 2) ||      // Llama-3-8B
            (kf_h == 8 && kf_i == 11 && head_dim == 64 && hpw == 2) ||        // TinyLlama-1.1B
-           (kf_h == 1 && kf_i == 2 && head_dim == 64 && hpw == 2);           // 256 / 512-wide test model (tests/hip_emul)
+           (kf_h == 1 && kf_i == 2 && head_dim == 64 && hpw == 2);           // 256 / 512-wide model of the unit tests
 }
 
 hipError_t layer_launch(LayerArgs &L, int kf_h, int kf_i, int head_dim, int hpw, int nblocks, size_t lds, hipStream_t st) {
