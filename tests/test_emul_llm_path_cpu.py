@@ -360,7 +360,7 @@ def test_step_chunking_boundaries(E, n):
     eng.close()
 
 
-PERSIST_SPEC = O.LlmSpec(256, 512, 2, 4, 2, 512, 10000.0, 1e-5, vision_hidden_size=128)     # every projection plans 8 waves
+PERSIST_SPEC = O.LlmSpec(256, 768, 2, 4, 2, 512, 10000.0, 1e-5, vision_hidden_size=128)     # every projection plans 8 waves; down-proj in 3 K slices
 
 
 @pytest.mark.parametrize("blocks", [3] if not FULL else [3, 7])
@@ -373,6 +373,7 @@ def test_persistent_layer_kernel_is_bit_identical(E, blocks, monkeypatch):
     toks = O.default_tokens(spec)
     ref, gold = O.LlamaOracle(spec, w, torch.bfloat16), O.LlamaOracle(spec, w, torch.float32)
     eng = E.EmulEngine(spec).load_weights(w, O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+    assert E.gemv_plan(spec.intermediate_size, True) == (8, 1, 1, 3) and E.gemv_plan(spec.hidden_size, False) == (8, 1, 1, 1)
     monkeypatch.setenv("VLO_PERSISTENT", str(blocks))
     ps = eng.new_session()
     monkeypatch.delenv("VLO_PERSISTENT")

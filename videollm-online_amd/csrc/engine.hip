@@ -698,6 +698,10 @@ static int run_chunk_persistent(vlo_session *s, const unsigned short *src, int m
         L.part_o = s->part_o; L.part_ml = s->part_ml; L.attn_out = s->attn;
         L.bar_counter = s->bar; L.bar_err = s->bar + 1; L.bar_base = s->bar_issued;
         L.bar_timeout_ticks = 200000000;              // 2 s of the 100 MHz counter
+        {
+            static const int pf = getenv("VLO_PERSISTENT_PREFETCH") ? atoi(getenv("VLO_PERSISTENT_PREFETCH")) : 1;
+            L.prefetch = pf;
+        }
         HIP_TRY(layer_launch(L, W.qkv.plan.KF, W.down.plan.KF, hd, ag.hpw, s->persistent_blocks, lds, st));
         s->bar_issued += (unsigned)layer_barriers_per_launch() * (unsigned)s->persistent_blocks;
         prev = s->partial;

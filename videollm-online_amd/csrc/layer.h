@@ -30,6 +30,7 @@ struct LayerArgs {
     unsigned *bar_counter, *bar_err;
     unsigned bar_base;
     long long bar_timeout_ticks;
+    int prefetch;                 // 1: next-phase weight fragments are put in flight before each grid barrier (stage P1)
 };
 
 int layer_barriers_per_launch(void);

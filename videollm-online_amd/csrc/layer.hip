@@ -5,8 +5,9 @@
 //     -> gate/up GEMV [RMSNorm on load, SwiGLU] -> down GEMV [K-split partials]
 // run inside one kernel whose resident blocks (one per CU) walk the SAME virtual grids with the SAME kernel bodies
 // (gemv_body.inc, attn_body.inc, rmsnorm_body.inc are included textually here and in the stand-alone kernels), separated by
-// grid barriers.  Results are bit-identical to the launch-per-phase pipeline by construction; this stage adds nothing but
-// the structure — the point of the structure, streaming the next phase's weights through the barrier, is the next stage.
+// grid barriers.  Results are bit-identical to the launch-per-phase pipeline by construction.  Stage P1 (LayerArgs.prefetch):
+// a block waiting at the barrier in front of a GEMV phase already has its first weight fragments of that phase in flight,
+// so the HBM stream runs through the phase change instead of restarting after it.
 //
 // Grid barrier: one monotonic counter; every block arrives once per barrier and waits for base + k * gridDim.x.  Memory
 // hand-off follows cdna_hip_programming.md §6 Guideline 16: every wave drains its stores, block barrier, ONE lane does the
@@ -21,13 +22,22 @@
 
 typedef __attribute__((address_space(1))) unsigned int lgu32;
 
-VLO_DEV void grid_barrier(unsigned *counter, unsigned target, unsigned *err, long long timeout_ticks) {
+// `prefetch`: what this block wants in flight while it waits (the next GEMV phase's first weight fragments).  Seven of the
+// eight waves issue it right after their stores have drained; the leader wave only after its arrival is out, because its
+// release / acquire sequence waits on vmcnt(0), which counts those loads too.
+template <class F>
+VLO_DEV void grid_barrier(unsigned *counter, unsigned target, unsigned *err, long long timeout_ticks, F prefetch) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every wave: its global stores have left the CU
+    const bool leader_wave = threadIdx.x < 64;
+    if (!leader_wave) prefetch();
     __syncthreads();
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the write-back is complete before the arrival is visible
         __hip_atomic_fetch_add((lgu32 *)counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (leader_wave) prefetch();
+    if (threadIdx.x == 0) {
         const long long t0 = wall_clock64();
         while ((int)(__hip_atomic_load((lgu32 *)counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
             if (wall_clock64() - t0 > timeout_ticks) {             // a block that is not resident, or a dead peer: do not hang
@@ -53,15 +63,31 @@ VLO_DEV float gelu_python_bf16(float x) {
 }
 VLO_DEV float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
+// the first weight fragments of virtual block (vbx, vby): the geometry text of the GEMV body, nothing else
+template <int KF, int NW, int EPI>
+VLO_DEV void gemv16_preload(const GemvArgs &a, const int vbx, const int vby, float4 *red, frag_ab (&pre)[KF]) {
+#define VLO_GEMV_BX vbx
+#define VLO_GEMV_BY vby
+#include "gemv_head.inc"
+#undef VLO_GEMV_BX
+#undef VLO_GEMV_BY
+    (void)rs_lds; (void)tmp_lds; (void)m16; (void)qd; (void)tile_b;
+#pragma unroll
+    for (int kf = 0; kf < KF; ++kf) pre[kf] = wr[kf];
+}
+
+// the GEMV body for virtual block (vbx, vby) of a (vgx, *) grid whose first fragments are already in `pre`
 template <int KF, int NW, int XSRC, int EPI>
-VLO_DEV void gemv16_dev(const GemvArgs &a, const int vbx, const int vby, const int vgx, float4 *red) {
+VLO_DEV void gemv16_dev(const GemvArgs &a, const int vbx, const int vby, const int vgx, float4 *red, const frag_ab (&pre)[KF]) {
 #define VLO_GEMV_BX vbx
 #define VLO_GEMV_BY vby
 #define VLO_GEMV_GX vgx
+#define VLO_GEMV_PRELOADED pre
 #include "gemv_body.inc"
 #undef VLO_GEMV_BX
 #undef VLO_GEMV_BY
 #undef VLO_GEMV_GX
+#undef VLO_GEMV_PRELOADED
 }
 
 template <int HD, int HPW>
@@ -136,19 +162,31 @@ __global__ __launch_bounds__(512) void llm_layer_kernel(LayerArgs L) {
     extern __shared__ __attribute__((aligned(16))) float4 lds[];
     const int nb = gridDim.x, bid = blockIdx.x;
     unsigned target = L.bar_base;
-#define VLO_BARRIER() grid_barrier(L.bar_counter, target += (unsigned)nb, L.bar_err, L.bar_timeout_ticks)
+    // Cross-phase prefetch (L.prefetch): while a block waits at the barrier in front of a GEMV phase, the first weight
+    // fragments of ITS first virtual block of that phase are already in flight (16 KiB per wave at KF = 16), so the HBM
+    // stream does not stop for the barrier and the phase starts on loaded registers.  `have` = preH / preI hold them.
+    frag_ab preH[KFH], preI[KFI];
+    bool have = false;
+    auto nothing = []() {};
+#define VLO_BARRIER(...) grid_barrier(L.bar_counter, target += (unsigned)nb, L.bar_err, L.bar_timeout_ticks, __VA_ARGS__)
+#define VLO_GEMV_PHASE(KF_, XSRC_, EPI_, ARGS_, GX_, GY_, PRE_)                                                          \
+    for (int vb = bid; vb < (GX_) * (GY_); vb += nb) {                                                                    \
+        if (!(have && vb == bid)) gemv16_preload<KF_, 8, EPI_>(ARGS_, vb % (GX_), vb / (GX_), lds, PRE_);                 \
+        gemv16_dev<KF_, 8, XSRC_, EPI_>(ARGS_, vb % (GX_), vb / (GX_), GX_, lds, PRE_);                                   \
+        __syncthreads();                                                                                                  \
+    }                                                                                                                     \
+    have = false
     // phase 0: h (+)= bf16(sum of the previous layer's down-proj slices); x = RMSNorm(h) * w_in
     for (int vb = bid; vb < L.m; vb += nb) {
         add_rmsnorm_dev(L.h, L.prev, L.prev_ks, L.H, L.ln_in, L.x, L.H, L.H, L.eps, vb);
         __syncthreads();
     }
-    VLO_BARRIER();
+    VLO_BARRIER([&]() {
+        if (L.prefetch && bid < L.qkv_gx) { gemv16_preload<KFH, 8, EPI_ROPE>(L.qkv, bid, 0, lds, preH); have = true; }
+    });
     // phase 1: q, k, v = x W^T; RoPE; K / V^T appended to the session's pages
-    for (int vb = bid; vb < L.qkv_gx; vb += nb) {
-        gemv16_dev<KFH, 8, XSRC_PLAIN, EPI_ROPE>(L.qkv, vb, 0, L.qkv_gx, lds);
-        __syncthreads();
-    }
-    VLO_BARRIER();
+    VLO_GEMV_PHASE(KFH, XSRC_PLAIN, EPI_ROPE, L.qkv, L.qkv_gx, 1, preH);
+    VLO_BARRIER(nothing);
     // phase 2: split-KV attention partials, virtual grid (nsplit, kv heads)
     {
         const int items = L.nsplit * L.kv.num_kv_heads;
@@ -163,27 +201,28 @@ __global__ __launch_bounds__(512) void llm_layer_kernel(LayerArgs L) {
             __syncthreads();
         }
     }
-    VLO_BARRIER();
+    VLO_BARRIER([&]() {      // o_proj's fragments stay in registers across the (light) combine phase
+        if (L.prefetch && bid < L.o_gx) { gemv16_preload<KFH, 8, EPI_RESID>(L.o, bid, 0, lds, preH); have = true; }
+    });
     // phase 3: merge the splits
     combine_dev(L.part_o, L.part_ml, L.nsplit, L.nh, HD, L.m, L.attn_out, bid, nb);
-    VLO_BARRIER();
+    VLO_BARRIER(nothing);
     // phase 4: h += bf16(attn W_o^T), row sums of squares of the new h
-    for (int vb = bid; vb < L.o_gx; vb += nb) {
-        gemv16_dev<KFH, 8, XSRC_PLAIN, EPI_RESID>(L.o, vb, 0, L.o_gx, lds);
-        __syncthreads();
-    }
-    VLO_BARRIER();
+    VLO_GEMV_PHASE(KFH, XSRC_PLAIN, EPI_RESID, L.o, L.o_gx, 1, preH);
+    VLO_BARRIER([&]() {
+        if (L.prefetch && bid < L.gu_gx) { gemv16_preload<KFH, 8, EPI_SWIGLU>(L.gu, bid, 0, lds, preH); have = true; }
+    });
     // phase 5: act = silu(gate) * up, post-attention RMSNorm on the operand load
-    for (int vb = bid; vb < L.gu_gx; vb += nb) {
-        gemv16_dev<KFH, 8, XSRC_NORM, EPI_SWIGLU>(L.gu, vb, 0, L.gu_gx, lds);
-        __syncthreads();
-    }
-    VLO_BARRIER();
+    VLO_GEMV_PHASE(KFH, XSRC_NORM, EPI_SWIGLU, L.gu, L.gu_gx, 1, preH);
+    VLO_BARRIER([&]() {
+        if (L.prefetch && bid < L.down_gx * L.down_gy) {
+            gemv16_preload<KFI, 8, EPI_PARTIAL_F32>(L.down, bid % L.down_gx, bid / L.down_gx, lds, preI);
+            have = true;
+        }
+    });
     // phase 6: down-proj K-slice partials (combined by the next layer's phase 0, or by add_rmsnorm after the last layer)
-    for (int vb = bid; vb < L.down_gx * L.down_gy; vb += nb) {
-        gemv16_dev<KFI, 8, XSRC_PLAIN, EPI_PARTIAL_F32>(L.down, vb % L.down_gx, vb / L.down_gx, L.down_gx, lds);
-        __syncthreads();
-    }
+    VLO_GEMV_PHASE(KFI, XSRC_PLAIN, EPI_PARTIAL_F32, L.down, L.down_gx, L.down_gy, preI);
+#undef VLO_GEMV_PHASE
 #undef VLO_BARRIER
 }
 
@@ -204,12 +243,12 @@ static hipError_t launch_one(LayerArgs &L, int nblocks, size_t lds, hipStream_t 
 bool layer_kernel_supports(int kf_h, int kf_i, int head_dim, int hpw) {
     return (kf_h == 16 && kf_i == 14 && head_dim == 128 && hpw == 2) ||      // Llama-3-8B
            (kf_h == 8 && kf_i == 11 && head_dim == 64 && hpw == 2) ||        // TinyLlama-1.1B
-           (kf_h == 1 && kf_i == 2 && head_dim == 64 && hpw == 2);           // 256 / 512-wide model of the unit tests
+           (kf_h == 1 && kf_i == 1 && head_dim == 64 && hpw == 2);           // 256 / 768-wide model of the unit tests (down-proj in 3 K slices)
 }
 
 hipError_t layer_launch(LayerArgs &L, int kf_h, int kf_i, int head_dim, int hpw, int nblocks, size_t lds, hipStream_t st) {
     if (kf_h == 16 && kf_i == 14 && head_dim == 128 && hpw == 2) return launch_one<16, 14, 128, 2>(L, nblocks, lds, st);
     if (kf_h == 8 && kf_i == 11 && head_dim == 64 && hpw == 2) return launch_one<8, 11, 64, 2>(L, nblocks, lds, st);
-    if (kf_h == 1 && kf_i == 2 && head_dim == 64 && hpw == 2) return launch_one<1, 2, 64, 2>(L, nblocks, lds, st);
+    if (kf_h == 1 && kf_i == 1 && head_dim == 64 && hpw == 2) return launch_one<1, 1, 64, 2>(L, nblocks, lds, st);
     return hipErrorInvalidValue;
 }
