@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # First GPU call of the next round: validate and time everything that was written without GPU time.
 #
-#   gpurun --timeout 1500 -- 'bash tools/next_round_gpu_checks.sh'
+#   gpurun --timeout 2400 -- 'bash tools/next_round_gpu_checks.sh'
 #
 # Every stage runs under its own `timeout`, writes its log to gpurun_out/next_round/ and never stops the later
 # stages; the summary at the end says which stage passed.  Nothing here changes a default: the fused short-chunk
@@ -39,9 +39,14 @@ stage p2p_two_process_tests 600 env VLO_EXPERIMENTAL=1 python -m pytest tests/te
 stage p2p_bench_two_ranks 600 env VLO_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
     --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 120 --warmup 10 --tp --tp-allreduce p2p \
     --model tinyllama-1.1b --no-cpu-baseline
+# 4b. persistent layer kernel: bit-identical to the launch pipeline?  then A/B timing with and without the cross-phase prefetch
+stage persistent_tests 900 env VLO_EXPERIMENTAL=1 python -m pytest tests/test_zz_gpu_persistent.py -x -q -m gpu -s
+stage persistent_probe_prefetch 420 python tools/probe_persistent.py --iters 40
+stage persistent_probe_noprefetch 420 env VLO_PERSISTENT_PREFETCH=0 python tools/probe_persistent.py --iters 40
 # 5. end-to-end effect of the fused decode path on the headline bench (short run), default vs VLO_FUSED_ROWS=1
 stage bench_default_300 420 python bench.py --steps 300 --warmup 10 --no-cpu-baseline
 stage bench_fused1_300 420 env VLO_FUSED_ROWS=1 python bench.py --steps 300 --warmup 10 --no-cpu-baseline
+stage bench_persistent_300 420 env VLO_PERSISTENT=1 python bench.py --steps 300 --warmup 10 --no-cpu-baseline
 
 echo "=== summary" | tee -a "$OUT/summary.txt"
 for k in "${!RC[@]}"; do echo "$k: exit ${RC[$k]}"; done | sort | tee -a "$OUT/summary.txt"
