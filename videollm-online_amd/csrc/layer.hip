@@ -236,6 +236,13 @@ static hipError_t launch_one(LayerArgs &L, int nblocks, size_t lds, hipStream_t 
         hipFuncSetAttribute((const void *)llm_layer_kernel<KFH, KFI, HD, HPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
+    // cooperative launch: the runtime checks the grid against the occupancy query (a block that is not resident would leave the
+    // barriers waiting for their time-out).  VLO_PERSISTENT_COOP=0: a plain launch — same residency, no check, ~15 us less host time
+    static const bool coop = getenv("VLO_PERSISTENT_COOP") ? atoi(getenv("VLO_PERSISTENT_COOP")) != 0 : true;
+    if (!coop) {
+        hipLaunchKernelGGL((llm_layer_kernel<KFH, KFI, HD, HPW>), dim3(nblocks), dim3(512), lds, st, L);
+        return hipGetLastError();
+    }
     void *params[] = {&L};
     return hipLaunchCooperativeKernel(llm_layer_kernel<KFH, KFI, HD, HPW>, dim3(nblocks), dim3(512), params, (unsigned)lds, st);
 }
