@@ -1,6 +1,9 @@
 """Persistent layer kernel (csrc/layer.hip, VLO_PERSISTENT): one cooperative launch per decoder layer, resident blocks walking
 the launch pipeline's virtual grids between grid barriers, next-phase weights prefetched through the barriers.
 
+(VLO_PERSISTENT_PREFETCH is read once per process by the engine: the parametrisation exercises the value of the FIRST case that
+steps a persistent session; run the file twice with -k to see both.)
+
 NOT YET RUN ON HARDWARE (written without GPU time; bit-identical to the launch pipeline in the CPU emulation, where the grid
 barriers are real but the GPU memory model is not).  Opt-in (VLO_EXPERIMENTAL=1) until the first run.  On the GPU the logits
 must equal the default pipeline's BIT FOR BIT: same kernel bodies, same virtual grids, same summation orders."""
@@ -15,8 +18,9 @@ pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(os.environ.get("VLO_EXPERIMENTAL") != "1", reason="opt-in until first validated on a GPU (VLO_EXPERIMENTAL=1)")]
 
 
-@pytest.mark.parametrize("name,seed,prefetch", [("tinyllama-2l", 5, 0), ("tinyllama-2l", 5, 1), ("llama-3-8b-2l", 6, 0), ("llama-3-8b-2l", 6, 1)])
-def test_persistent_equals_launch_pipeline(name, seed, prefetch, monkeypatch):
+@pytest.mark.parametrize("name,seed,prefetch,whole_step", [("tinyllama-2l", 5, 0, 0), ("tinyllama-2l", 5, 1, 1), ("llama-3-8b-2l", 6, 0, 0),
+                                                           ("llama-3-8b-2l", 6, 1, 0), ("llama-3-8b-2l", 6, 1, 1)])
+def test_persistent_equals_launch_pipeline(name, seed, prefetch, whole_step, monkeypatch):
     from videollm_online_amd.engine import Engine, EngineConfig
     spec = O.LLM_SPECS[name]
     w = O.init_llm_weights(spec, seed=seed)
@@ -32,8 +36,10 @@ def test_persistent_equals_launch_pipeline(name, seed, prefetch, monkeypatch):
     eng.finalize()
     monkeypatch.setenv("VLO_PERSISTENT", "1")                 # one resident block per CU
     monkeypatch.setenv("VLO_PERSISTENT_PREFETCH", str(prefetch))
+    monkeypatch.setenv("VLO_PERSISTENT_STEP", str(whole_step))     # 1: all layers of a step in ONE launch
     ps = eng.new_session()
     monkeypatch.delenv("VLO_PERSISTENT")
+    monkeypatch.delenv("VLO_PERSISTENT_STEP")
     ds = eng.new_session()
     g = torch.Generator().manual_seed(seed + 100)
     H = spec.hidden_size

@@ -29,8 +29,11 @@ def main():
     sessions = {}
     sessions["launches"] = eng.new_session()
     os.environ["VLO_PERSISTENT"] = "1"          # one resident block per CU; VLO_PERSISTENT_PREFETCH (default 1) is read once per process
-    sessions["persistent"] = eng.new_session()
+    sessions["persistent/layer"] = eng.new_session()
+    os.environ["VLO_PERSISTENT_STEP"] = "1"     # all layers of a step in ONE launch
+    sessions["persistent/step"] = eng.new_session()
     os.environ.pop("VLO_PERSISTENT", None)
+    os.environ.pop("VLO_PERSISTENT_STEP", None)
     fill = torch.randn(64, H, device="cuda").bfloat16()
     print(f"VLO_PERSISTENT_PREFETCH={os.environ.get('VLO_PERSISTENT_PREFETCH', '1 (default)')} for the persistent column; "
           f"run again with VLO_PERSISTENT_PREFETCH=0 for the other variant")

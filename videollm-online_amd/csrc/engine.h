@@ -80,6 +80,8 @@ struct vlo_session {
     int persistent_blocks = 0;                   // > 0: 16-row chunks run one persistent launch per layer on this many blocks (VLO_PERSISTENT)
     unsigned *bar = nullptr;                     // persistent layer kernel: [0] barrier counter, [1] sticky time-out word
     unsigned bar_issued = 0;                     // arrivals every block has made so far (host-side count, wraps)
+    bool persistent_step = false;                // VLO_PERSISTENT_STEP: all layers of a chunk in ONE launch (device array of LayerArgs)
+    void *layer_args_dev = nullptr;              // [num_layers] LayerArgs
     std::vector<int> pages;
     std::vector<void *> owned;
     unsigned short *h = nullptr, *x = nullptr, *act = nullptr, *attn = nullptr, *q = nullptr, *emb1 = nullptr;

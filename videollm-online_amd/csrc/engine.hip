@@ -422,11 +422,13 @@ int vlo_session_create(vlo_engine *e, int64_t max_tokens_hint, vlo_session **out
                         layer_kernel_supports(L0.qkv.plan.KF, L0.down.plan.KF, hd, hpw);
         if (ok) {
             A((void **)&s->bar, 256);
+            A(&s->layer_args_dev, (size_t)c.num_layers * sizeof(LayerArgs));
             if (rc) {
                 vlo_session_destroy(s);
                 return rc;
             }
             s->persistent_blocks = nb;
+            s->persistent_step = getenv("VLO_PERSISTENT_STEP") && atoi(getenv("VLO_PERSISTENT_STEP")) != 0;
         }
     }
     HIP_TRY(hipDeviceSynchronize());
@@ -669,6 +671,9 @@ static int run_chunk_persistent(vlo_session *s, const unsigned short *src, int m
     HIP_TRY(attention_geometry(kv, nh, s->len, m, &ag));
     const float *prev = nullptr;
     int prev_ks = 0;
+    std::vector<LayerArgs> all;                       // whole-step launch: the per-layer arguments, copied to the device once
+    if (s->persistent_step) all.reserve(c.num_layers);
+    size_t lds_step = 0;
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerWeights &W = e->layers[l];
         LayerArgs L{};
@@ -702,10 +707,23 @@ static int run_chunk_persistent(vlo_session *s, const unsigned short *src, int m
             static const int pf = getenv("VLO_PERSISTENT_PREFETCH") ? atoi(getenv("VLO_PERSISTENT_PREFETCH")) : 1;
             L.prefetch = pf;
         }
-        HIP_TRY(layer_launch(L, W.qkv.plan.KF, W.down.plan.KF, hd, ag.hpw, s->persistent_blocks, lds, st));
-        s->bar_issued += (unsigned)layer_barriers_per_launch() * (unsigned)s->persistent_blocks;
+        if (s->persistent_step) {
+            all.push_back(L);                         // bar_base of layers > 0 is not read: the kernel keeps counting
+            lds_step = std::max(lds_step, lds);
+        } else {
+            HIP_TRY(layer_launch(L, W.qkv.plan.KF, W.down.plan.KF, hd, ag.hpw, s->persistent_blocks, lds, st));
+            s->bar_issued += (unsigned)layer_barriers_per_launch() * (unsigned)s->persistent_blocks;
+        }
         prev = s->partial;
         prev_ks = W.down.plan.ksplit;
+    }
+    if (s->persistent_step) {
+        // pageable source: the copy has left `all` when hipMemcpyAsync returns; stream-ordered before the launch
+        HIP_TRY(hipMemcpyAsync(s->layer_args_dev, all.data(), all.size() * sizeof(LayerArgs), hipMemcpyHostToDevice, st));
+        const LayerWeights &W0 = e->layers[0];
+        HIP_TRY(step_launch((const LayerArgs *)s->layer_args_dev, c.num_layers, W0.qkv.plan.KF, W0.down.plan.KF, hd, ag.hpw,
+                            s->persistent_blocks, lds_step, st));
+        s->bar_issued += (unsigned)step_barriers_per_launch(c.num_layers) * (unsigned)s->persistent_blocks;
     }
     if (want_last || want_all) {
         HIP_TRY(add_rmsnorm_launch(s->h, prev, prev_ks, H, (const unsigned short *)e->norm_w, s->x, H, H, c.rms_eps, m, st));

@@ -37,3 +37,8 @@ int layer_barriers_per_launch(void);
 // instantiations: (fragments per wave of the H-long reductions, of the I-long one, head_dim, query heads per wave)
 bool layer_kernel_supports(int kf_h, int kf_i, int head_dim, int hpw);
 hipError_t layer_launch(LayerArgs &L, int kf_h, int kf_i, int head_dim, int hpw, int nblocks, size_t lds_bytes, hipStream_t st);
+// all layers of a step in ONE launch: `layers_dev` = device array of num_layers LayerArgs (layers_dev[0].bar_base counts); the
+// launch makes step_barriers_per_launch(num_layers) barrier arrivals per block
+int step_barriers_per_launch(int num_layers);
+hipError_t step_launch(const LayerArgs *layers_dev, int num_layers, int kf_h, int kf_i, int head_dim, int hpw, int nblocks, size_t lds_bytes,
+                       hipStream_t st);

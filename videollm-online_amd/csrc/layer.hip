@@ -157,16 +157,13 @@ VLO_DEV void combine_dev(const float *part_o, const float *part_ml, int nsplit, 
     }
 }
 
+// The seven phases of one decoder layer for the resident block `bid` of `nb`.  `target` counts barrier arrivals (every block
+// adds one per barrier); preH / preI / have carry prefetched weight fragments from one barrier to the phase behind it — and,
+// in the whole-step kernel, from the end of one layer to the qkv phase of the next.  `next`: the following layer of the same
+// launch (null in the per-layer kernel and after the last layer): its qkv fragments go in flight behind this layer's down-proj.
 template <int KFH, int KFI, int HD, int HPW>
-__global__ __launch_bounds__(512) void llm_layer_kernel(LayerArgs L) {
-    extern __shared__ __attribute__((aligned(16))) float4 lds[];
-    const int nb = gridDim.x, bid = blockIdx.x;
-    unsigned target = L.bar_base;
-    // Cross-phase prefetch (L.prefetch): while a block waits at the barrier in front of a GEMV phase, the first weight
-    // fragments of ITS first virtual block of that phase are already in flight (16 KiB per wave at KF = 16), so the HBM
-    // stream does not stop for the barrier and the phase starts on loaded registers.  `have` = preH / preI hold them.
-    frag_ab preH[KFH], preI[KFI];
-    bool have = false;
+VLO_DEV void layer_phases(const LayerArgs &L, const LayerArgs *next, const int bid, const int nb, unsigned &target, float4 *lds,
+                          frag_ab (&preH)[KFH], frag_ab (&preI)[KFI], bool &have) {
     auto nothing = []() {};
 #define VLO_BARRIER(...) grid_barrier(L.bar_counter, target += (unsigned)nb, L.bar_err, L.bar_timeout_ticks, __VA_ARGS__)
 #define VLO_GEMV_PHASE(KF_, XSRC_, EPI_, ARGS_, GX_, GY_, PRE_)                                                          \
@@ -181,8 +178,8 @@ __global__ __launch_bounds__(512) void llm_layer_kernel(LayerArgs L) {
         add_rmsnorm_dev(L.h, L.prev, L.prev_ks, L.H, L.ln_in, L.x, L.H, L.H, L.eps, vb);
         __syncthreads();
     }
-    VLO_BARRIER([&]() {
-        if (L.prefetch && bid < L.qkv_gx) { gemv16_preload<KFH, 8, EPI_ROPE>(L.qkv, bid, 0, lds, preH); have = true; }
+    VLO_BARRIER([&]() {      // (already in flight when the previous layer of this launch ended with the prefetch)
+        if (L.prefetch && !have && bid < L.qkv_gx) { gemv16_preload<KFH, 8, EPI_ROPE>(L.qkv, bid, 0, lds, preH); have = true; }
     });
     // phase 1: q, k, v = x W^T; RoPE; K / V^T appended to the session's pages
     VLO_GEMV_PHASE(KFH, XSRC_PLAIN, EPI_ROPE, L.qkv, L.qkv_gx, 1, preH);
@@ -222,12 +219,46 @@ __global__ __launch_bounds__(512) void llm_layer_kernel(LayerArgs L) {
     });
     // phase 6: down-proj K-slice partials (combined by the next layer's phase 0, or by add_rmsnorm after the last layer)
     VLO_GEMV_PHASE(KFI, XSRC_PLAIN, EPI_PARTIAL_F32, L.down, L.down_gx, L.down_gy, preI);
+    if (next) {              // whole-step kernel: the boundary between two layers is one more barrier, not a launch
+        VLO_BARRIER([&]() {
+            if (next->prefetch && bid < next->qkv_gx) { gemv16_preload<KFH, 8, EPI_ROPE>(next->qkv, bid, 0, lds, preH); have = true; }
+        });
+    }
 #undef VLO_GEMV_PHASE
 #undef VLO_BARRIER
 }
 
+template <int KFH, int KFI, int HD, int HPW>
+__global__ __launch_bounds__(512) void llm_layer_kernel(LayerArgs L) {
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];
+    unsigned target = L.bar_base;
+    frag_ab preH[KFH], preI[KFI];
+    bool have = false;
+    layer_phases<KFH, KFI, HD, HPW>(L, nullptr, blockIdx.x, gridDim.x, target, lds, preH, preI, have);
+}
+
+// all decoder layers of a step in ONE launch: `layers` = device array of the per-layer arguments (bar_base of the first one counts)
+template <int KFH, int KFI, int HD, int HPW>
+__global__ __launch_bounds__(512) void llm_step_kernel(const LayerArgs *layers, int num_layers) {
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];
+    unsigned target = layers[0].bar_base;
+    frag_ab preH[KFH], preI[KFI];
+    bool have = false;
+    for (int l = 0; l < num_layers; ++l)
+        layer_phases<KFH, KFI, HD, HPW>(layers[l], l + 1 < num_layers ? layers + l + 1 : nullptr, blockIdx.x, gridDim.x, target, lds, preH, preI,
+                                        have);
+}
+
 // ---- host side --------------------------------------------------------------------------------------------------------------
 int layer_barriers_per_launch(void) { return 6; }
+int step_barriers_per_launch(int num_layers) { return 7 * num_layers - 1; }
+
+// cooperative launch: the runtime checks the grid against the occupancy query (a block that is not resident would leave the
+// barriers waiting for their time-out).  VLO_PERSISTENT_COOP=0: a plain launch — same residency, no check, ~15 us less host time
+static bool use_coop() {
+    static const bool coop = getenv("VLO_PERSISTENT_COOP") ? atoi(getenv("VLO_PERSISTENT_COOP")) != 0 : true;
+    return coop;
+}
 
 template <int KFH, int KFI, int HD, int HPW>
 static hipError_t launch_one(LayerArgs &L, int nblocks, size_t lds, hipStream_t st) {
@@ -236,15 +267,27 @@ static hipError_t launch_one(LayerArgs &L, int nblocks, size_t lds, hipStream_t 
         hipFuncSetAttribute((const void *)llm_layer_kernel<KFH, KFI, HD, HPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    // cooperative launch: the runtime checks the grid against the occupancy query (a block that is not resident would leave the
-    // barriers waiting for their time-out).  VLO_PERSISTENT_COOP=0: a plain launch — same residency, no check, ~15 us less host time
-    static const bool coop = getenv("VLO_PERSISTENT_COOP") ? atoi(getenv("VLO_PERSISTENT_COOP")) != 0 : true;
-    if (!coop) {
+    if (!use_coop()) {
         hipLaunchKernelGGL((llm_layer_kernel<KFH, KFI, HD, HPW>), dim3(nblocks), dim3(512), lds, st, L);
         return hipGetLastError();
     }
     void *params[] = {&L};
     return hipLaunchCooperativeKernel(llm_layer_kernel<KFH, KFI, HD, HPW>, dim3(nblocks), dim3(512), params, (unsigned)lds, st);
+}
+
+template <int KFH, int KFI, int HD, int HPW>
+static hipError_t launch_step(const LayerArgs *layers_dev, int num_layers, int nblocks, size_t lds, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void *)llm_step_kernel<KFH, KFI, HD, HPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    if (!use_coop()) {
+        hipLaunchKernelGGL((llm_step_kernel<KFH, KFI, HD, HPW>), dim3(nblocks), dim3(512), lds, st, layers_dev, num_layers);
+        return hipGetLastError();
+    }
+    void *params[] = {&layers_dev, &num_layers};
+    return hipLaunchCooperativeKernel(llm_step_kernel<KFH, KFI, HD, HPW>, dim3(nblocks), dim3(512), params, (unsigned)lds, st);
 }
 
 bool layer_kernel_supports(int kf_h, int kf_i, int head_dim, int hpw) {
@@ -257,5 +300,13 @@ hipError_t layer_launch(LayerArgs &L, int kf_h, int kf_i, int head_dim, int hpw,
     if (kf_h == 16 && kf_i == 14 && head_dim == 128 && hpw == 2) return launch_one<16, 14, 128, 2>(L, nblocks, lds, st);
     if (kf_h == 8 && kf_i == 11 && head_dim == 64 && hpw == 2) return launch_one<8, 11, 64, 2>(L, nblocks, lds, st);
     if (kf_h == 1 && kf_i == 1 && head_dim == 64 && hpw == 2) return launch_one<1, 1, 64, 2>(L, nblocks, lds, st);
+    return hipErrorInvalidValue;
+}
+
+hipError_t step_launch(const LayerArgs *layers_dev, int num_layers, int kf_h, int kf_i, int head_dim, int hpw, int nblocks, size_t lds,
+                       hipStream_t st) {
+    if (kf_h == 16 && kf_i == 14 && head_dim == 128 && hpw == 2) return launch_step<16, 14, 128, 2>(layers_dev, num_layers, nblocks, lds, st);
+    if (kf_h == 8 && kf_i == 11 && head_dim == 64 && hpw == 2) return launch_step<8, 11, 64, 2>(layers_dev, num_layers, nblocks, lds, st);
+    if (kf_h == 1 && kf_i == 1 && head_dim == 64 && hpw == 2) return launch_step<1, 1, 64, 2>(layers_dev, num_layers, nblocks, lds, st);
     return hipErrorInvalidValue;
 }
