@@ -147,6 +147,8 @@ static inline float atomicAdd(float *p, float v) {          // relaxed fp32 atom
 static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 #define __builtin_amdgcn_s_sleep(x) sched_yield()
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(order)
+// HW_REG_XCC_ID: a scrambled, uneven block -> "XCD" map (5 populated groups), so nothing may rely on a placement pattern
+#define __builtin_amdgcn_s_getreg(imm) ((unsigned)((blockIdx.x * 5u + 3u) % 7u % 5u))
 #define __builtin_nontemporal_load(p) (*(p))
 
 // direct-to-LDS load: every lane's `size` bytes land at the wave-uniform LDS base + lane * size

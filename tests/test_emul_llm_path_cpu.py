@@ -363,8 +363,9 @@ def test_step_chunking_boundaries(E, n):
 PERSIST_SPEC = O.LlmSpec(256, 768, 2, 4, 2, 512, 10000.0, 1e-5, vision_hidden_size=128)     # every projection plans 8 waves; down-proj in 3 K slices
 
 
-@pytest.mark.parametrize("blocks,whole_step", [(3, 1)] if not FULL else [(3, 0), (3, 1), (7, 0), (7, 1)])
-def test_persistent_layer_kernel_is_bit_identical(E, blocks, whole_step, monkeypatch):
+@pytest.mark.parametrize("blocks,whole_step,barrier", [(3, 1, "flat"), (7, 1, "xcd")] if not FULL else
+                         [(3, 0, "flat"), (3, 1, "flat"), (7, 0, "flat"), (7, 1, "flat"), (3, 0, "xcd"), (7, 1, "xcd"), (7, 0, "xcd")])
+def test_persistent_layer_kernel_is_bit_identical(E, blocks, whole_step, barrier, monkeypatch):
     """VLO_PERSISTENT (csrc/layer.hip): one cooperative launch per decoder layer, its resident blocks walking the same virtual
     grids with the same kernel bodies between grid barriers (the emulation runs every block in its own process, so the
     barriers are real).  Same engine, two sessions: the logits must equal the launch-per-phase pipeline's bit for bit."""
@@ -376,9 +377,11 @@ def test_persistent_layer_kernel_is_bit_identical(E, blocks, whole_step, monkeyp
     assert E.gemv_plan(spec.intermediate_size, True) == (8, 1, 1, 3) and E.gemv_plan(spec.hidden_size, False) == (8, 1, 1, 1)
     monkeypatch.setenv("VLO_PERSISTENT", str(blocks))
     monkeypatch.setenv("VLO_PERSISTENT_STEP", str(whole_step))       # 1: all layers of a step in ONE launch
+    monkeypatch.setenv("VLO_PERSISTENT_BARRIER", barrier)            # xcd: hierarchical barrier; the emulated XCD map is scrambled and uneven
     ps = eng.new_session()
     monkeypatch.delenv("VLO_PERSISTENT")
     monkeypatch.delenv("VLO_PERSISTENT_STEP")
+    monkeypatch.delenv("VLO_PERSISTENT_BARRIER")
     ds = eng.new_session()
     rc = gc = None
     for i, x in enumerate(_steps(spec, ref, toks, 8, [11, 1] + ([16, 3] if FULL else []))):
@@ -387,6 +390,6 @@ def test_persistent_layer_kernel_is_bit_identical(E, blocks, whole_step, monkeyp
         lp, ap = eng.llm_step(ps, x)
         ld, ad = eng.llm_step(ds, x)
         assert eng.session_len(ps) == eng.session_len(ds) == len(rc)
-        _three_way(f"persistent x{blocks}{' whole step' if whole_step else ''}", i, ap, rl, gl)
+        _three_way(f"persistent x{blocks}{' whole step' if whole_step else ''} {barrier}", i, ap, rl, gl)
         assert torch.equal(ap, ad) and torch.equal(lp, ld), f"step {i}: persistent and launch-per-phase logits differ"
     eng.close()

@@ -18,9 +18,11 @@ pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(os.environ.get("VLO_EXPERIMENTAL") != "1", reason="opt-in until first validated on a GPU (VLO_EXPERIMENTAL=1)")]
 
 
-@pytest.mark.parametrize("name,seed,prefetch,whole_step", [("tinyllama-2l", 5, 0, 0), ("tinyllama-2l", 5, 1, 1), ("llama-3-8b-2l", 6, 0, 0),
-                                                           ("llama-3-8b-2l", 6, 1, 0), ("llama-3-8b-2l", 6, 1, 1)])
-def test_persistent_equals_launch_pipeline(name, seed, prefetch, whole_step, monkeypatch):
+@pytest.mark.parametrize("name,seed,prefetch,whole_step,barrier",
+                         [("tinyllama-2l", 5, 0, 0, "flat"), ("tinyllama-2l", 5, 1, 1, "flat"), ("llama-3-8b-2l", 6, 0, 0, "flat"),
+                          ("llama-3-8b-2l", 6, 1, 0, "flat"), ("llama-3-8b-2l", 6, 1, 1, "flat"),
+                          ("llama-3-8b-2l", 6, 1, 0, "xcd"), ("llama-3-8b-2l", 6, 1, 1, "xcd"), ("tinyllama-2l", 5, 1, 1, "xcd")])
+def test_persistent_equals_launch_pipeline(name, seed, prefetch, whole_step, barrier, monkeypatch):
     from videollm_online_amd.engine import Engine, EngineConfig
     spec = O.LLM_SPECS[name]
     w = O.init_llm_weights(spec, seed=seed)
@@ -37,9 +39,11 @@ def test_persistent_equals_launch_pipeline(name, seed, prefetch, whole_step, mon
     monkeypatch.setenv("VLO_PERSISTENT", "1")                 # one resident block per CU
     monkeypatch.setenv("VLO_PERSISTENT_PREFETCH", str(prefetch))
     monkeypatch.setenv("VLO_PERSISTENT_STEP", str(whole_step))     # 1: all layers of a step in ONE launch
+    monkeypatch.setenv("VLO_PERSISTENT_BARRIER", barrier)          # xcd: hierarchical barrier grouped by HW_REG_XCC_ID
     ps = eng.new_session()
     monkeypatch.delenv("VLO_PERSISTENT")
     monkeypatch.delenv("VLO_PERSISTENT_STEP")
+    monkeypatch.delenv("VLO_PERSISTENT_BARRIER")
     ds = eng.new_session()
     g = torch.Generator().manual_seed(seed + 100)
     H = spec.hidden_size

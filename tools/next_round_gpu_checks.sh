@@ -48,6 +48,7 @@ stage bench_default_300 420 python bench.py --steps 300 --warmup 10 --no-cpu-bas
 stage bench_fused1_300 420 env VLO_FUSED_ROWS=1 python bench.py --steps 300 --warmup 10 --no-cpu-baseline
 stage bench_persistent_300 420 env VLO_PERSISTENT=1 python bench.py --steps 300 --warmup 10 --no-cpu-baseline
 stage bench_persistent_step_300 420 env VLO_PERSISTENT=1 VLO_PERSISTENT_STEP=1 python bench.py --steps 300 --warmup 10 --no-cpu-baseline
+stage bench_persistent_step_xcd_300 420 env VLO_PERSISTENT=1 VLO_PERSISTENT_STEP=1 VLO_PERSISTENT_BARRIER=xcd python bench.py --steps 300 --warmup 10 --no-cpu-baseline
 
 echo "=== summary" | tee -a "$OUT/summary.txt"
 for k in "${!RC[@]}"; do echo "$k: exit ${RC[$k]}"; done | sort | tee -a "$OUT/summary.txt"

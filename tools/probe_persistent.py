@@ -32,6 +32,9 @@ def main():
     sessions["persistent/layer"] = eng.new_session()
     os.environ["VLO_PERSISTENT_STEP"] = "1"     # all layers of a step in ONE launch
     sessions["persistent/step"] = eng.new_session()
+    os.environ["VLO_PERSISTENT_BARRIER"] = "xcd"    # XCD-hierarchical grid barrier
+    sessions["persistent/step/xcd"] = eng.new_session()
+    os.environ.pop("VLO_PERSISTENT_BARRIER", None)
     os.environ.pop("VLO_PERSISTENT", None)
     os.environ.pop("VLO_PERSISTENT_STEP", None)
     fill = torch.randn(64, H, device="cuda").bfloat16()

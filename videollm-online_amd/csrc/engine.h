@@ -80,6 +80,8 @@ struct vlo_session {
     int persistent_blocks = 0;                   // > 0: 16-row chunks run one persistent launch per layer on this many blocks (VLO_PERSISTENT)
     unsigned *bar = nullptr;                     // persistent layer kernel: [0] barrier counter, [1] sticky time-out word
     unsigned bar_issued = 0;                     // arrivals every block has made so far (host-side count, wraps)
+    int barrier_kind = 0;                        // VLO_PERSISTENT_BARRIER=xcd: XCD-hierarchical grid barrier (zeroed state per launch)
+    unsigned *bar_xcd = nullptr;
     bool persistent_step = false;                // VLO_PERSISTENT_STEP: all layers of a chunk in ONE launch (device array of LayerArgs)
     void *layer_args_dev = nullptr;              // [num_layers] LayerArgs
     std::vector<int> pages;

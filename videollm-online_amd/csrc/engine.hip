@@ -423,6 +423,8 @@ int vlo_session_create(vlo_engine *e, int64_t max_tokens_hint, vlo_session **out
         if (ok) {
             A((void **)&s->bar, 256);
             A(&s->layer_args_dev, (size_t)c.num_layers * sizeof(LayerArgs));
+            A((void **)&s->bar_xcd, (size_t)layer_xcd_words() * 4);
+            if (const char *bk = getenv("VLO_PERSISTENT_BARRIER")) s->barrier_kind = strcmp(bk, "xcd") == 0 ? 1 : 0;
             if (rc) {
                 vlo_session_destroy(s);
                 return rc;
@@ -707,12 +709,14 @@ static int run_chunk_persistent(vlo_session *s, const unsigned short *src, int m
             static const int pf = getenv("VLO_PERSISTENT_PREFETCH") ? atoi(getenv("VLO_PERSISTENT_PREFETCH")) : 1;
             L.prefetch = pf;
         }
+        L.barrier_kind = s->barrier_kind; L.bar_xcd = s->bar_xcd;
         if (s->persistent_step) {
             all.push_back(L);                         // bar_base of layers > 0 is not read: the kernel keeps counting
             lds_step = std::max(lds_step, lds);
         } else {
+            if (s->barrier_kind == 1) HIP_TRY(hipMemsetAsync(s->bar_xcd, 0, (size_t)layer_xcd_words() * 4, st));
             HIP_TRY(layer_launch(L, W.qkv.plan.KF, W.down.plan.KF, hd, ag.hpw, s->persistent_blocks, lds, st));
-            s->bar_issued += (unsigned)layer_barriers_per_launch() * (unsigned)s->persistent_blocks;
+            s->bar_issued += (unsigned)layer_barriers_per_launch(s->barrier_kind) * (unsigned)s->persistent_blocks;
         }
         prev = s->partial;
         prev_ks = W.down.plan.ksplit;
@@ -721,9 +725,10 @@ static int run_chunk_persistent(vlo_session *s, const unsigned short *src, int m
         // pageable source: the copy has left `all` when hipMemcpyAsync returns; stream-ordered before the launch
         HIP_TRY(hipMemcpyAsync(s->layer_args_dev, all.data(), all.size() * sizeof(LayerArgs), hipMemcpyHostToDevice, st));
         const LayerWeights &W0 = e->layers[0];
+        if (s->barrier_kind == 1) HIP_TRY(hipMemsetAsync(s->bar_xcd, 0, (size_t)layer_xcd_words() * 4, st));
         HIP_TRY(step_launch((const LayerArgs *)s->layer_args_dev, c.num_layers, W0.qkv.plan.KF, W0.down.plan.KF, hd, ag.hpw,
                             s->persistent_blocks, lds_step, st));
-        s->bar_issued += (unsigned)step_barriers_per_launch(c.num_layers) * (unsigned)s->persistent_blocks;
+        s->bar_issued += (unsigned)step_barriers_per_launch(c.num_layers, s->barrier_kind) * (unsigned)s->persistent_blocks;
     }
     if (want_last || want_all) {
         HIP_TRY(add_rmsnorm_launch(s->h, prev, prev_ks, H, (const unsigned short *)e->norm_w, s->x, H, H, c.rms_eps, m, st));

@@ -30,15 +30,18 @@ struct LayerArgs {
     unsigned *bar_counter, *bar_err;
     unsigned bar_base;
     long long bar_timeout_ticks;
+    int barrier_kind;             // 0: flat counter; 1: XCD-hierarchical (layer.hip) — bar_xcd must be ZERO when the launch starts
+    unsigned *bar_xcd;            // layer_xcd_words() unsigned words
     int prefetch;                 // 1: next-phase weight fragments are put in flight before each grid barrier (stage P1)
 };
 
-int layer_barriers_per_launch(void);
+int layer_barriers_per_launch(int barrier_kind);
+int layer_xcd_words(void);
 // instantiations: (fragments per wave of the H-long reductions, of the I-long one, head_dim, query heads per wave)
 bool layer_kernel_supports(int kf_h, int kf_i, int head_dim, int hpw);
 hipError_t layer_launch(LayerArgs &L, int kf_h, int kf_i, int head_dim, int hpw, int nblocks, size_t lds_bytes, hipStream_t st);
 // all layers of a step in ONE launch: `layers_dev` = device array of num_layers LayerArgs (layers_dev[0].bar_base counts); the
-// launch makes step_barriers_per_launch(num_layers) barrier arrivals per block
-int step_barriers_per_launch(int num_layers);
+// launch makes step_barriers_per_launch(num_layers, kind) arrivals per block on the flat counter
+int step_barriers_per_launch(int num_layers, int barrier_kind);
 hipError_t step_launch(const LayerArgs *layers_dev, int num_layers, int kf_h, int kf_i, int head_dim, int hpw, int nblocks, size_t lds_bytes,
                        hipStream_t st);

@@ -9,7 +9,7 @@
 // a block waiting at the barrier in front of a GEMV phase already has its first weight fragments of that phase in flight,
 // so the HBM stream runs through the phase change instead of restarting after it.
 //
-// Grid barrier: one monotonic counter; every block arrives once per barrier and waits for base + k * gridDim.x.  Memory
+// Grid barrier (flat form): one monotonic counter; every block arrives once per barrier and waits for base + k * gridDim.x.  Memory
 // hand-off follows cdna_hip_programming.md §6 Guideline 16: every wave drains its stores, block barrier, ONE lane does the
 // agent-scope release fence (+ the asm wait the compiler may not drop), the relaxed arrive, a relaxed sc1 poll with
 // s_sleep, ONE agent-scope acquire fence, block barrier, then plain loads.  The spin is bounded (s_memrealtime).
@@ -25,30 +25,104 @@ typedef __attribute__((address_space(1))) unsigned int lgu32;
 // `prefetch`: what this block wants in flight while it waits (the next GEMV phase's first weight fragments).  Seven of the
 // eight waves issue it right after their stores have drained; the leader wave only after its arrival is out, because its
 // release / acquire sequence waits on vmcnt(0), which counts those loads too.
+//
+// Two forms (LayerArgs.barrier_kind):
+//   flat  every block: agent release fence, arrive on ONE counter, poll it, agent acquire fence.  Correct whatever the
+//         block -> XCD placement is; 256 write-backs and a 256-way fan-in per barrier.
+//   xcd   hierarchical (MI355X_MICROARCH.md, price-list row barrier-xcd): blocks are grouped by the XCD they RUN on (read from
+//         the hardware, HW_REG_XCC_ID — no placement pattern is assumed; group sizes come from a census taken before the first
+//         barrier of the launch, which is always flat).  A block drains its stores into its XCD's L2 and arrives on the group's
+//         counter; the LAST arriver of a group does the one release fence for that L2, arrives on the top counter, waits for
+//         all groups, acquires, and publishes the group's generation word; the others poll that word and acquire.
+struct BarrierCtx {
+    unsigned *flat_counter, *err, *xcd;      // xcd: census[8] | group counters[8] | group generations[8] | top, one 128-B line each
+    long long timeout_ticks;
+    unsigned flat_target;                    // arrivals the NEXT flat barrier waits for
+    int kind, nb;
+    int k;                                   // xcd barriers done in this launch
+    int group, group_size, groups;           // this block's XCD, its population, populated XCDs (valid after the census barrier)
+};
+#define VLO_XCD_LINE 32                      // unsigned words per 128-B line
+VLO_DEV unsigned *xcd_census(const BarrierCtx &b, int g) { return b.xcd + (size_t)g * VLO_XCD_LINE; }
+VLO_DEV unsigned *xcd_count(const BarrierCtx &b, int g) { return b.xcd + (size_t)(8 + g) * VLO_XCD_LINE; }
+VLO_DEV unsigned *xcd_gen(const BarrierCtx &b, int g) { return b.xcd + (size_t)(16 + g) * VLO_XCD_LINE; }
+VLO_DEV unsigned *xcd_top(const BarrierCtx &b) { return b.xcd + (size_t)24 * VLO_XCD_LINE; }
+#define VLO_XCD_WORDS (25 * VLO_XCD_LINE)
+
+VLO_DEV unsigned ld_relaxed(unsigned *p) { return __hip_atomic_load((lgu32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// wait until *p has reached `want` (wrap-safe); false on time-out
+VLO_DEV bool spin_until(unsigned *p, unsigned want, unsigned *err, long long timeout_ticks) {
+    const long long t0 = wall_clock64();
+    while ((int)(ld_relaxed(p) - want) < 0) {
+        if (wall_clock64() - t0 > timeout_ticks) {                 // a block that is not resident, or a dead peer: do not hang
+            __hip_atomic_fetch_or((lgu32 *)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return true;
+}
+
 template <class F>
-VLO_DEV void grid_barrier(unsigned *counter, unsigned target, unsigned *err, long long timeout_ticks, F prefetch) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every wave: its global stores have left the CU
+VLO_DEV void grid_barrier(BarrierCtx &b, F prefetch) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every wave: its global stores have left the CU (they are in L2)
     const bool leader_wave = threadIdx.x < 64;
     if (!leader_wave) prefetch();
     __syncthreads();
+    const bool xcd = b.kind == 1 && b.k > 0;                      // the first barrier of a launch is flat: it completes the census
+    bool waits_top = true;
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the write-back is complete before the arrival is visible
-        __hip_atomic_fetch_add((lgu32 *)counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!xcd) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the write-back is complete before the arrival is visible
+            __hip_atomic_fetch_add((lgu32 *)b.flat_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const unsigned old = __hip_atomic_fetch_add((lgu32 *)xcd_count(b, b.group), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            waits_top = old + 1u == (unsigned)b.k * (unsigned)b.group_size;      // the last arriver of this XCD in this round
+            if (waits_top) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");               // ONE write-back for the XCD's L2
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add((lgu32 *)xcd_top(b), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
     if (leader_wave) prefetch();
     if (threadIdx.x == 0) {
-        const long long t0 = wall_clock64();
-        while ((int)(__hip_atomic_load((lgu32 *)counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-            if (wall_clock64() - t0 > timeout_ticks) {             // a block that is not resident, or a dead peer: do not hang
-                __hip_atomic_fetch_or((lgu32 *)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
+        if (!xcd) {
+            spin_until(b.flat_counter, b.flat_target, b.err, b.timeout_ticks);
+        } else if (waits_top) {
+            spin_until(xcd_top(b), (unsigned)b.k * (unsigned)b.groups, b.err, b.timeout_ticks);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store((lgu32 *)xcd_gen(b, b.group), (unsigned)b.k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            spin_until(xcd_gen(b, b.group), (unsigned)b.k, b.err, b.timeout_ticks);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (!(xcd && waits_top)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
+    if (!xcd) b.flat_target += (unsigned)b.nb;
+    if (b.kind == 1) {
+        if (b.k == 0) {                                           // census complete: everybody reads the populations
+            int groups = 0;
+            for (int g = 0; g < 8; ++g) groups += ld_relaxed(xcd_census(b, g)) != 0u;
+            b.groups = groups;
+            b.group_size = (int)ld_relaxed(xcd_census(b, b.group));
+        }
+        b.k += 1;
+    }
+}
+
+// HW_REG_XCC_ID (id 20), bits [3:0]: the XCD this wave runs on
+VLO_DEV int hw_xcc_id() { return (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u); }
+
+VLO_DEV void barrier_init(BarrierCtx &b, const LayerArgs &L, int nb) {
+    b.flat_counter = L.bar_counter; b.err = L.bar_err; b.xcd = L.bar_xcd; b.timeout_ticks = L.bar_timeout_ticks;
+    b.flat_target = L.bar_base + (unsigned)nb; b.kind = L.barrier_kind; b.nb = nb; b.k = 0;
+    b.group = 0; b.group_size = nb; b.groups = 1;
+    if (b.kind == 1) {
+        b.group = hw_xcc_id();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add((lgu32 *)xcd_census(b, b.group), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---- the phase bodies, from the same text as the stand-alone kernels ------------------------------------------------------
@@ -157,15 +231,14 @@ VLO_DEV void combine_dev(const float *part_o, const float *part_ml, int nsplit, 
     }
 }
 
-// The seven phases of one decoder layer for the resident block `bid` of `nb`.  `target` counts barrier arrivals (every block
-// adds one per barrier); preH / preI / have carry prefetched weight fragments from one barrier to the phase behind it — and,
+// The seven phases of one decoder layer for the resident block `bid` of `nb`.  `bar`: the launch's barrier state; preH / preI / have carry prefetched weight fragments from one barrier to the phase behind it — and,
 // in the whole-step kernel, from the end of one layer to the qkv phase of the next.  `next`: the following layer of the same
 // launch (null in the per-layer kernel and after the last layer): its qkv fragments go in flight behind this layer's down-proj.
 template <int KFH, int KFI, int HD, int HPW>
-VLO_DEV void layer_phases(const LayerArgs &L, const LayerArgs *next, const int bid, const int nb, unsigned &target, float4 *lds,
+VLO_DEV void layer_phases(const LayerArgs &L, const LayerArgs *next, const int bid, const int nb, BarrierCtx &bar, float4 *lds,
                           frag_ab (&preH)[KFH], frag_ab (&preI)[KFI], bool &have) {
     auto nothing = []() {};
-#define VLO_BARRIER(...) grid_barrier(L.bar_counter, target += (unsigned)nb, L.bar_err, L.bar_timeout_ticks, __VA_ARGS__)
+#define VLO_BARRIER(...) grid_barrier(bar, __VA_ARGS__)
 #define VLO_GEMV_PHASE(KF_, XSRC_, EPI_, ARGS_, GX_, GY_, PRE_)                                                          \
     for (int vb = bid; vb < (GX_) * (GY_); vb += nb) {                                                                    \
         if (!(have && vb == bid)) gemv16_preload<KF_, 8, EPI_>(ARGS_, vb % (GX_), vb / (GX_), lds, PRE_);                 \
@@ -231,27 +304,32 @@ VLO_DEV void layer_phases(const LayerArgs &L, const LayerArgs *next, const int b
 template <int KFH, int KFI, int HD, int HPW>
 __global__ __launch_bounds__(512) void llm_layer_kernel(LayerArgs L) {
     extern __shared__ __attribute__((aligned(16))) float4 lds[];
-    unsigned target = L.bar_base;
+    BarrierCtx bar;
+    barrier_init(bar, L, gridDim.x);
     frag_ab preH[KFH], preI[KFI];
     bool have = false;
-    layer_phases<KFH, KFI, HD, HPW>(L, nullptr, blockIdx.x, gridDim.x, target, lds, preH, preI, have);
+    layer_phases<KFH, KFI, HD, HPW>(L, nullptr, blockIdx.x, gridDim.x, bar, lds, preH, preI, have);
 }
 
 // all decoder layers of a step in ONE launch: `layers` = device array of the per-layer arguments (bar_base of the first one counts)
 template <int KFH, int KFI, int HD, int HPW>
 __global__ __launch_bounds__(512) void llm_step_kernel(const LayerArgs *layers, int num_layers) {
     extern __shared__ __attribute__((aligned(16))) float4 lds[];
-    unsigned target = layers[0].bar_base;
+    BarrierCtx bar;
+    barrier_init(bar, layers[0], gridDim.x);
     frag_ab preH[KFH], preI[KFI];
     bool have = false;
     for (int l = 0; l < num_layers; ++l)
-        layer_phases<KFH, KFI, HD, HPW>(layers[l], l + 1 < num_layers ? layers + l + 1 : nullptr, blockIdx.x, gridDim.x, target, lds, preH, preI,
+        layer_phases<KFH, KFI, HD, HPW>(layers[l], l + 1 < num_layers ? layers + l + 1 : nullptr, blockIdx.x, gridDim.x, bar, lds, preH, preI,
                                         have);
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
-int layer_barriers_per_launch(void) { return 6; }
-int step_barriers_per_launch(int num_layers) { return 7 * num_layers - 1; }
+// FLAT-counter arrivals per block and launch (what the host adds to bar_base): all barriers of the launch with the flat form,
+// only the first (census) one with the XCD-hierarchical form
+int layer_barriers_per_launch(int barrier_kind) { return barrier_kind == 1 ? 1 : 6; }
+int step_barriers_per_launch(int num_layers, int barrier_kind) { return barrier_kind == 1 ? 1 : 7 * num_layers - 1; }
+int layer_xcd_words(void) { return VLO_XCD_WORDS; }
 
 // cooperative launch: the runtime checks the grid against the occupancy query (a block that is not resident would leave the
 // barriers waiting for their time-out).  VLO_PERSISTENT_COOP=0: a plain launch — same residency, no check, ~15 us less host time
