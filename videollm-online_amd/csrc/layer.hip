@@ -137,30 +137,33 @@ VLO_DEV float gelu_python_bf16(float x) {
 }
 VLO_DEV float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-// the first weight fragments of virtual block (vbx, vby): the geometry text of the GEMV body, nothing else
+// the first weight fragments of virtual block (vbx, vby) into `pre`: the geometry text of the GEMV body, nothing else
 template <int KF, int NW, int EPI>
 VLO_DEV void gemv16_preload(const GemvArgs &a, const int vbx, const int vby, float4 *red, frag_ab (&pre)[KF]) {
 #define VLO_GEMV_BX vbx
 #define VLO_GEMV_BY vby
+#define VLO_GEMV_WR_REF pre
 #include "gemv_head.inc"
 #undef VLO_GEMV_BX
 #undef VLO_GEMV_BY
+#undef VLO_GEMV_WR_REF
     (void)rs_lds; (void)tmp_lds; (void)m16; (void)qd; (void)tile_b;
-#pragma unroll
-    for (int kf = 0; kf < KF; ++kf) pre[kf] = wr[kf];
 }
 
-// the GEMV body for virtual block (vbx, vby) of a (vgx, *) grid whose first fragments are already in `pre`
+// the GEMV body for virtual block (vbx, vby) of a (vgx, *) grid whose first fragments are already in `pre`; `pre` IS the body's
+// weight register set (it is reloaded by the rolling prefetch and holds nothing useful afterwards)
 template <int KF, int NW, int XSRC, int EPI>
-VLO_DEV void gemv16_dev(const GemvArgs &a, const int vbx, const int vby, const int vgx, float4 *red, const frag_ab (&pre)[KF]) {
+VLO_DEV void gemv16_dev(const GemvArgs &a, const int vbx, const int vby, const int vgx, float4 *red, frag_ab (&pre)[KF]) {
 #define VLO_GEMV_BX vbx
 #define VLO_GEMV_BY vby
 #define VLO_GEMV_GX vgx
-#define VLO_GEMV_PRELOADED pre
+#define VLO_GEMV_WR_REF pre
+#define VLO_GEMV_PRELOADED 1
 #include "gemv_body.inc"
 #undef VLO_GEMV_BX
 #undef VLO_GEMV_BY
 #undef VLO_GEMV_GX
+#undef VLO_GEMV_WR_REF
 #undef VLO_GEMV_PRELOADED
 }
 
