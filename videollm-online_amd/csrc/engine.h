@@ -78,7 +78,8 @@ struct vlo_session {
     bool has_logits = false;
     int fused_rows = 0;                          // chunks of <= this many rows take run_chunk_fused (VLO_FUSED_ROWS at creation; 0 = off)
     int persistent_blocks = 0;                   // > 0: 16-row chunks run one persistent launch per layer on this many blocks (VLO_PERSISTENT)
-    unsigned *bar = nullptr;                     // persistent layer kernel: [0] barrier counter, [1] sticky time-out word
+    unsigned *bar = nullptr;                     // persistent layer kernel: the flat barrier counter
+    unsigned *bar_err_host = nullptr;            // pinned, device-visible: sticky time-out word of the grid barriers (read without a sync)
     unsigned bar_issued = 0;                     // arrivals every block has made so far (host-side count, wraps)
     int barrier_kind = 0;                        // VLO_PERSISTENT_BARRIER=xcd: XCD-hierarchical grid barrier (zeroed state per launch)
     unsigned *bar_xcd = nullptr;

@@ -429,6 +429,11 @@ int vlo_session_create(vlo_engine *e, int64_t max_tokens_hint, vlo_session **out
                 vlo_session_destroy(s);
                 return rc;
             }
+            if (hipHostMalloc((void **)&s->bar_err_host, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+                vlo_session_destroy(s);
+                return fail(VLO_E_HIP, "hipHostMalloc failed");
+            }
+            *s->bar_err_host = 0u;
             s->persistent_blocks = nb;
             s->persistent_step = getenv("VLO_PERSISTENT_STEP") && atoi(getenv("VLO_PERSISTENT_STEP")) != 0;
         }
@@ -456,6 +461,7 @@ void vlo_session_destroy(vlo_session *s) {
     vlo_session_reset(s);
     for (void *p : s->owned) hipFree(p);
     if (s->host_tok) hipHostFree(s->host_tok);
+    if (s->bar_err_host) hipHostFree(s->bar_err_host);
     if (s->host_pt) hipHostFree(s->host_pt);
     delete s;
 }
@@ -660,12 +666,8 @@ static int run_chunk_persistent(vlo_session *s, const unsigned short *src, int m
     const vlo_config &c = e->cfg;
     const int H = c.hidden_size, I = c.intermediate_size, hd = e->head_dim, nh = c.num_heads;
     int rc;
-    {
-        unsigned err = 0;
-        HIP_TRY(hipMemcpyAsync(&err, s->bar + 1, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (err) return fail(VLO_E_HIP, "persistent layer kernel: a grid barrier timed out (are all blocks resident?)");
-    }
+    if (*(volatile unsigned *)s->bar_err_host)
+        return fail(VLO_E_HIP, "persistent layer kernel: a grid barrier timed out (are all blocks resident?); results since then are invalid");
     if ((rc = ensure_pages(s, s->len + m, st))) return rc;
     const KvGeom kv = kv_geom(s);
     HIP_TRY(copy_rows_launch(src, s->h, m, H, st));
@@ -703,7 +705,7 @@ static int run_chunk_persistent(vlo_session *s, const unsigned short *src, int m
         L.q = s->q; L.kv = kv; L.layer = l; L.nh = nh; L.G = ag.G; L.KS = ag.KS; L.chunk = ag.chunk; L.nsplit = ag.nsplit;
         L.attn_threads = ag.nhg * ag.KS * 64; L.pos0 = s->len; L.scale = ag.scale;
         L.part_o = s->part_o; L.part_ml = s->part_ml; L.attn_out = s->attn;
-        L.bar_counter = s->bar; L.bar_err = s->bar + 1; L.bar_base = s->bar_issued;
+        L.bar_counter = s->bar; L.bar_err = s->bar_err_host; L.bar_base = s->bar_issued;
         L.bar_timeout_ticks = 200000000;              // 2 s of the 100 MHz counter
         {
             static const int pf = getenv("VLO_PERSISTENT_PREFETCH") ? atoi(getenv("VLO_PERSISTENT_PREFETCH")) : 1;

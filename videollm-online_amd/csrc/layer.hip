@@ -55,7 +55,7 @@ VLO_DEV bool spin_until(unsigned *p, unsigned want, unsigned *err, long long tim
     const long long t0 = wall_clock64();
     while ((int)(ld_relaxed(p) - want) < 0) {
         if (wall_clock64() - t0 > timeout_ticks) {                 // a block that is not resident, or a dead peer: do not hang
-            __hip_atomic_fetch_or((lgu32 *)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // pinned host word
             return false;
         }
         __builtin_amdgcn_s_sleep(2);
