@@ -176,7 +176,9 @@ VLO_DEV void attn_chunk_dev(const bf16_t *q, KvGeom kv, int layer, int nh, int G
 #define VLO_ATTN_BZ 0
 #define VLO_ATTN_GX vgx
 #define VLO_ATTN_EXIT break
+#define VLO_ATTN_NO_KPREFETCH 1
 #include "attn_body.inc"
+#undef VLO_ATTN_NO_KPREFETCH
 #undef VLO_ATTN_BX
 #undef VLO_ATTN_BY
 #undef VLO_ATTN_BZ
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(512) void llm_layer_kernel(LayerArgs L) {
 
 // all decoder layers of a step in ONE launch: `layers` = device array of the per-layer arguments (bar_base of the first one counts)
 template <int KFH, int KFI, int HD, int HPW>
-__global__ __launch_bounds__(512) void llm_step_kernel(const LayerArgs *layers, int num_layers) {
+__global__ __launch_bounds__(512) void llm_step_kernel(const LayerArgs *__restrict__ layers, int num_layers) {
     extern __shared__ __attribute__((aligned(16))) float4 lds[];
     BarrierCtx bar;
     barrier_init(bar, layers[0], gridDim.x);
