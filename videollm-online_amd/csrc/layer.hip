@@ -125,6 +125,16 @@ VLO_DEV void barrier_init(BarrierCtx &b, const LayerArgs &L, int nb) {
     }
 }
 
+// The phase bodies derive their lane / wave / row indices from threadIdx.x; left alone, the compiler shares those address
+// computations across the phases and keeps them in registers through the attention phase, which has none to spare (24 instead
+// of 68 B of scratch per lane in the 8B kernel).  The attention body therefore sees its own opaque copy of the thread index.
+struct TidX { unsigned x; };
+VLO_DEV TidX opaque_tid() {
+    unsigned v = threadIdx.x;
+    asm volatile("" : "+v"(v));
+    return TidX{v};
+}
+
 // ---- the phase bodies, from the same text as the stand-alone kernels ------------------------------------------------------
 // (rounding points follow the reference's bf16 CPU path — see gemv.hip / llm_ops.hip)
 VLO_DEV float silu_bf16(float g) { return rbf(g / (1.0f + __expf(-g))); }
@@ -170,6 +180,8 @@ VLO_DEV void gemv16_dev(const GemvArgs &a, const int vbx, const int vby, const i
 template <int HD, int HPW>
 VLO_DEV void attn_chunk_dev(const bf16_t *q, KvGeom kv, int layer, int nh, int G, int KS, int64_t pos0, int n, int chunk, float scale,
                             float *part_o, float *part_ml, const int vbx, const int vby, const int vgx, float4 *lds_o) {
+    const TidX vlo_tid = opaque_tid();
+#define threadIdx vlo_tid
     do {                                                           // VLO_ATTN_EXIT leaves the body, not the kernel
 #define VLO_ATTN_BX vbx
 #define VLO_ATTN_BY vby
@@ -185,6 +197,7 @@ VLO_DEV void attn_chunk_dev(const bf16_t *q, KvGeom kv, int layer, int nh, int G
 #undef VLO_ATTN_GX
 #undef VLO_ATTN_EXIT
     } while (0);
+#undef threadIdx
 }
 
 #define RMS_THREADS 512
