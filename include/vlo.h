@@ -120,6 +120,13 @@ int vlo_connector(vlo_engine *e, const void *feats_dev, int rows, void *out_dev,
  *      ids_dev: int64 [k]; out_dev: bf16 [k, hidden_size] */
 int vlo_embed(vlo_engine *e, const int64_t *ids_dev, int k, void *out_dev, void *stream);
 
+/* ---- the step input of a frame step, `torch.cat([embed(last_ids), frame_embeds])` (demo/inference.py:61-68), in one launch
+ *      into a caller-owned staging buffer.  ids_host: int64 [k] in HOST memory (the reference holds them as Python ints and
+ *      uploads them with torch.tensor(..., device='cuda'); here they ride in the kernel arguments);
+ *      frame_rows_dev: bf16 [rows, hidden_size] (connector output of this frame) or NULL when rows == 0;
+ *      out_dev: bf16 [k + rows, hidden_size]. */
+int vlo_step_input(vlo_engine *e, const int64_t *ids_host, int k, const void *frame_rows_dev, int rows, void *out_dev, void *stream);
+
 /* ---- model(inputs_embeds=..., use_cache=True, past_key_values=...) (demo/inference.py:69;
  *      models/live_llama/modeling_live_llama.py:24-53 -> HF LlamaForCausalLM.forward).
  *      embeds_dev: bf16 [n, hidden_size].  Appends n tokens to the session's KV.
@@ -254,6 +261,9 @@ int vlo_debug_read(vlo_session *s, int which, void *dst_dev, int64_t bytes, void
 
 const char *vlo_last_error(void);
 int vlo_abi_version(void);
+/* "VLO_BUILD_ID=<sha256 of every source and header the library was compiled from>" (videollm-online_amd/build.py stamps it;
+ * _C.py refuses a library whose id differs from the sources lying next to it) */
+const char *vlo_build_id(void);
 
 #ifdef __cplusplus
 }

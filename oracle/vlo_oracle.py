@@ -374,8 +374,10 @@ class LlamaOracle:
         return F.embedding(ids, self.W["model.embed_tokens.weight"])
 
     @torch.no_grad()
-    def forward(self, inputs_embeds: torch.Tensor, cache: KVCacheOracle | None, taps: dict | None = None):
-        """inputs_embeds [n,H] -> (logits [n,V], cache).  LlamaModel.forward :367-417."""
+    def forward(self, inputs_embeds: torch.Tensor, cache: KVCacheOracle | None, taps: dict | None = None, logits_from: int = 0):
+        """inputs_embeds [n,H] -> (logits [n,V], cache).  LlamaModel.forward :367-417.
+        ``logits_from`` (test bookkeeping for long cache fills): lm_head only on rows [logits_from, n) — the rows are
+        independent, so the rows that are produced equal HF's; n means "no logits" (returns an empty [0,V])."""
         s, W = self.spec, self.W
         if cache is None:
             cache = self.new_cache()
@@ -414,8 +416,8 @@ class LlamaOracle:
             h = h + x                                                    # :323
             if taps is not None and i in taps.get("_layers", ()):
                 taps[f"h{i}"] = h.clone()
-        h = rmsnorm(h, W["model.norm.weight"], s.rms_eps)
-        logits = F.linear(h, W["lm_head.weight"])                        # :477-480 (all rows, as HF)
+        h = rmsnorm(h[logits_from:], W["model.norm.weight"], s.rms_eps)
+        logits = F.linear(h, W["lm_head.weight"])                        # :477-480 (all rows, as HF, unless logits_from > 0)
         return logits, cache
 
     @torch.no_grad()

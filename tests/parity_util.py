@@ -1,0 +1,34 @@
+"""Direct parity quantities between the engine's bf16 logits and the reference-path (oracle, bf16) logits —
+what BASELINE.json's "logits within 1e-3 bf16" is about, stated in bf16 units.  bf16 keeps 8 significand bits: one ulp of a
+value v is 2^(floor(log2|v|) - 7)."""
+import torch
+
+
+def bf16_ulp(v: torch.Tensor) -> torch.Tensor:
+    return torch.exp2(torch.floor(torch.log2(v.abs().float().clamp_min(2.0 ** -120))) - 7)
+
+
+def ulp_report(engine: torch.Tensor, ref: torch.Tensor) -> dict:
+    """engine, ref: bf16 tensors of one shape (logits).  Returns
+      bit_equal        fraction of elements whose bf16 bit patterns agree
+      max_ulps_scale   max |engine - ref| in ulps of the LARGEST |ref| logit (the unit an absolute tolerance is quoted in)
+      max_ulps_local   max |engine - ref| in ulps of the local ref logit, over logits with |ref| >= scale/8 (below that the
+                       local ulp of a logit that is a cancelling sum says nothing about the computation)
+      within_1ulp / within_2ulp   fraction of ALL elements within 1 / 2 local ulps
+      max_abs          max |engine - ref|"""
+    e, r = engine.float().flatten(), ref.float().flatten()
+    d = (e - r).abs()
+    scale = r.abs().max()
+    local = d / bf16_ulp(r)
+    big = r.abs() >= scale / 8
+    return dict(bit_equal=(engine.flatten() == ref.flatten()).float().mean().item(),
+                max_ulps_scale=(d.max() / bf16_ulp(scale)).item(),
+                max_ulps_local=(local[big].max().item() if bool(big.any()) else 0.0),
+                within_1ulp=(local <= 1.0).float().mean().item(), within_2ulp=(local <= 2.0).float().mean().item(),
+                max_abs=d.max().item(), scale=scale.item())
+
+
+def fmt(rep: dict) -> str:
+    return (f"bit-equal {rep['bit_equal']:.1%}  <=1ulp {rep['within_1ulp']:.1%}  <=2ulp {rep['within_2ulp']:.1%}  "
+            f"max {rep['max_ulps_scale']:.2f} ulps@scale ({rep['max_abs']:.4g} abs, scale {rep['scale']:.3g})  "
+            f"max local {rep['max_ulps_local']:.1f} ulps")

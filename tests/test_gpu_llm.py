@@ -10,8 +10,15 @@ import pytest
 import torch
 
 from oracle import vlo_oracle as O
+from parity_util import fmt, ulp_report
 
 pytestmark = pytest.mark.gpu
+
+# Direct engine-vs-reference-path gates (VERDICT r1 weak #2a), set from the first hardware measurement of these quantities
+# (gpurun_out r2; DESIGN.md section 2 records the numbers): fraction of logits whose bf16 bit pattern equals the reference
+# bf16 CPU path's, and the largest difference in bf16 ulps of the largest logit.
+MIN_BIT_EQUAL = {"toy": 0.5, "toy128": 0.5, "tinyllama-2l": 0.5, "llama-3-8b-2l": 0.5}
+MAX_ULPS_AT_SCALE = 2.0
 
 
 def _engine(spec, w, kv_pool_tokens=4096, vit=None):
@@ -90,10 +97,11 @@ def test_llm_stream_parity(name, seed):
         e, r, scale = _three_way(allr, rl, gl)
         worst = max(worst, e / scale)
         assert e <= 1.5 * r + 1e-3 * scale, f"step {i}: engine err {e} vs reference-bf16 err {r} (scale {scale})"
-        # most logits should be bit-identical to the reference's bf16 path
-        same = (allr == rl).float().mean().item()
-        print(f"[{name}] step {i}: engine err {e:.4g} ref-bf16 err {r:.4g} scale {scale:.3g} bit-equal {same:.1%}")
-        assert same > 0.15, f"step {i}: only {same:.2%} of logits bit-equal to the reference bf16 path"
+        # the direct quantity: engine vs the reference's bf16 path, in bf16 ulps
+        rep = ulp_report(allr, rl)
+        print(f"[{name}] step {i}: engine err {e:.4g} ref-bf16 err {r:.4g} scale {scale:.3g} | engine vs ref-bf16: {fmt(rep)}")
+        assert rep["bit_equal"] >= MIN_BIT_EQUAL[name], f"step {i}: only {rep['bit_equal']:.2%} of logits bit-equal to the reference bf16 path"
+        assert rep["max_ulps_scale"] <= MAX_ULPS_AT_SCALE, f"step {i}: {rep['max_ulps_scale']:.2f} bf16 ulps (at logit scale) from the reference bf16 path"
         assert _tokens_agree(int(last.float().argmax()), gl[-1], int(rl[-1].float().argmax()))
     # KV contents (layer 0 and last, kv head 0) against the reference cache
     for layer in (0, spec.num_layers - 1):
@@ -466,4 +474,70 @@ def test_full_depth_8b_shape_aliased_layers():
         if O.top2_margin(gl[-1])[0] > 0.25:
             assert int(last.float().argmax()) == int(gl[-1].argmax())
     assert len(sess) == len(rc) == 69
+    eng.close()
+
+
+def test_step_input_equals_embed_cat():
+    """vlo_step_input (ids as kernel arguments + frame rows, one launch) == torch.cat([embed(ids), frame_rows]) bit for bit
+    (demo/inference.py:61-68), for id lists shorter and longer than one launch's worth (32)."""
+    spec = O.LLM_SPECS["toy128"]
+    w = O.init_llm_weights(spec, seed=3)
+    eng = _engine(spec, w)
+    g = torch.Generator().manual_seed(5)
+    H = spec.hidden_size
+    stage = torch.empty(128, H, dtype=torch.bfloat16, device="cuda")
+    for k, rows in ((1, 10), (3, 10), (35, 10), (70, 10), (4, 0), (0, 10)):
+        ids = torch.randint(0, spec.vocab_size, (k,), generator=g).tolist()
+        fr = torch.randn(rows, H, generator=g).bfloat16().cuda() if rows else None
+        out = eng.step_input(ids, fr, stage)
+        parts = ([eng.embed(torch.tensor(ids))] if k else []) + ([fr] if rows else [])
+        torch.cuda.synchronize()
+        assert out.shape == (k + rows, H) and torch.equal(out, torch.cat(parts)), (k, rows)
+    eng.close()
+
+
+@pytest.mark.parametrize("name,seed,checkpoints", [("llama-3-8b-2l", 11, (4096, 13245))])
+def test_config2_context_logits_parity(name, seed, checkpoints):
+    """BASELINE.json configs[1] at its context (VERDICT r1 weak #2b): two DISTINCT decoder layers at the true Llama-3-8B
+    width, the cache filled to 4 096 and then to 13 245 tokens (where a 10 min @ 2 FPS stream ends) through the engine's
+    64-token block path and, in lock-step, through the oracle in bf16 (the reference CPU/sdpa path) and fp32 (gold); at each
+    length a frame step (n = 11) and a decode step (n = 1) are compared 3-way on the LOGITS of every row, plus the direct
+    engine-vs-reference quantities in bf16 ulps."""
+    spec = O.LLM_SPECS[name]
+    w = O.init_llm_weights(spec, seed=seed)
+    toks = O.default_tokens(spec, seed=7, n_start=35)
+    ref, gold = O.LlamaOracle(spec, w, torch.bfloat16), O.LlamaOracle(spec, w, torch.float32)
+    eng = _engine(spec, w, kv_pool_tokens=16384)
+    sess = eng.new_session()
+    g = torch.Generator().manual_seed(seed + 1)
+    H = spec.hidden_size
+    rc = gc = None
+    Lc = 0
+    for target in checkpoints:
+        while Lc < target:                       # interleaved text + frame-like rows, 1 024 at a time on the CPU side
+            m = min(1024, target - Lc)
+            ids = torch.randint(0, spec.vocab_size, (m,), generator=g)
+            x = ref.embed(ids)
+            fr = torch.rand(m, generator=g) < 0.9          # ~10 of 11 stream tokens are frame tokens
+            x[fr] = torch.randn(int(fr.sum()), H, generator=g).bfloat16()
+            _, rc = ref.forward(x, rc, logits_from=m)
+            _, gc = gold.forward(x, gc, logits_from=m)
+            eng.llm_step(sess, x.cuda(), want_last=False)
+            Lc += m
+        assert sess.get_seq_length() == len(rc) == Lc
+        frame = torch.cat([ref.embed(torch.tensor([toks.interval_id])), torch.randn(10, H, generator=g).bfloat16()])
+        for kind, x in (("frame n=11", frame), ("decode n=1", ref.embed(torch.tensor([17])))):
+            rl, rc = ref.forward(x, rc)
+            gl, gc = gold.forward(x, gc)
+            _, allr = eng.llm_step(sess, x.cuda(), want_last=False, want_all=True)
+            torch.cuda.synchronize()
+            allr = allr.cpu()
+            e, r, scale = _three_way(allr, rl, gl)
+            rep = ulp_report(allr, rl)
+            print(f"[{name}] Lc={Lc} {kind}: engine err {e:.4g} ref-bf16 err {r:.4g} scale {scale:.3g} | engine vs ref-bf16: {fmt(rep)}")
+            assert e <= 1.5 * r + 1e-3 * scale, f"Lc={Lc} {kind}: engine err {e} vs reference-bf16 err {r}"
+            assert rep["bit_equal"] >= 0.4 and rep["max_ulps_scale"] <= MAX_ULPS_AT_SCALE, fmt(rep)
+            assert _tokens_agree(int(allr[-1].float().argmax()), gl[-1], int(rl[-1].float().argmax()))
+            Lc += x.shape[0]
+    sess.close()
     eng.close()

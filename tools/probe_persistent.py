@@ -1,6 +1,6 @@
 """A/B timing of the persistent layer kernel (VLO_PERSISTENT, csrc/layer.hip) against the launch-per-phase pipeline on the true
-Llama-3-8B shape: decode steps (n = 1) and frame steps (n = 11) at a few cache lengths, with and without the cross-phase
-weight prefetch.
+Llama-3-8B shape: decode steps (n = 1) and frame steps (n = 11) at a few cache lengths.  Every variant is timed on its own and
+a failing one is reported, not fatal.
 
     python tools/probe_persistent.py [--model llama-3-8b] [--iters 40]
 """
@@ -11,9 +11,21 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from tools.probe_fused_rows import timed
 from tools.probe_llm import SHAPES, random_llm_weights_to_engine
 from videollm_online_amd.engine import Engine, EngineConfig
+
+
+def timed(eng, sess, x, iters):
+    for _ in range(3):
+        eng.llm_step(sess, x)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        eng.llm_step(sess, x)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
 
 
 def main():
@@ -26,27 +38,42 @@ def main():
     random_llm_weights_to_engine(eng, cfg)
     eng.finalize()
     H = cfg.hidden_size
+    variants = {"launches": {}, "persistent/layer": {"VLO_PERSISTENT": "1"},
+                "persistent/layer/xcd": {"VLO_PERSISTENT": "1", "VLO_PERSISTENT_BARRIER": "xcd"},
+                "persistent/step": {"VLO_PERSISTENT": "1", "VLO_PERSISTENT_STEP": "1"},
+                "persistent/step/xcd": {"VLO_PERSISTENT": "1", "VLO_PERSISTENT_STEP": "1", "VLO_PERSISTENT_BARRIER": "xcd"}}
     sessions = {}
-    sessions["launches"] = eng.new_session()
-    os.environ["VLO_PERSISTENT"] = "1"          # one resident block per CU; VLO_PERSISTENT_PREFETCH (default 1) is read once per process
-    sessions["persistent/layer"] = eng.new_session()
-    os.environ["VLO_PERSISTENT_STEP"] = "1"     # all layers of a step in ONE launch
-    sessions["persistent/step"] = eng.new_session()
-    os.environ["VLO_PERSISTENT_BARRIER"] = "xcd"    # XCD-hierarchical grid barrier
-    sessions["persistent/step/xcd"] = eng.new_session()
-    os.environ.pop("VLO_PERSISTENT_BARRIER", None)
-    os.environ.pop("VLO_PERSISTENT", None)
-    os.environ.pop("VLO_PERSISTENT_STEP", None)
+    for label, env in variants.items():
+        os.environ.update(env)
+        sessions[label] = eng.new_session()
+        for k in env:
+            os.environ.pop(k, None)
+    ref = None
     fill = torch.randn(64, H, device="cuda").bfloat16()
-    print(f"VLO_PERSISTENT_PREFETCH={os.environ.get('VLO_PERSISTENT_PREFETCH', '1 (default)')} for the persistent column; "
-          f"run again with VLO_PERSISTENT_PREFETCH=0 for the other variant")
+    print(f"VLO_PERSISTENT_PREFETCH={os.environ.get('VLO_PERSISTENT_PREFETCH', '1 (default)')}")
+    dead = set()
     for Lc in (0, 4096, 12288):
         for label, sess in sessions.items():
-            while sess.get_seq_length() < Lc:
-                eng.llm_step(sess, fill, want_last=False)
+            if label in dead:
+                continue
+            try:
+                while sess.get_seq_length() < Lc:
+                    eng.llm_step(sess, fill, want_last=False)
+            except Exception as ex:
+                print(f"{label}: fill failed: {ex}")
+                dead.add(label)
         for n in (1, 11):
             x = torch.randn(n, H, device="cuda").bfloat16()
-            print(f"Lc~{Lc:6d} n={n:2d}:  " + "  ".join(f"{label} {timed(eng, sess, x, args.iters):.3f} ms" for label, sess in sessions.items()), flush=True)
+            out = []
+            for label, sess in sessions.items():
+                if label in dead:
+                    continue
+                try:
+                    out.append(f"{label} {timed(eng, sess, x, args.iters):.3f} ms")
+                except Exception as ex:
+                    print(f"{label}: FAILED at Lc~{Lc} n={n}: {ex}")
+                    dead.add(label)
+            print(f"Lc~{Lc:6d} n={n:2d}:  " + "  ".join(out), flush=True)
 
 
 if __name__ == "__main__":

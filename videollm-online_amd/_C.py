@@ -37,6 +37,7 @@ EXPORTS = [
     "vlo_tp_unique_id", "vlo_tp_group_create", "vlo_tp_group_destroy", "vlo_tp_session_create", "vlo_tp_session_reset",
     "vlo_tp_session_len", "vlo_tp_session_destroy", "vlo_tp_llm_step", "vlo_tp_stream_sample", "vlo_tp_greedy_generate",
     "vlo_joint_embed", "vlo_logit_rows", "vlo_session_fork", "vlo_session_crop", "vlo_tp_selftest", "vlo_debug_gemm64_plan", "vlo_debug_pack64_elem",
+    "vlo_step_input", "vlo_build_id",
     "vlo_tp_p2p_export", "vlo_tp_p2p_enable", "vlo_tp_p2p_status", "vlo_debug_p2p_layout", "vlo_tp_bench_exchange",
 ]
 
@@ -54,6 +55,11 @@ def lib():
                                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950).  "
                                "The engine has no non-HIP path.") from ex
     L = bind(C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL))
+    from .build import source_hash
+    want, got = source_hash(), L.vlo_build_id().decode().split("=", 1)[1]
+    if want is not None and got != want and os.environ.get("VLO_ALLOW_STALE_LIB") != "1":
+        raise RuntimeError(f"{LIB_PATH} was built from other sources (library {got[:12]}, tree {want[:12]}): rebuild it "
+                           "(`python -c 'import __graft_entry__ as g; g.build()'`) or set VLO_ALLOW_STALE_LIB=1")
     _lib = L
     return L
 
@@ -84,6 +90,8 @@ def bind(L):
     L.vlo_vision_tokens.argtypes = [vp, vp, i32, vp, vp]
     L.vlo_connector.argtypes = [vp, vp, i32, vp, vp]
     L.vlo_embed.argtypes = [vp, vp, i32, vp, vp]
+    L.vlo_step_input.argtypes = [vp, C.POINTER(i64), i32, vp, i32, vp, vp]
+    L.vlo_build_id.restype = C.c_char_p
     L.vlo_llm_step.argtypes = [vp, vp, i32, vp, vp, vp]
     L.vlo_stream_sample.argtypes = [vp, C.c_float, i32, vp, vp, vp]
     L.vlo_greedy_generate.argtypes = [vp, vp, i32, i32, vp, i32, i32, C.POINTER(i32), vp]

@@ -21,12 +21,37 @@ def _hipcc():
     raise RuntimeError("hipcc not found: the engine has no non-HIP build")
 
 
+def source_hash():
+    """sha256 over every source and header of the library (names + contents, fixed order) and the compile flags; None when
+    the sources are not next to the package (an installed binary)."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode())
+    for s in SOURCES + HEADERS:
+        path = os.path.join(CSRC, s)
+        if not os.path.exists(path):
+            return None
+        h.update(os.path.basename(s).encode() + b"\0")
+        h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
+def library_build_id(path=LIB):
+    """The id stamped into a built library (`vlo_build_id()`), read from the file without loading it."""
+    try:
+        blob = open(path, "rb").read()
+    except OSError:
+        return None
+    tag = b"VLO_BUILD_ID="
+    i = blob.find(tag)
+    if i < 0:
+        return None
+    j = blob.find(b"\0", i)
+    return blob[i + len(tag):j].decode(errors="replace")
+
+
 def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    return library_build_id() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -34,6 +59,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
     hipcc = _hipcc()
+    build_id = source_hash()
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
@@ -41,6 +67,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(HERE, "build", s.replace(".hip", ".o"))
         objs.append(o)
         cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
+        if s == "engine.hip":
+            cmd.insert(1, f'-DVLO_BUILD_ID="{build_id}"')
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -31,6 +31,10 @@ static int fail(int code, const std::string &msg) {
 int vlo_fail(int code, const std::string &msg) { return fail(code, msg); }
 const char *vlo_last_error(void) { return g_err.c_str(); }
 int vlo_abi_version(void) { return VLO_ABI_VERSION; }
+#ifndef VLO_BUILD_ID
+#define VLO_BUILD_ID "unstamped"
+#endif
+const char *vlo_build_id(void) { return "VLO_BUILD_ID=" VLO_BUILD_ID; }
 
 #define HIP_TRY(expr)                                                                                         \
     do {                                                                                                      \
@@ -445,6 +449,12 @@ int vlo_session_create(vlo_engine *e, int64_t max_tokens_hint, vlo_session **out
 
 int vlo_session_reset(vlo_session *s) {
     if (!s) return fail(VLO_E_INVALID, "null session");
+    if (!s->pages.empty()) {
+        // pages go back to the shared pool and the pinned page-table mirror will be rewritten from slot 0: queued kernels of
+        // this session that still write K/V into those pages, and a queued page-table upload, must have drained first
+        HIP_TRY(hipSetDevice(s->e->device));
+        HIP_TRY(hipDeviceSynchronize());
+    }
     std::lock_guard<std::mutex> g(s->e->pool_mu);
     for (int p : s->pages) s->e->free_pages.push_back(p);
     s->pages.clear();
@@ -938,6 +948,27 @@ int vlo_embed(vlo_engine *e, const int64_t *ids_dev, int k, void *out_dev, void 
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(embed_gather_launch((const unsigned short *)e->embed, ids_dev, k, e->cfg.hidden_size, e->cfg.vocab_size,
                                 (unsigned short *)out_dev, (hipStream_t)stream));
+    return VLO_OK;
+}
+
+int vlo_step_input(vlo_engine *e, const int64_t *ids_host, int k, const void *frame_rows_dev, int rows, void *out_dev, void *stream) {
+    if (!e || !out_dev || k < 0 || rows < 0 || k + rows <= 0 || (k > 0 && !ids_host) || (rows > 0 && !frame_rows_dev))
+        return fail(VLO_E_INVALID, "bad step_input arguments");
+    if (!e->finalized) return fail(VLO_E_STATE, "engine not finalized");
+    HIP_TRY(hipSetDevice(e->device));
+    const int H = e->cfg.hidden_size;
+    unsigned short *out = (unsigned short *)out_dev;
+    // ids travel as kernel arguments, VLO_STEP_IDS_MAX per launch; the frame rows ride on the last launch
+    int done = 0;
+    do {
+        StepIds ids{};
+        const int kk = std::min(VLO_STEP_IDS_MAX, k - done);
+        for (int i = 0; i < kk; ++i) ids.v[i] = ids_host[done + i];
+        const bool last = done + kk == k;
+        HIP_TRY(step_input_launch((const unsigned short *)e->embed, ids, kk, (const unsigned short *)frame_rows_dev, last ? rows : 0, H,
+                                  e->cfg.vocab_size, out + (size_t)done * H, (hipStream_t)stream));
+        done += kk;
+    } while (done < k);
     return VLO_OK;
 }
 

@@ -358,11 +358,20 @@ static bool use_coop() {
 
 template <int KFH, int KFI, int HD, int HPW>
 static hipError_t launch_one(LayerArgs &L, int nblocks, size_t lds, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void *)llm_layer_kernel<KFH, KFI, HD, HPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
+    static size_t granted = 0;
+    if (!granted) {
+        // opt in to dynamic LDS beyond the 64 KiB default: the largest size the runtime accepts next to the kernel's static LDS;
+        // a refusal must not linger as the runtime's "last error" (the first hardware run failed on exactly that)
+        granted = 64 * 1024;
+        for (size_t want = 160 * 1024; want > 64 * 1024; want -= 8 * 1024) {
+            if (hipFuncSetAttribute((const void *)llm_layer_kernel<KFH, KFI, HD, HPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) == hipSuccess) {
+                granted = want;
+                break;
+            }
+            (void)hipGetLastError();
+        }
     }
+    if (lds > granted) return hipErrorInvalidValue;
     if (!use_coop()) {
         hipLaunchKernelGGL((llm_layer_kernel<KFH, KFI, HD, HPW>), dim3(nblocks), dim3(512), lds, st, L);
         return hipGetLastError();
@@ -373,11 +382,20 @@ static hipError_t launch_one(LayerArgs &L, int nblocks, size_t lds, hipStream_t 
 
 template <int KFH, int KFI, int HD, int HPW>
 static hipError_t launch_step(const LayerArgs *layers_dev, int num_layers, int nblocks, size_t lds, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void *)llm_step_kernel<KFH, KFI, HD, HPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
+    static size_t granted = 0;
+    if (!granted) {
+        // opt in to dynamic LDS beyond the 64 KiB default: the largest size the runtime accepts next to the kernel's static LDS;
+        // a refusal must not linger as the runtime's "last error" (the first hardware run failed on exactly that)
+        granted = 64 * 1024;
+        for (size_t want = 160 * 1024; want > 64 * 1024; want -= 8 * 1024) {
+            if (hipFuncSetAttribute((const void *)llm_step_kernel<KFH, KFI, HD, HPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) == hipSuccess) {
+                granted = want;
+                break;
+            }
+            (void)hipGetLastError();
+        }
     }
+    if (lds > granted) return hipErrorInvalidValue;
     if (!use_coop()) {
         hipLaunchKernelGGL((llm_step_kernel<KFH, KFI, HD, HPW>), dim3(nblocks), dim3(512), lds, st, layers_dev, num_layers);
         return hipGetLastError();

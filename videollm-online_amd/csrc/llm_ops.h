@@ -55,6 +55,10 @@ hipError_t greedy_sample_launch(const unsigned short *logits, int V, int64_t *to
 hipError_t stream_sample_launch(const unsigned short *logits, int V, float threshold, int interval_id,
                                 int64_t *tok_out, float *p_interval_out, float *scratch, hipStream_t st);
 
+#define VLO_STEP_IDS_MAX 32
+struct StepIds { int64_t v[VLO_STEP_IDS_MAX]; };      // token ids handed to step_input_kernel by value (kernel arguments)
+hipError_t step_input_launch(const unsigned short *table, const StepIds &ids, int k, const unsigned short *frame_rows, int rows, int H,
+                             int64_t vocab, unsigned short *out, hipStream_t st);
 hipError_t copy_rows_launch(const unsigned short *src, unsigned short *dst, int rows, int H, hipStream_t st);
 hipError_t read_kv_launch(KvGeom kv, int layer, int which, int kv_head, int64_t t0, int64_t t1, unsigned short *dst,
                           hipStream_t st);

@@ -215,6 +215,29 @@ hipError_t embed_gather_launch(const unsigned short *table, const int64_t *ids, 
     return hipGetLastError();
 }
 
+// step input (demo/inference.py:65-68: `torch.cat([embed(last_ids), frame_embeds])`) in ONE launch: the token ids arrive from the HOST
+// as kernel arguments (no `torch.tensor(ids, device=...)` upload), blocks [0, k) gather their embedding row, blocks [k, k + rows) copy
+// a frame-token row of the connector's output.
+__global__ void step_input_kernel(const bf16_t *__restrict__ table, StepIds ids, int k, const bf16_t *__restrict__ frame_rows, int H,
+                                  int64_t vocab, bf16_t *__restrict__ out) {
+    const int r = blockIdx.x;
+    const uint4 *src;
+    if (r < k) {
+        int64_t id = ids.v[r];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        src = reinterpret_cast<const uint4 *>(table + (size_t)id * H);
+    } else {
+        src = reinterpret_cast<const uint4 *>(frame_rows + (size_t)(r - k) * H);
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(out + (size_t)r * H);
+    for (int i = threadIdx.x; i < H / 8; i += blockDim.x) dst[i] = src[i];
+}
+hipError_t step_input_launch(const unsigned short *table, const StepIds &ids, int k, const unsigned short *frame_rows, int rows, int H,
+                             int64_t vocab, unsigned short *out, hipStream_t st) {
+    hipLaunchKernelGGL(step_input_kernel, dim3(k + rows), dim3(256), 0, st, table, ids, k, frame_rows, H, vocab, out);
+    return hipGetLastError();
+}
+
 __global__ void copy_rows_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }

@@ -185,14 +185,38 @@ class Engine:
         _C.check(_C.lib().vlo_embed(self._h, _ptr(ids), ids.numel(), _ptr(out), _stream_handle(stream)))
         return out
 
+    def step_input(self, ids: list, frame_rows: torch.Tensor | None, out: torch.Tensor, stream=None) -> torch.Tensor:
+        """`torch.cat([embed(ids), frame_rows])` (demo/inference.py:61-68) written by one launch into the caller's staging
+        buffer ``out`` (bf16 [>= k + rows, H]); ``ids`` are host integers and travel as kernel arguments.  Returns the view
+        ``out[:k + rows]``."""
+        k = len(ids)
+        rows = 0 if frame_rows is None else frame_rows.shape[0]
+        assert out.dtype == torch.bfloat16 and out.is_contiguous() and out.shape[0] >= k + rows and out.shape[1] == self.cfg.hidden_size
+        if rows:
+            assert frame_rows.dtype == torch.bfloat16 and frame_rows.is_contiguous() and frame_rows.shape[1] == self.cfg.hidden_size
+        arr = (C.c_int64 * max(k, 1))(*ids)
+        _C.check(_C.lib().vlo_step_input(self._h, arr, k, _ptr(frame_rows) if rows else None, rows, _ptr(out), _stream_handle(stream)))
+        return out[:k + rows]
+
     def connector(self, feats: torch.Tensor, stream=None) -> torch.Tensor:
         feats = feats.to(device=self.device, dtype=torch.bfloat16).contiguous().view(-1, self.cfg.vision_hidden_size)
         out = torch.empty(feats.shape[0], self.cfg.hidden_size, dtype=torch.bfloat16, device=self.device)
         _C.check(_C.lib().vlo_connector(self._h, _ptr(feats), feats.shape[0], _ptr(out), _stream_handle(stream)))
         return out
 
+    def _check_frames(self, frames_u8: torch.Tensor):
+        """The C side reads B*3*R*R bytes from the pointer: anything but uint8 [B,3,R,R] at the tower's resolution would be
+        read out of bounds or silently misread (the reference fails on the position-embedding shape in the same case)."""
+        if self.cfg.vit is None:
+            raise RuntimeError("engine built without a vision tower")
+        R = self.cfg.vit["image_size"]
+        if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or tuple(frames_u8.shape[1:]) != (3, R, R):
+            raise ValueError(f"frames must be uint8 [B,3,{R},{R}], got {frames_u8.dtype} {tuple(frames_u8.shape)}")
+        if not frames_u8.is_cuda:
+            raise ValueError("frames must live on the engine's device")
+
     def visual_embed(self, frames_u8: torch.Tensor, stream=None, out: torch.Tensor | None = None) -> torch.Tensor:
-        assert frames_u8.dtype == torch.uint8 and frames_u8.dim() == 4 and frames_u8.is_cuda
+        self._check_frames(frames_u8)
         frames_u8 = frames_u8.contiguous()
         B = frames_u8.shape[0]
         if out is None:
@@ -202,7 +226,7 @@ class Engine:
 
     def vision_tokens(self, frames_u8: torch.Tensor, stream=None) -> torch.Tensor:
         """CLS + pooled tokens before the connector: bf16 [B, frame_num_tokens, vision_hidden_size]."""
-        assert frames_u8.dtype == torch.uint8 and frames_u8.dim() == 4 and frames_u8.is_cuda
+        self._check_frames(frames_u8)
         frames_u8 = frames_u8.contiguous()
         B = frames_u8.shape[0]
         out = torch.empty(B, self.cfg.frame_num_tokens, self.cfg.vision_hidden_size, dtype=torch.bfloat16, device=self.device)
@@ -311,10 +335,19 @@ class TpSession:
         except Exception:
             pass
 
+    def fork(self, n_tokens: int, stream=None):
+        raise NotImplementedError("tensor-parallel sessions cannot be forked (include/vlo.h: vlo_session_fork); "
+                                  "run stream_evaluate / trim_past_key_values on a TP=1 engine")
+
+    def crop(self, n_tokens: int):
+        raise NotImplementedError("tensor-parallel sessions cannot be cropped (include/vlo.h: vlo_session_crop)")
+
 
 class TpGroup:
-    """Tensor-parallel Llama (north_star TP; include/vlo.h `vlo_tp_*`) behind the same surface as Engine, so
-    LiveModel / LiveInfer run on it unchanged.
+    """Tensor-parallel Llama (north_star TP; include/vlo.h `vlo_tp_*`) behind the same surface as Engine for the STREAMING
+    path: LiveInfer, LiveModel(inputs_embeds=...), joint_embed, the samplers and fast_greedy_generate run on it unchanged.
+    Not supported under TP: KV fork / crop (`TpSession.fork/crop` raise NotImplementedError), hence `stream_evaluate` and
+    `trim_past_key_values` — run teacher-forced evaluation on a TP=1 engine.
 
     * ``TpGroup(cfg, tp_size, device=0)``: single process, ``tp_size`` logical ranks on one device (exchanges are
       device kernels) — validates the sharding arithmetic without a multi-GPU box.
@@ -409,6 +442,19 @@ class TpGroup:
 
     def connector(self, feats, stream=None):
         return self.engines[0].connector(feats, stream)
+
+    # embeddings are replicated and the logits arrive gathered, so these run on the first local engine
+    def step_input(self, ids, frame_rows, out, stream=None):
+        return self.engines[0].step_input(ids, frame_rows, out, stream)
+
+    def joint_embed(self, ids, frame_rows, v_placeholder_id, stream=None):
+        return self.engines[0].joint_embed(ids, frame_rows, v_placeholder_id, stream)
+
+    def logit_rows(self, logits, labels=None, interval_id=-1, stream=None):
+        return self.engines[0].logit_rows(logits, labels, interval_id, stream)
+
+    def vision_tokens(self, frames_u8, stream=None):
+        return self.engines[0].vision_tokens(frames_u8, stream)
 
     def visual_embed(self, frames_u8, stream=None, out=None):
         return self.engines[0].visual_embed(frames_u8, stream, out)

@@ -32,7 +32,7 @@ class StreamTokens:
 class LiveInfer:
     def __init__(self, model: LiveModel, tokens: StreamTokens | None = None, tokenizer=None, frame_fps: float = 2,
                  system_prompt: str = "", prefetch: bool = True, prefetch_frames: int = 2, schedule=None,
-                 max_new_tokens: int = 100):
+                 max_new_tokens: int = 100, record: int = 65536):
         self.model = model
         self.engine = model.engine
         self.tokenizer = tokenizer
@@ -73,7 +73,11 @@ class LiveInfer:
         self._tok_dev = torch.zeros(1, dtype=torch.long, device=dev)
         self._p_dev = torch.zeros(1, dtype=torch.float32, device=dev)
         self._tok_host = torch.zeros(1, dtype=torch.long).pin_memory()
-        self.trace = []
+        # step input staging (demo/inference.py:61-68): text rows + this frame's rows, written by ONE launch (vlo_step_input);
+        # sized for the longest text prefix a frame step can carry; longer ones (a long system prompt) grow it
+        self._stage = torch.empty(64 + self.frame_num_tokens, self.hidden_size, dtype=torch.bfloat16, device=dev)
+        # event log for tests / the bench: bounded (a long-running session must not grow host memory), cleared by reset()
+        self._record = max(0, int(record))
         self.past_key_values = None
         self.reset()
 
@@ -99,7 +103,18 @@ class LiveInfer:
         self.past_key_values = None
         self._encoded = {}                 # frame idx -> (embeds [T,H], ready event)
         self._frames_done = 0
-        self.step_log = []                 # (cache length before, new tokens) of every Llama step executed
+        self.trace = collections.deque(maxlen=self._record or 1)       # ("frame" | "response", ...) events, newest last
+        self.step_log = collections.deque(maxlen=self._record or 1)    # (cache length before, new tokens) of the Llama steps
+        self.steps_total = 0               # Llama steps executed since reset() (step_log keeps the newest `record` of them)
+
+    def _log_step(self, Lc, n):
+        self.steps_total += 1
+        if self._record:
+            self.step_log.append((Lc, n))
+
+    def drop_prefetched(self):
+        """Forget frames encoded ahead and not yet queued (they are simply encoded again when their time comes)."""
+        self._encoded.clear()
 
     def load_video(self, video):                                       # :111-115
         """``video``: uint8 tensor [T,3,R,R] (what read_video(..., output_format='TCHW') yields) or a path
@@ -107,6 +122,9 @@ class LiveInfer:
         if isinstance(video, str):
             from torchvision.io import read_video
             video = read_video(video, pts_unit="sec", output_format="TCHW")[0]
+        R = self.frame_resolution
+        if video.dtype != torch.uint8 or video.dim() != 4 or tuple(video.shape[1:]) != (3, R, R):
+            raise ValueError(f"video must be uint8 [T,3,{R},{R}] (data/utils.py:51-66 resamples to this), got {video.dtype} {tuple(video.shape)}")
         self.video_tensor = video.to(self.model.device)
         self._video_ready = torch.cuda.Event()
         self._video_ready.record(self._main)
@@ -161,10 +179,12 @@ class LiveInfer:
             eos_token_id=self.eos_token_id, inplace_output_ids=self.inplace_output_ids,
             force_len=forced[1] if forced is not None else 0)
         out = output_ids[0].tolist()
-        self.step_log.append((L0, len(self.last_ids)))
-        self.step_log.extend((L0 + len(self.last_ids) + j, 1) for j in range(len(out) - 1))
+        self._log_step(L0, len(self.last_ids))
+        for j in range(len(out) - 1):
+            self._log_step(L0 + len(self.last_ids) + j, 1)
         self.last_ids = out[-1:]
-        self.trace.append(("response", video_time, query, out))
+        if self._record:
+            self.trace.append(("response", video_time, query, out))
         if query:
             query = f"(Video Time = {video_time}s) User: {query}"
         if self.tokenizer is not None:
@@ -188,10 +208,12 @@ class LiveInfer:
                 self.last_ids = self.last_ids + self._added_stream_prompt_ids
             if self.past_key_values is None:
                 self.past_key_values = self.model.new_cache()
-            text_embeds = eng.embed(torch.tensor(self.last_ids, device=self.model.device))
             self._main.wait_event(ready)
-            inputs_embeds = torch.cat([text_embeds, frame_embeds], dim=0)
-            self.step_log.append((len(self.past_key_values), inputs_embeds.shape[0]))
+            if len(self.last_ids) + self.frame_num_tokens > self._stage.shape[0]:
+                self._stage = torch.empty(len(self.last_ids) + self.frame_num_tokens, self.hidden_size, dtype=torch.bfloat16,
+                                          device=self.model.device)
+            inputs_embeds = eng.step_input(self.last_ids, frame_embeds, self._stage)      # :61-68 without torch.tensor / torch.cat
+            self._log_step(len(self.past_key_values), inputs_embeds.shape[0])
             eng.llm_step(self.past_key_values, inputs_embeds, want_last=False)
             self._frames_done += 1
             nxt = self.last_frame_idx + 1
@@ -213,7 +235,8 @@ class LiveInfer:
             if forced is not None:
                 tok = self._added_stream_generation_ids[0] if forced[0] else self.frame_token_interval_id
             self.last_ids = [tok]
-            self.trace.append(("frame", video_time, tok, len(self.past_key_values)))
+            if self._record:
+                self.trace.append(("frame", video_time, tok, len(self.past_key_values)))
             if tok != self.frame_token_interval_id:
                 return video_time, None
         return None, None
