@@ -152,8 +152,8 @@ def test_full_depth_siglip_l_vs_cpu_fp32_reference():
     fp32 path is bounded by the distance of the oracle's own fp16-autocast emulation: err <= 2 x that + 2 bf16 ulps of the
     output scale (the tokens are written as bf16).  The numbers are printed; DESIGN.md section 2 records them."""
     vspec = O.VIT_SPECS["siglip-l16-384"]
-    spec = O.LLM_SPECS["toy128"]
-    w, vw = O.init_llm_weights(spec, seed=3), O.init_vit_weights(vspec, seed=2)
+    spec = O.LLM_SPECS["tinyllama-2l"]            # any LLM whose connector takes the tower's 1024-wide tokens
+    w, vw = O.init_llm_weights(spec, seed=5), O.init_vit_weights(vspec, seed=2)
     frames = O.synthetic_frames(2, vspec.image_size, seed=99)
     gold = O.siglip_vision_encode(vw, vspec, frames)                                  # the CPU reference path, fp32
     amp = O.siglip_vision_encode(vw, vspec, frames, mm_dtype=torch.float16)          # the GPU reference path, emulated

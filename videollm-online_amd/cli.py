@@ -29,9 +29,7 @@ def main(argv=None):
     args = ap.parse_args(argv)
 
     import torch
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, root)
-    import bench as B                                   # shapes, synthetic frames, random weights, token ids
+    from . import synthetic as B                        # shapes, synthetic frames, random weights, token ids
     from .engine import Engine, EngineConfig
     from .inference import LiveInfer
     from .modeling_live import LiveModel

@@ -22,7 +22,6 @@ struct PackedLinear {
     void *Wp = nullptr;
     int N = 0, K = 0, NT = 0;
     GemvPlan plan{};
-    GemvPlan plan_whole{};    // same image, K never split across blocks (epilogues that need final sums); == plan when it has ksplit 1
     Gemm64Plan plan64{};      // the 64-token block path over the same packed image (prefill.hip)
 };
 
@@ -76,15 +75,6 @@ struct vlo_session {
     vlo_engine *e = nullptr;
     int64_t len = 0;
     bool has_logits = false;
-    int fused_rows = 0;                          // chunks of <= this many rows take run_chunk_fused (VLO_FUSED_ROWS at creation; 0 = off)
-    int persistent_blocks = 0;                   // > 0: 16-row chunks run one persistent launch per layer on this many blocks (VLO_PERSISTENT)
-    unsigned *bar = nullptr;                     // persistent layer kernel: the flat barrier counter
-    unsigned *bar_err_host = nullptr;            // pinned, device-visible: sticky time-out word of the grid barriers (read without a sync)
-    unsigned bar_issued = 0;                     // arrivals every block has made so far (host-side count, wraps)
-    int barrier_kind = 0;                        // VLO_PERSISTENT_BARRIER=xcd: XCD-hierarchical grid barrier (zeroed state per launch)
-    unsigned *bar_xcd = nullptr;
-    bool persistent_step = false;                // VLO_PERSISTENT_STEP: all layers of a chunk in ONE launch (device array of LayerArgs)
-    void *layer_args_dev = nullptr;              // [num_layers] LayerArgs
     std::vector<int> pages;
     std::vector<void *> owned;
     unsigned short *h = nullptr, *x = nullptr, *act = nullptr, *attn = nullptr, *q = nullptr, *emb1 = nullptr;

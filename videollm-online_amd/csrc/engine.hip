@@ -19,7 +19,6 @@
 #include "common.cuh"
 #include "engine.h"
 #include "gemv.h"
-#include "layer.h"
 #include "llm_ops.h"
 #include "vit.h"
 
@@ -197,7 +196,6 @@ static int make_linear(vlo_engine *e, PackedLinear *pl, int N, int K, bool allow
     pl->K = K;
     pl->NT = (N + 15) / 16;
     if (gemv_plan(K, allow_ksplit, &pl->plan)) return fail(VLO_E_UNSUPPORTED, "no GEMV plan for K=" + std::to_string(K));
-    if (gemv_plan(K, false, &pl->plan_whole)) return fail(VLO_E_UNSUPPORTED, "no whole-K GEMV plan for K=" + std::to_string(K));
     if (gemm64_plan(K, &pl->plan64)) return fail(VLO_E_UNSUPPORTED, "no block-GEMM plan for K=" + std::to_string(K));
     const size_t bytes = (size_t)pl->NT * 16 * K * 2;
     int rc = dev_alloc(&pl->Wp, bytes);
@@ -410,38 +408,6 @@ int vlo_session_create(vlo_engine *e, int64_t max_tokens_hint, vlo_session **out
         return fail(VLO_E_HIP, "hipHostMalloc failed");
     }
     s->last_logits = s->logits;
-    if (const char *v = getenv("VLO_FUSED_ROWS")) s->fused_rows = std::max(0, std::min(16, atoi(v)));
-    if (const char *v = getenv("VLO_PERSISTENT")) {
-        // opt-in: one persistent launch per decoder layer (layer.hip).  The value is the number of resident blocks; 1 means
-        // "one per CU of this device".  Only for models whose four projections all plan 8 waves and an instantiated shape.
-        int nb = atoi(v);
-        if (nb == 1) {
-            hipDeviceProp_t prop;
-            nb = hipGetDeviceProperties(&prop, e->device) == hipSuccess ? prop.multiProcessorCount : 256;
-        }
-        const LayerWeights &L0 = e->layers[0];
-        const int G = c.num_heads / c.num_kv_heads, hpw = (G % 2 == 0) ? 2 : 1;
-        const bool ok = nb > 0 && e->tp_size == 1 && L0.qkv.plan.NW == 8 && L0.o.plan.NW == 8 && L0.gate_up.plan.NW == 8 && L0.down.plan.NW == 8 &&
-                        L0.qkv.plan.KF == L0.o.plan.KF && L0.qkv.plan.KF == L0.gate_up.plan.KF &&
-                        layer_kernel_supports(L0.qkv.plan.KF, L0.down.plan.KF, hd, hpw);
-        if (ok) {
-            A((void **)&s->bar, 256);
-            A(&s->layer_args_dev, (size_t)c.num_layers * sizeof(LayerArgs));
-            A((void **)&s->bar_xcd, (size_t)layer_xcd_words() * 4);
-            if (const char *bk = getenv("VLO_PERSISTENT_BARRIER")) s->barrier_kind = strcmp(bk, "xcd") == 0 ? 1 : 0;
-            if (rc) {
-                vlo_session_destroy(s);
-                return rc;
-            }
-            if (hipHostMalloc((void **)&s->bar_err_host, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
-                vlo_session_destroy(s);
-                return fail(VLO_E_HIP, "hipHostMalloc failed");
-            }
-            *s->bar_err_host = 0u;
-            s->persistent_blocks = nb;
-            s->persistent_step = getenv("VLO_PERSISTENT_STEP") && atoi(getenv("VLO_PERSISTENT_STEP")) != 0;
-        }
-    }
     HIP_TRY(hipDeviceSynchronize());
     *out = s;
     return VLO_OK;
@@ -471,7 +437,6 @@ void vlo_session_destroy(vlo_session *s) {
     vlo_session_reset(s);
     for (void *p : s->owned) hipFree(p);
     if (s->host_tok) hipHostFree(s->host_tok);
-    if (s->bar_err_host) hipHostFree(s->bar_err_host);
     if (s->host_pt) hipHostFree(s->host_pt);
     delete s;
 }
@@ -598,163 +563,6 @@ GemvArgs gemv_args(const PackedLinear &pl, const unsigned short *x, int ldx, int
     return a;
 }
 
-// Opt-in variant of run_chunk for SHORT chunks (m <= session.fused_rows, VLO_FUSED_ROWS; meant for the n = 1 decode steps),
-// 6 launches per decoder layer and no separate norm kernel at all:
-//   qkv GEMV      [input RMSNorm on the operand load | RoPE + paged KV append]         -> q, K, V^T
-//   attention, combine                                                                 -> attn
-//   o GEMV        [residual add + row sum-of-squares]                                  -> h, sq
-//   gate/up GEMV  [post-attention RMSNorm on the operand load | SwiGLU]                -> act
-//   down GEMV     [WHOLE K per block | residual add + row sum-of-squares]              -> h, sq
-// and the final RMSNorm rides on the lm_head operand load.  Whole-K down-proj re-reads the activation rows once per
-// column tile (m * I * 2 bytes from L2 per block): +10 us per layer at m = 11, which is why run_chunk splits K there and
-// pays an add_rmsnorm launch instead — but nothing at m = 1.  Same rounding points as run_chunk; the fp32 summation
-// order inside the down-proj dot products differs (K chunks walked by one wave vs K slices added by add_rmsnorm).
-static int run_chunk_fused(vlo_session *s, const unsigned short *src, int m, bool want_last, bool want_all, hipStream_t st) {
-    vlo_engine *e = s->e;
-    const vlo_config &c = e->cfg;
-    const int H = c.hidden_size, I = c.intermediate_size, hd = e->head_dim, nh = c.num_heads;
-    int rc;
-    if ((rc = ensure_pages(s, s->len + m, st))) return rc;
-    const KvGeom kv = kv_geom(s);
-    HIP_TRY(prep_rows_launch(src, s->h, s->sq[1], m, H, st));       // h = embeddings, sq[1][0][row] = their sums of squares
-    const float *sq_in = s->sq[1];
-    int sq_parts = 1;
-    for (int l = 0; l < c.num_layers; ++l) {
-        const LayerWeights &L = e->layers[l];
-        {   // qkv, input RMSNorm on load
-            GemvArgs a = gemv_args(L.qkv, s->h, H, m);
-            a.norm_w = (const unsigned short *)L.ln_in; a.sq_in = sq_in; a.sq_in_parts = sq_parts; a.eps = c.rms_eps;
-            a.out_bf16 = s->q; a.cos_tab = (const unsigned short *)e->cos_tab; a.sin_tab = (const unsigned short *)e->sin_tab;
-            a.kv = kv; a.layer = l; a.num_heads = nh; a.pos0 = s->len;
-            HIP_TRY(gemv_launch(a, L.qkv.plan, XSRC_NORM, EPI_ROPE, st));
-        }
-        HIP_TRY(attention_launch(s->q, kv, l, nh, s->len, m, s->part_o, s->part_ml, s->attn, st));
-        {   // o_proj + residual
-            GemvArgs a = gemv_args(L.o, s->attn, nh * hd, m);
-            a.h = s->h; a.ldo = H; a.sq_out = s->sq[0];
-            sq_parts = gemv_grid_x(a, L.o.plan, EPI_RESID);
-            HIP_TRY(gemv_launch(a, L.o.plan, XSRC_PLAIN, EPI_RESID, st));
-            sq_in = s->sq[0];
-        }
-        {   // gate/up + SwiGLU, post-attention RMSNorm on load
-            hipEvent_t ev0 = nullptr, ev1 = nullptr;
-            if (e->prof_stride > 0 && (e->prof_seen++ % e->prof_stride) == 0) prof_acquire(e, &ev0, &ev1);
-            GemvArgs a = gemv_args(L.gate_up, s->h, H, m);
-            a.norm_w = (const unsigned short *)L.ln_post; a.sq_in = sq_in; a.sq_in_parts = sq_parts; a.eps = c.rms_eps;
-            a.out_bf16 = s->act; a.ldo = I;
-            if (ev0) hipEventRecord(ev0, st);
-            HIP_TRY(gemv_launch(a, L.gate_up.plan, XSRC_NORM, EPI_SWIGLU, st));
-            if (ev1) hipEventRecord(ev1, st);
-        }
-        {   // down_proj (whole K) + residual
-            GemvArgs a = gemv_args(L.down, s->act, I, m);
-            a.h = s->h; a.ldo = H; a.sq_out = s->sq[1];
-            sq_parts = gemv_grid_x(a, L.down.plan_whole, EPI_RESID);
-            HIP_TRY(gemv_launch(a, L.down.plan_whole, XSRC_PLAIN, EPI_RESID, st));
-            sq_in = s->sq[1];
-        }
-    }
-    if (want_last || want_all) {
-        // final RMSNorm on the lm_head operand load; only the rows that are read (row r0 of h / of the sq partials = row 0 here)
-        const int r0 = want_all ? 0 : m - 1, nr = want_all ? m : 1;
-        GemvArgs a = gemv_args(e->lm_head, s->h + (size_t)r0 * H, H, nr);
-        a.norm_w = (const unsigned short *)e->norm_w; a.sq_in = sq_in + r0; a.sq_in_parts = sq_parts; a.eps = c.rms_eps;
-        a.out_bf16 = s->logits; a.ldo = c.vocab_size;
-        HIP_TRY(gemv_launch(a, e->lm_head.plan, XSRC_NORM, EPI_BF16, st));
-        s->last_logits = s->logits + (size_t)(nr - 1) * c.vocab_size;
-        s->has_logits = true;
-    }
-    s->len += m;
-    return VLO_OK;
-}
-
-// Opt-in variant of run_chunk (VLO_PERSISTENT): the same seven phases per decoder layer inside ONE persistent launch
-// (layer.hip), resident blocks walking the same virtual grids with the same kernel bodies between grid barriers — the
-// logits are bit-identical to run_chunk's.  Stage P0 of DESIGN.md §7 item 1 (structure only, no cross-phase prefetch yet).
-static int run_chunk_persistent(vlo_session *s, const unsigned short *src, int m, bool want_last, bool want_all, hipStream_t st) {
-    vlo_engine *e = s->e;
-    const vlo_config &c = e->cfg;
-    const int H = c.hidden_size, I = c.intermediate_size, hd = e->head_dim, nh = c.num_heads;
-    int rc;
-    if (*(volatile unsigned *)s->bar_err_host)
-        return fail(VLO_E_HIP, "persistent layer kernel: a grid barrier timed out (are all blocks resident?); results since then are invalid");
-    if ((rc = ensure_pages(s, s->len + m, st))) return rc;
-    const KvGeom kv = kv_geom(s);
-    HIP_TRY(copy_rows_launch(src, s->h, m, H, st));
-    AttnGeom ag;
-    HIP_TRY(attention_geometry(kv, nh, s->len, m, &ag));
-    const float *prev = nullptr;
-    int prev_ks = 0;
-    std::vector<LayerArgs> all;                       // whole-step launch: the per-layer arguments, copied to the device once
-    if (s->persistent_step) all.reserve(c.num_layers);
-    size_t lds_step = 0;
-    for (int l = 0; l < c.num_layers; ++l) {
-        const LayerWeights &W = e->layers[l];
-        LayerArgs L{};
-        size_t lds = ag.lds_bytes, lb = 0;
-        int gy = 0;
-        L.qkv = gemv_args(W.qkv, s->x, H, m);
-        L.qkv.out_bf16 = s->q; L.qkv.cos_tab = (const unsigned short *)e->cos_tab; L.qkv.sin_tab = (const unsigned short *)e->sin_tab;
-        L.qkv.kv = kv; L.qkv.layer = l; L.qkv.num_heads = nh; L.qkv.pos0 = s->len;
-        HIP_TRY(gemv_prepare(&L.qkv, W.qkv.plan, EPI_ROPE, &L.qkv_gx, &gy, &lb));
-        lds = std::max(lds, lb);
-        L.o = gemv_args(W.o, s->attn, nh * hd, m);
-        L.o.h = s->h; L.o.ldo = H; L.o.sq_out = s->sq[0];
-        HIP_TRY(gemv_prepare(&L.o, W.o.plan, EPI_RESID, &L.o_gx, &gy, &lb));
-        lds = std::max(lds, lb);
-        L.gu = gemv_args(W.gate_up, s->h, H, m);
-        L.gu.norm_w = (const unsigned short *)W.ln_post; L.gu.sq_in = s->sq[0]; L.gu.sq_in_parts = L.o_gx; L.gu.eps = c.rms_eps;
-        L.gu.out_bf16 = s->act; L.gu.ldo = I;
-        HIP_TRY(gemv_prepare(&L.gu, W.gate_up.plan, EPI_SWIGLU, &L.gu_gx, &gy, &lb));
-        lds = std::max(lds, lb);
-        L.down = gemv_args(W.down, s->act, I, m);
-        L.down.out_f32 = s->partial; L.down.ldo = H;
-        HIP_TRY(gemv_prepare(&L.down, W.down.plan, EPI_PARTIAL_F32, &L.down_gx, &L.down_gy, &lb));
-        lds = std::max(lds, lb);
-        L.h = s->h; L.prev = prev; L.prev_ks = prev_ks; L.ln_in = (const unsigned short *)W.ln_in; L.x = s->x; L.H = H; L.m = m; L.eps = c.rms_eps;
-        L.q = s->q; L.kv = kv; L.layer = l; L.nh = nh; L.G = ag.G; L.KS = ag.KS; L.chunk = ag.chunk; L.nsplit = ag.nsplit;
-        L.attn_threads = ag.nhg * ag.KS * 64; L.pos0 = s->len; L.scale = ag.scale;
-        L.part_o = s->part_o; L.part_ml = s->part_ml; L.attn_out = s->attn;
-        L.bar_counter = s->bar; L.bar_err = s->bar_err_host; L.bar_base = s->bar_issued;
-        L.bar_timeout_ticks = 200000000;              // 2 s of the 100 MHz counter
-        {
-            static const int pf = getenv("VLO_PERSISTENT_PREFETCH") ? atoi(getenv("VLO_PERSISTENT_PREFETCH")) : 1;
-            L.prefetch = pf;
-        }
-        L.barrier_kind = s->barrier_kind; L.bar_xcd = s->bar_xcd;
-        if (s->persistent_step) {
-            all.push_back(L);                         // bar_base of layers > 0 is not read: the kernel keeps counting
-            lds_step = std::max(lds_step, lds);
-        } else {
-            if (s->barrier_kind == 1) HIP_TRY(hipMemsetAsync(s->bar_xcd, 0, (size_t)layer_xcd_words() * 4, st));
-            HIP_TRY(layer_launch(L, W.qkv.plan.KF, W.down.plan.KF, hd, ag.hpw, s->persistent_blocks, lds, st));
-            s->bar_issued += (unsigned)layer_barriers_per_launch(s->barrier_kind) * (unsigned)s->persistent_blocks;
-        }
-        prev = s->partial;
-        prev_ks = W.down.plan.ksplit;
-    }
-    if (s->persistent_step) {
-        // pageable source: the copy has left `all` when hipMemcpyAsync returns; stream-ordered before the launch
-        HIP_TRY(hipMemcpyAsync(s->layer_args_dev, all.data(), all.size() * sizeof(LayerArgs), hipMemcpyHostToDevice, st));
-        const LayerWeights &W0 = e->layers[0];
-        if (s->barrier_kind == 1) HIP_TRY(hipMemsetAsync(s->bar_xcd, 0, (size_t)layer_xcd_words() * 4, st));
-        HIP_TRY(step_launch((const LayerArgs *)s->layer_args_dev, c.num_layers, W0.qkv.plan.KF, W0.down.plan.KF, hd, ag.hpw,
-                            s->persistent_blocks, lds_step, st));
-        s->bar_issued += (unsigned)step_barriers_per_launch(c.num_layers, s->barrier_kind) * (unsigned)s->persistent_blocks;
-    }
-    if (want_last || want_all) {
-        HIP_TRY(add_rmsnorm_launch(s->h, prev, prev_ks, H, (const unsigned short *)e->norm_w, s->x, H, H, c.rms_eps, m, st));
-        const int r0 = want_all ? 0 : m - 1, nr = want_all ? m : 1;
-        GemvArgs a = gemv_args(e->lm_head, s->x + (size_t)r0 * H, H, nr);
-        a.out_bf16 = s->logits; a.ldo = c.vocab_size;
-        HIP_TRY(gemv_launch(a, e->lm_head.plan, XSRC_PLAIN, EPI_BF16, st));
-        s->last_logits = s->logits + (size_t)(nr - 1) * c.vocab_size;
-        s->has_logits = true;
-    }
-    s->len += m;
-    return VLO_OK;
-}
-
 // one chunk of m <= 16 new tokens whose embeddings are at `src`.  Per decoder layer (7 launches):
 //   add_rmsnorm   [+ down-proj split-K combine + residual of the previous layer]      -> x
 //   qkv GEMV      [RoPE + paged KV append in the epilogue]                             -> q, K, V^T
@@ -764,8 +572,6 @@ static int run_chunk_persistent(vlo_session *s, const unsigned short *src, int m
 //   down GEMV     [K split over blocks, fp32 partials]                                 -> partial
 static int run_chunk(vlo_session *s, const unsigned short *src, int m, bool want_last, bool want_all, hipStream_t st) {
     static const bool fuse_norm = getenv("VLO_FUSE_NORM") ? atoi(getenv("VLO_FUSE_NORM")) != 0 : true;
-    if (m <= s->fused_rows) return run_chunk_fused(s, src, m, want_last, want_all, st);
-    if (s->persistent_blocks > 0) return run_chunk_persistent(s, src, m, want_last, want_all, st);
     vlo_engine *e = s->e;
     const vlo_config &c = e->cfg;
     const int H = c.hidden_size, I = c.intermediate_size, hd = e->head_dim, nh = c.num_heads;
