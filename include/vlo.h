@@ -112,6 +112,17 @@ int vlo_visual_embed(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_
  *      frames_dev: uint8 [B,3,R,R];  out_dev: bf16 [B, frame_num_tokens, vision_hidden_size] (CLS + pooled, PRE-connector;
  *      the reference stores them with `.to(torch.bfloat16)`, data/utils.py:101) */
 int vlo_vision_tokens(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_dev, void *stream);
+/* ---- frame preparation in front of `load_video`: what the reference does with an external ffmpeg
+ *      (data/utils.py:51-66 `ffmpeg_once`: scale the longer side to R keeping the aspect ratio — the other side a multiple of
+ *      2 —, -sws_flags bicubic, pad to R x R with black; demo/cli.py:13-22) followed by read_video(..., 'TCHW')
+ *      (demo/inference.py:112).  src_dev: decoded uint8 RGB frames, layout 0 = [T,H,W,3] (decoder output), 1 = [T,3,H,W];
+ *      resolution: R, or 0 for the vision tower's image size; cubic_a: Keys parameter of the antialiased bicubic (-0.6 =
+ *      libswscale's default B=0,C=0.6; -0.5 = PIL / torch antialias); out_dev: uint8 [T,3,R,R]. */
+int vlo_frame_ingest(vlo_engine *e, const uint8_t *src_dev, int T, int H, int W, int layout, int resolution, float cubic_a,
+                     uint8_t *out_dev, void *stream);
+/* host-only: scaled size (ow, oh) and pad offset (x0, y0) of the call above for W x H frames (any pointer may be NULL) */
+int vlo_frame_ingest_geometry(int W, int H, int R, int *ow, int *oh, int *x0, int *y0);
+
 /* connector only (frames already encoded: the `hasattr(self,'vision_encode')` false branch,
  * models/modeling_live.py:22-26).  feats_dev: bf16 [rows, vision_hidden_size] */
 int vlo_connector(vlo_engine *e, const void *feats_dev, int rows, void *out_dev, void *stream);

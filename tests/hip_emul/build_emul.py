@@ -1,4 +1,4 @@
-"""Builds tests/hip_emul/_build/libvlo_emul.so: the engine's SOURCES (csrc/{gemv,prefill,llm_ops,vit,engine,tp}.hip)
+"""Builds tests/hip_emul/_build/libvlo_emul.so: the engine's SOURCES (csrc/{gemv,prefill,llm_ops,vit,ingest,engine,tp}.hip)
 compiled as host C++ against the HIP-on-threads shim (hip_emul.h); csrc/vit.hip as well.  Test infrastructure only — the product is libvlo.so."""
 import os
 import re
@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "videollm-online_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
-SOURCES = ["gemv.hip", "prefill.hip", "llm_ops.hip", "vit.hip", "engine.hip", "tp.hip"]
+SOURCES = ["gemv.hip", "prefill.hip", "llm_ops.hip", "vit.hip", "ingest.hip", "engine.hip", "tp.hip"]
 
 
 def clang():

@@ -127,6 +127,15 @@ class EmulEngine:
         check(lib().vlo_visual_embed(self._h, _ptr(f), f.shape[0], _ptr(out), stream))
         return out
 
+    def frame_ingest(self, frames_u8, layout, resolution, cubic_a=-0.6):
+        """decoded uint8 frames [T,H,W,3] (layout 0) or [T,3,H,W] (layout 1) -> uint8 [T,3,R,R] (include/vlo.h vlo_frame_ingest)"""
+        f = frames_u8.contiguous()
+        T = f.shape[0]
+        H, W = (f.shape[1], f.shape[2]) if layout == 0 else (f.shape[2], f.shape[3])
+        out = torch.zeros(T, 3, resolution, resolution, dtype=torch.uint8)
+        check(lib().vlo_frame_ingest(self._h, _ptr(f), T, H, W, layout, resolution, cubic_a, _ptr(out), None))
+        return out
+
     def vision_tokens(self, frames_u8):
         f = frames_u8.contiguous()
         out = torch.zeros(f.shape[0], self.vit.frame_num_tokens, self.vit.hidden_size, dtype=torch.bfloat16)

@@ -1,0 +1,105 @@
+"""GPU parity of vlo_frame_ingest (csrc/ingest.hip) — the device-side restatement of the reference's ffmpeg preparation
+(data/utils.py:51-66) — against oracle/ingest_oracle.py, against torch's antialiased bicubic, and of the FrameRing feed of
+LiveInfer against the reference's "whole video resident" load_video.
+
+Tolerance: byte output; the kernel accumulates in fp32 with fp32 tap weights, the oracle in float64, so a pixel whose exact
+value sits on a rounding boundary may differ by ONE level: max |diff| <= 1 and >= 99.5 % of the pixels identical."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ingest_oracle as G
+from oracle import vlo_oracle as O
+from test_gpu_liveinfer import _build
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine():
+    from videollm_online_amd.engine import Engine, EngineConfig
+    spec = O.LLM_SPECS["toy128"]
+    cfg = EngineConfig(hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size, num_hidden_layers=spec.num_layers,
+                       num_attention_heads=spec.num_heads, num_key_value_heads=spec.num_kv_heads, vocab_size=spec.vocab_size,
+                       vision_hidden_size=spec.vision_hidden_size, kv_pool_tokens=512)
+    e = Engine(cfg)
+    e.load_weights(O.init_llm_weights(spec, seed=3))
+    return e.finalize()
+
+
+def _frames(T, H, W, seed):
+    rng = np.random.default_rng(seed)
+    fr = rng.integers(0, 256, (T, H, W, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    fr[0] = np.stack([(xx * 255 // max(W - 1, 1)), (yy * 255 // max(H - 1, 1)), ((xx + yy) % 256)], -1).astype(np.uint8)   # smooth content
+    return fr
+
+
+@pytest.mark.parametrize("H,W,R,layout", [(1080, 1920, 384, "THWC"), (1920, 1080, 384, "TCHW"), (360, 640, 384, "THWC"),
+                                          (375, 500, 384, "TCHW"), (384, 384, 384, "THWC"), (240, 320, 384, "TCHW"), (97, 131, 96, "THWC")])
+def test_frame_ingest_matches_oracle(H, W, R, layout):
+    eng = _engine()
+    fr = _frames(2, H, W, H + W)
+    want = G.ingest(fr, R, -0.6)
+    src = torch.from_numpy(fr if layout == "THWC" else np.ascontiguousarray(fr.transpose(0, 3, 1, 2))).cuda()
+    got = eng.frame_ingest(src, layout, R).cpu().numpy()
+    d = np.abs(got.astype(int) - want.astype(int))
+    print(f"[ingest {W}x{H} -> {R} {layout}] max |diff| {d.max()}, identical {100 * (d == 0).mean():.3f} %")
+    assert d.max() <= 1 and (d == 0).mean() >= 0.995
+    if H == W == R:
+        assert np.array_equal(got, fr.transpose(0, 3, 1, 2))
+    eng.close()
+
+
+def test_frame_ingest_matches_torch_antialiased_bicubic():
+    """a = -0.5 is the kernel torch's F.interpolate(mode='bicubic', antialias=True) uses: same pixels up to one level."""
+    eng = _engine()
+    H, W, R = 720, 1280, 384
+    fr = torch.from_numpy(_frames(2, H, W, 5)).cuda()
+    got = eng.frame_ingest(fr, "THWC", R, cubic_a=-0.5)
+    ow, oh, x0, y0 = G.ffmpeg_scale_pad_geometry(W, H, R)
+    ref = torch.nn.functional.interpolate(fr.permute(0, 3, 1, 2).float(), size=(oh, ow), mode="bicubic", antialias=True, align_corners=False)
+    ref = ref.add(0.5).floor().clamp(0, 255).to(torch.uint8)
+    assert not got[:, :, :y0].any() and not got[:, :, y0 + oh:].any()            # black bars
+    d = (got[:, :, y0:y0 + oh, x0:x0 + ow].int() - ref.int()).abs()
+    assert int(d.max()) <= 1 and float((d == 0).float().mean()) >= 0.99, (int(d.max()), float((d == 0).float().mean()))
+    eng.close()
+
+
+def test_frame_ring_feeds_liveinfer_like_a_resident_video():
+    """12 decoded 90x160 frames pushed 3 at a time through an 8-frame ring (it wraps, and never holds the whole video) give the
+    same stream events as load_video on the prepared [T,3,R,R] tensor; so does load_video on the raw decoded frames."""
+    from videollm_online_amd.ingest import FrameRing
+    spec, vspec = O.LLM_SPECS["toy128"], O.VIT_SPECS["toy"]
+    w, vw = O.init_llm_weights(spec, seed=3), O.init_vit_weights(vspec, seed=1)
+    toks = O.default_tokens(spec, seed=7, n_start=19)
+    raw = torch.from_numpy(_frames(12, 90, 160, 3))
+    prepared = torch.from_numpy(G.ingest(raw.numpy(), vspec.image_size, -0.6))
+    eng, li = _build(spec, vspec, w, vw, toks, prefetch=True, prefetch_frames=2, max_new_tokens=4)
+    q = "Please narrate the video in real time."
+
+    def drive(load):
+        li.reset()
+        feed = load()
+        li.input_query_stream(q, video_time=0.0)
+        for i in range(12):
+            if feed is not None and i % 3 == 0:
+                feed.push(raw[i:i + 3])
+            li.input_video_stream(i / 2)
+            li()
+        return list(li.trace)
+
+    dev_prepared = eng.frame_ingest(raw.cuda(), "THWC")
+    d = (dev_prepared.cpu().int() - prepared.int()).abs()
+    assert int(d.max()) <= 1
+    a = drive(lambda: li.load_video(dev_prepared))
+    b = drive(lambda: li.load_video(raw.cuda()))                      # decoded frames: prepared on the device by load_video
+    ring = FrameRing(eng, 90, 160, capacity=8, chunk=3)
+
+    def with_ring():
+        li.load_video(ring)
+        return ring
+    c = drive(with_ring)
+    assert a == b == c and len(a) >= 12
+    assert ring.head == 12 and ring.tail >= 10 and ring.frames.shape[0] == 8
+    li.reset()
+    eng.close()

@@ -37,7 +37,7 @@ EXPORTS = [
     "vlo_tp_unique_id", "vlo_tp_group_create", "vlo_tp_group_destroy", "vlo_tp_session_create", "vlo_tp_session_reset",
     "vlo_tp_session_len", "vlo_tp_session_destroy", "vlo_tp_llm_step", "vlo_tp_stream_sample", "vlo_tp_greedy_generate",
     "vlo_joint_embed", "vlo_logit_rows", "vlo_session_fork", "vlo_session_crop", "vlo_tp_selftest", "vlo_debug_gemm64_plan", "vlo_debug_pack64_elem",
-    "vlo_step_input", "vlo_build_id",
+    "vlo_step_input", "vlo_build_id", "vlo_frame_ingest", "vlo_frame_ingest_geometry",
     "vlo_tp_p2p_export", "vlo_tp_p2p_enable", "vlo_tp_p2p_status", "vlo_debug_p2p_layout", "vlo_tp_bench_exchange",
 ]
 
@@ -92,6 +92,8 @@ def bind(L):
     L.vlo_embed.argtypes = [vp, vp, i32, vp, vp]
     L.vlo_step_input.argtypes = [vp, C.POINTER(i64), i32, vp, i32, vp, vp]
     L.vlo_build_id.restype = C.c_char_p
+    L.vlo_frame_ingest.argtypes = [vp, vp, i32, i32, i32, i32, i32, C.c_float, vp, vp]
+    L.vlo_frame_ingest_geometry.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.vlo_llm_step.argtypes = [vp, vp, i32, vp, vp, vp]
     L.vlo_stream_sample.argtypes = [vp, C.c_float, i32, vp, vp, vp]
     L.vlo_greedy_generate.argtypes = [vp, vp, i32, i32, vp, i32, i32, C.POINTER(i32), vp]

@@ -61,6 +61,7 @@ struct vlo_engine {
     std::mutex pool_mu;
 
     VitState *vit = nullptr;
+    void *ingest = nullptr;                      // ingest.hip: cached tap tables + scratch of vlo_frame_ingest
 
     // live timing of the dominant kernel (vlo_profile_*)
     int prof_stride = 0;
@@ -97,4 +98,5 @@ struct KvGeom;
 int ensure_pages(vlo_session *s, int64_t new_len, hipStream_t st);
 GemvArgs gemv_args(const PackedLinear &pl, const unsigned short *x, int ldx, int n_rows);
 KvGeom kv_geom(const vlo_session *s);
+void ingest_destroy(vlo_engine *e);
 int vlo_fail(int code, const std::string &msg);   // sets the thread-local error string, returns code

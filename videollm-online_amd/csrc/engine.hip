@@ -121,6 +121,7 @@ void vlo_engine_destroy(vlo_engine *e) {
     for (void *p : e->owned) hipFree(p);
     for (auto &pr : e->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     vit_destroy(e);
+    ingest_destroy(e);
     delete e;
 }
 

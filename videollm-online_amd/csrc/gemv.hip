@@ -165,8 +165,6 @@ static hipError_t launch_variant(const GemvArgs &a, int xsrc, int epi, dim3 grid
     } while (0)
     if (xsrc == XSRC_NORM) {
         if (epi == EPI_SWIGLU) VLO_GO(XSRC_NORM, EPI_SWIGLU);
-        if (epi == EPI_ROPE) VLO_GO(XSRC_NORM, EPI_ROPE);      // run_chunk_fused: input RMSNorm on the qkv operand load
-        if (epi == EPI_BF16) VLO_GO(XSRC_NORM, EPI_BF16);      // run_chunk_fused: final RMSNorm on the lm_head operand load
     } else {
         if (epi == EPI_ROPE) VLO_GO(XSRC_PLAIN, EPI_ROPE);
         if (epi == EPI_SWIGLU) VLO_GO(XSRC_PLAIN, EPI_SWIGLU);

@@ -32,7 +32,6 @@ hipError_t add_rmsnorm_launch(unsigned short *h, const float *partial, int kspli
                               hipStream_t st);
 
 // copy `rows` embedding rows into the residual stream h and write their sums of squares to sq_out[0..rows)
-hipError_t prep_rows_launch(const unsigned short *src, unsigned short *h, float *sq_out, int rows, int H, hipStream_t st);
 
 // chunk attention (n <= 16 queries at positions pos0..pos0+n-1 against keys [0, pos0+n); the block path passes n <= 64
 // = up to four 16-query sub-chunks in one launch)

@@ -1,6 +1,5 @@
 // llm_ops.hip — the non-GEMV kernels of one Llama streaming step on gfx950.
 //
-//   prep_rows_kernel        stage the step's input embeddings + their row sums of squares
 //                           (RMSNorm, residual adds, RoPE and the KV append are fused into gemv.hip)
 //   attn_chunk_kernel       n<=16 queries x growing KV, GQA, bottom-right causal mask fused,
 //                           split-KV with online softmax (replaces mask build + repeat_kv + SDPA,
@@ -34,31 +33,6 @@ hipError_t add_rmsnorm_launch(unsigned short *h, const float *partial, int kspli
                               unsigned short *x, int H, int ldx, float eps, int n, hipStream_t st) {
     if (H > 8 * RMS_THREADS * RMS_MAXCH || (H & 7)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(add_rmsnorm_kernel, dim3(n), dim3(RMS_THREADS), 0, st, h, partial, ksplit, partial_ld, w, x, H, ldx, eps);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------
-// step input: copy the n new embedding rows into the residual stream and emit each row's sum of
-// squares (consumed by the first layer's norm-on-load GEMV).  One block per row.
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void prep_rows_kernel(const bf16_t *__restrict__ src, bf16_t *__restrict__ h,
-                                                        float *__restrict__ sq_out, int H) {
-    __shared__ float sm[16];
-    const int m = blockIdx.x;
-    float ss = 0.f;
-    for (int ch = threadIdx.x; ch < (H >> 3); ch += blockDim.x) {
-        const uint4 raw = *reinterpret_cast<const uint4 *>(src + (size_t)m * H + ch * 8);
-        *reinterpret_cast<uint4 *>(h + (size_t)m * H + ch * 8) = raw;
-        const bf16_t *e = reinterpret_cast<const bf16_t *>(&raw);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ss += bf2f(e[j]) * bf2f(e[j]);
-    }
-    ss = block_sum(ss, sm);
-    if (threadIdx.x == 0) sq_out[m] = ss;          // sq_out[0][m]: a single partial
-}
-hipError_t prep_rows_launch(const unsigned short *src, unsigned short *h, float *sq_out, int rows, int H, hipStream_t st) {
-    if (H & 7) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(prep_rows_kernel, dim3(rows), dim3(256), 0, st, src, h, sq_out, H);
     return hipGetLastError();
 }
 

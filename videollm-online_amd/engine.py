@@ -224,6 +224,32 @@ class Engine:
         _C.check(_C.lib().vlo_visual_embed(self._h, _ptr(frames_u8), B, _ptr(out), _stream_handle(stream)))
         return out
 
+    def frame_ingest(self, frames: torch.Tensor, layout: str | None = None, resolution: int = 0, cubic_a: float = -0.6,
+                     out: torch.Tensor | None = None, stream=None) -> torch.Tensor:
+        """Decoded uint8 RGB frames of any size -> uint8 [T,3,R,R] as the reference's ffmpeg preparation + read_video yield them
+        (data/utils.py:51-66, demo/inference.py:112; include/vlo.h vlo_frame_ingest).  ``layout``: "THWC" (decoder output) or
+        "TCHW"; default = by the position of the size-3 axis."""
+        if frames.dtype != torch.uint8 or frames.dim() != 4 or not frames.is_cuda:
+            raise ValueError("frames must be a uint8 [T,H,W,3] or [T,3,H,W] tensor on the engine's device")
+        if layout is None:
+            layout = "THWC" if frames.shape[-1] == 3 and frames.shape[1] != 3 else "TCHW"
+        if layout == "THWC":
+            T, H, W, c = frames.shape
+        else:
+            T, c, H, W = frames.shape
+        if c != 3:
+            raise ValueError(f"expected 3 colour channels, got {tuple(frames.shape)} as {layout}")
+        R = resolution or (self.cfg.vit or {}).get("image_size", 0)
+        if R <= 0:
+            raise ValueError("resolution must be given for an engine without a vision tower")
+        frames = frames.contiguous()
+        if out is None:
+            out = torch.empty(T, 3, R, R, dtype=torch.uint8, device=self.device)
+        assert out.dtype == torch.uint8 and out.is_contiguous() and tuple(out.shape) == (T, 3, R, R)
+        _C.check(_C.lib().vlo_frame_ingest(self._h, _ptr(frames), T, H, W, 0 if layout == "THWC" else 1, R, cubic_a, _ptr(out),
+                                           _stream_handle(stream)))
+        return out
+
     def vision_tokens(self, frames_u8: torch.Tensor, stream=None) -> torch.Tensor:
         """CLS + pooled tokens before the connector: bf16 [B, frame_num_tokens, vision_hidden_size]."""
         self._check_frames(frames_u8)
@@ -455,6 +481,9 @@ class TpGroup:
 
     def vision_tokens(self, frames_u8, stream=None):
         return self.engines[0].vision_tokens(frames_u8, stream)
+
+    def frame_ingest(self, frames, layout=None, resolution=0, cubic_a=-0.6, out=None, stream=None):
+        return self.engines[0].frame_ingest(frames, layout, resolution, cubic_a, out, stream)
 
     def visual_embed(self, frames_u8, stream=None, out=None):
         return self.engines[0].visual_embed(frames_u8, stream, out)

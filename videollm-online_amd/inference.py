@@ -97,6 +97,7 @@ class LiveInfer:
         self.video_time = 0
         self.last_frame_idx = -1
         self.video_tensor = None
+        self._ring = None
         self.last_ids = []
         if self.past_key_values is not None:
             self.past_key_values.close()
@@ -117,19 +118,34 @@ class LiveInfer:
         self._encoded.clear()
 
     def load_video(self, video):                                       # :111-115
-        """``video``: uint8 tensor [T,3,R,R] (what read_video(..., output_format='TCHW') yields) or a path
-        (needs torchvision, exactly like the reference)."""
+        """``video``: uint8 tensor [T,3,R,R] (what read_video(..., output_format='TCHW') yields for the ffmpeg-prepared file),
+        decoded frames of ANY size as uint8 [T,H,W,3] / [T,3,H,W] (prepared on the device by vlo_frame_ingest exactly as
+        data/utils.py:51-66 prepares the file: longer side to R, bicubic, black padding), a ``FrameRing`` that is being
+        filled while the stream runs (the video never has to be resident as a whole), or a path (needs torchvision, exactly
+        like the reference)."""
+        from .ingest import FrameRing
+        self._ring = None
+        if isinstance(video, FrameRing):
+            self._ring, self.video_tensor = video, None
+            self._video_ready = None
+            return
         if isinstance(video, str):
             from torchvision.io import read_video
             video = read_video(video, pts_unit="sec", output_format="TCHW")[0]
         R = self.frame_resolution
-        if video.dtype != torch.uint8 or video.dim() != 4 or tuple(video.shape[1:]) != (3, R, R):
-            raise ValueError(f"video must be uint8 [T,3,{R},{R}] (data/utils.py:51-66 resamples to this), got {video.dtype} {tuple(video.shape)}")
-        self.video_tensor = video.to(self.model.device)
+        if video.dtype != torch.uint8 or video.dim() != 4 or 3 not in (video.shape[1], video.shape[3]):
+            raise ValueError(f"video must be uint8 [T,3,H,W] or [T,H,W,3], got {video.dtype} {tuple(video.shape)}")
+        video = video.to(self.model.device)
+        if tuple(video.shape[1:]) != (3, R, R):
+            video = self.engine.frame_ingest(video, resolution=R)     # the ffmpeg_once preparation, on the device
+        self.video_tensor = video
         self._video_ready = torch.cuda.Event()
         self._video_ready.record(self._main)
-        self.num_video_frames = self.video_tensor.size(0)
         self.video_duration = self.video_tensor.size(0) / self.frame_fps
+
+    @property
+    def num_video_frames(self):
+        return len(self._ring) if self._ring is not None else (0 if self.video_tensor is None else self.video_tensor.size(0))
 
     def input_query_stream(self, query, history=None, video_time=None):   # :93-100
         self.query_queue.append((self.video_time if video_time is None else video_time, query))
@@ -143,12 +159,19 @@ class LiveInfer:
         if not todo:
             return
         lo2, hi2 = todo[0], todo[-1] + 1
-        self._enc.wait_event(self._video_ready)      # the video upload; NOT the main stream's Llama work
+        if self._ring is not None:
+            frames, ready = self._ring.window(lo2, hi2)
+            frames.record_stream(self._enc)
+        else:
+            frames, ready = self.video_tensor[lo2:hi2], self._video_ready
+        self._enc.wait_event(ready)                  # the video upload / ingest; NOT the main stream's Llama work
         with torch.cuda.stream(self._enc):
-            emb = self.model.engine.visual_embed(self.video_tensor[lo2:hi2], stream=self._enc)
+            emb = self.model.engine.visual_embed(frames, stream=self._enc)
             emb.record_stream(self._main)
             ev = torch.cuda.Event()
             ev.record(self._enc)
+        if self._ring is not None:
+            self._ring.release(hi2, after=ev)        # the ring may overwrite these frames once this encode has read them
         for j, i in enumerate(range(lo2, hi2)):
             self._encoded[i] = (emb[j * self.frame_num_tokens:(j + 1) * self.frame_num_tokens], ev)
 
@@ -158,6 +181,9 @@ class LiveInfer:
             ranger = range(self.last_frame_idx + 1, frame_idx + 1)
             self._encode_async(ranger.start, ranger.stop)
             for r in ranger:
+                if r not in self._encoded:
+                    raise RuntimeError(f"frame {r} is not available: the video has {self.num_video_frames} frames"
+                                       + (" so far (push it into the FrameRing first)" if self._ring is not None else ""))
                 self.frame_embeds_queue.append((r / self.frame_fps, self._encoded.pop(r)))
         self.last_frame_idx = frame_idx
         self.video_time = video_time
