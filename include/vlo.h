@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VLO_ABI_VERSION 1
+#define VLO_ABI_VERSION 2
 
 enum {
     VLO_OK = 0,
@@ -44,7 +44,7 @@ enum {
     VLO_E_UNSUPPORTED = -6  /* shape the kernels do not cover */
 };
 
-enum { VLO_DT_F32 = 0, VLO_DT_BF16 = 1, VLO_DT_F16 = 2 };
+enum { VLO_DT_F32 = 0, VLO_DT_BF16 = 1, VLO_DT_F16 = 2, VLO_DT_FP8_E4M3 = 3 /* OCP e4m3fn, one byte per element */ };
 
 typedef struct vlo_engine vlo_engine;
 typedef struct vlo_session vlo_session;
@@ -80,6 +80,10 @@ typedef struct vlo_config {
     int64_t kv_pool_tokens;
     /* tensor parallel: this engine holds rank tp_rank's shard of a tp_size-way group (0/1 = none); see vlo_tp_* */
     int32_t tp_rank, tp_size;
+    /* storage of the streamed Llama projections (q/k/v/o, gate/up/down, lm_head): 0 = bf16; 1 = fp8 e4m3 with one fp32 scale
+     * per output channel (BASELINE.json configs[4] "fp8 MFMA weights").  With 1, vlo_engine_load_weight takes those matrices as
+     * VLO_DT_FP8_E4M3 [N][K] plus "<name>_scale" f32 [N] (W ~= q * scale[n]); activations, KV and accumulation are unchanged. */
+    int32_t weight_dtype;
 } vlo_config;
 
 /* ---- engine lifetime: replaces build_model_and_tokenizer(...)[0] + model.to('cuda')
@@ -171,6 +175,8 @@ double vlo_step_algorithmic_bytes(const vlo_engine *e, int64_t Lc, int n);
 /* raw skinny-GEMM entry used by unit tests: y[n,N] (f32) = x[n,K](bf16) @ W[N,K]^T (bf16), n<=16.
  * W_dev is an ordinary row-major device tensor; packs on every call (tests only). */
 int vlo_test_gemv(const void *x_dev, const void *W_dev, float *y_dev, int n, int N, int K, void *stream);
+/* the same through the fp8 e4m3 weight image: Wq_dev fp8 [N][K], scale_dev f32 [N]; y = (x @ Wq^T) * scale */
+int vlo_test_gemv_fp8(const void *x_dev, const void *Wq_dev, const float *scale_dev, float *y_dev, int n, int N, int K, void *stream);
 
 /* ---- teacher-forced evaluation: the arithmetic of LiveMixin.joint_embed / stream_evaluate /
  *      trim_past_key_values (models/modeling_live.py:29-42, 44-168, 170-171).  The per-turn bookkeeping over these

@@ -101,6 +101,8 @@ LLM_SPECS = {
     "tinyllama-1.1b": LlmSpec(2048, 5632, 22, 32, 4, 32000, 10000.0, 1e-5),
     # reduced-depth true-width variants and toy shapes for per-commit tests
     "llama-3-8b-2l": LlmSpec(4096, 14336, 2, 32, 8, 128256, 500000.0, 1e-5),
+    # one decoder layer at the Llama-3-70B width (BASELINE.json configs[4]); reduced vocabulary keeps the CPU oracle small
+    "llama-3-70b-1l": LlmSpec(8192, 28672, 1, 64, 8, 8192, 500000.0, 1e-5),
     "tinyllama-2l": LlmSpec(2048, 5632, 2, 32, 4, 32000, 10000.0, 1e-5),
     "toy": LlmSpec(256, 704, 2, 4, 2, 1024, 10000.0, 1e-5, vision_hidden_size=128),
     "toy128": LlmSpec(512, 1408, 3, 4, 2, 2048, 500000.0, 1e-5, vision_hidden_size=128),
@@ -357,14 +359,45 @@ class KVCacheOracle:
         return self.k[i], self.v[i]
 
 
+FP8_STREAMED = ("q_proj.weight", "k_proj.weight", "v_proj.weight", "o_proj.weight", "gate_proj.weight", "up_proj.weight",
+                "down_proj.weight", "lm_head.weight")
+
+
+def fp8_dequantized_weights(weights: dict) -> dict:
+    """BASELINE.json configs[4] ("fp8 MFMA weights"): the streamed Llama projections replaced by what an fp8 e4m3 store with one
+    scale per output channel holds — W' = fp8_rne(W / s) * s, s[n] = max|W[n]| / 448 — as fp32 tensors; everything else
+    untouched.  The reference has no fp8 path (config 5 exceeds the reference); the parity target of the fp8
+    engine is the reference arithmetic run on these weights: LlamaOracle keeps fp32 weights in fp32 and rounds the Linear's
+    OUTPUT to the activation dtype, like a bf16 Linear does."""
+    out = {}
+    for k, v in weights.items():
+        if k.endswith(FP8_STREAMED) and not k.startswith(("vision.", "connector.")):
+            Wf = v.float()
+            amax = Wf.abs().amax(dim=1)
+            s = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+            out[k] = (Wf / s[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float() * s[:, None]
+        else:
+            out[k] = v
+    return out
+
+
+def _llm_linear(x, W):
+    """F.linear; a weight kept in fp32 next to lower-precision activations (fp8_dequantized_weights) is applied in fp32 and
+    the output rounded to the activation dtype"""
+    if W.dtype == x.dtype:
+        return F.linear(x, W)
+    return F.linear(x.float(), W.float()).to(x.dtype)
+
+
 class LlamaOracle:
-    def __init__(self, spec: LlmSpec, weights: dict, dtype=torch.bfloat16):
+    def __init__(self, spec: LlmSpec, weights: dict, dtype=torch.bfloat16, keep_fp32=()):
+        """``keep_fp32``: names kept in fp32 whatever ``dtype`` is (the dequantised fp8 projections)"""
         self.spec, self.dtype = spec, dtype
         done = {}                                   # tensors aliased under several names are converted (and held) once
         self.W = {}
         for k, v in weights.items():
             if id(v) not in done:
-                done[id(v)] = v.to(dtype)
+                done[id(v)] = v.float() if k in keep_fp32 else v.to(dtype)
             self.W[k] = done[id(v)]
 
     def new_cache(self):
@@ -393,9 +426,9 @@ class LlamaOracle:
         for i in range(s.num_layers):
             p = f"model.layers.{i}."
             x = rmsnorm(h, W[p + "input_layernorm.weight"], s.rms_eps)
-            q = F.linear(x, W[p + "self_attn.q_proj.weight"]).view(n, nh, hd).transpose(0, 1)
-            k = F.linear(x, W[p + "self_attn.k_proj.weight"]).view(n, nkv, hd).transpose(0, 1)
-            v = F.linear(x, W[p + "self_attn.v_proj.weight"]).view(n, nkv, hd).transpose(0, 1)
+            q = _llm_linear(x, W[p + "self_attn.q_proj.weight"]).view(n, nh, hd).transpose(0, 1)
+            k = _llm_linear(x, W[p + "self_attn.k_proj.weight"]).view(n, nkv, hd).transpose(0, 1)
+            v = _llm_linear(x, W[p + "self_attn.v_proj.weight"]).view(n, nkv, hd).transpose(0, 1)
             q = (q * cos) + (rotate_half(q) * sin)                       # :157-158
             k = (k * cos) + (rotate_half(k) * sin)
             K, V = cache.update(i, k, v)
@@ -409,15 +442,15 @@ class LlamaOracle:
             a = a.transpose(0, 1).reshape(n, nh * hd)
             if taps is not None and i in taps.get("_layers", ()):
                 taps[f"attn{i}"] = a.clone()
-            h = h + F.linear(a, W[p + "self_attn.o_proj.weight"])        # :317
+            h = h + _llm_linear(a, W[p + "self_attn.o_proj.weight"])        # :317
             x = rmsnorm(h, W[p + "post_attention_layernorm.weight"], s.rms_eps)
-            x = F.linear(F.silu(F.linear(x, W[p + "mlp.gate_proj.weight"])) * F.linear(x, W[p + "mlp.up_proj.weight"]),
+            x = _llm_linear(F.silu(_llm_linear(x, W[p + "mlp.gate_proj.weight"])) * _llm_linear(x, W[p + "mlp.up_proj.weight"]),
                          W[p + "mlp.down_proj.weight"])                  # :174-176
             h = h + x                                                    # :323
             if taps is not None and i in taps.get("_layers", ()):
                 taps[f"h{i}"] = h.clone()
         h = rmsnorm(h[logits_from:], W["model.norm.weight"], s.rms_eps)
-        logits = F.linear(h, W["lm_head.weight"])                        # :477-480 (all rows, as HF, unless logits_from > 0)
+        logits = _llm_linear(h, W["lm_head.weight"])                        # :477-480 (all rows, as HF, unless logits_from > 0)
         return logits, cache
 
     @torch.no_grad()

@@ -45,6 +45,7 @@ def build(force=False, sanitize=None):
         src = re.sub(r"extern\s+__shared__", "extern", src)
         # GPU assembly (explicit s_waitcnt around direct-to-LDS loads): the emulated loads are synchronous
         src = re.sub(r'asm volatile\("s_waitcnt[^"]*"\s*:::\s*"memory"\);', ";", src)
+        src = re.sub(r'asm volatile\("s_waitcnt vmcnt\(%0\)"\s*::\s*"n"\([^;]*\)\s*:\s*"memory"\);', ";", src)   # counted form
         src = re.sub(r'asm volatile\(""\s*:\s*"\+v"\(\w+\)\);', ";", src)      # optimisation barrier on a VGPR value
         patched = os.path.join(OUT, s.replace(".hip", "_emul.cpp"))
         with open(patched, "w") as f:

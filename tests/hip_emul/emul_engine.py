@@ -44,6 +44,14 @@ def test_gemv(x, W):
     return y
 
 
+def test_gemv_fp8(x, Wq, scale):
+    """y[n,N] f32 = (x @ Wq^T) * scale through the fp8 e4m3 weight image of the emulated library (vlo_test_gemv_fp8)."""
+    x, Wq, scale = x.to(torch.bfloat16).contiguous(), Wq.contiguous().view(torch.uint8), scale.float().contiguous()
+    y = torch.zeros(x.shape[0], Wq.shape[0], dtype=torch.float32)
+    check(lib().vlo_test_gemv_fp8(_ptr(x), _ptr(Wq), _ptr(scale), _ptr(y), x.shape[0], Wq.shape[0], Wq.shape[1], None))
+    return y
+
+
 def gemv_plan(K, allow_ksplit):
     out = (C.c_int * 4)()
     check(lib().vlo_debug_gemv_plan(K, int(allow_ksplit), out))

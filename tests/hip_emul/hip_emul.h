@@ -146,6 +146,20 @@ static inline float atomicAdd(float *p, float v) {          // relaxed fp32 atom
 }
 static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 #define __builtin_amdgcn_s_sleep(x) sched_yield()
+#define __builtin_amdgcn_s_barrier() __syncthreads()
+// OCP e4m3fn pair -> two floats (v_cvt_pk_f32_fp8): bytes 0,1 (sel = false) or 2,3 of src
+static inline float emul_fp8_e4m3(unsigned b) {
+    const unsigned e = (b >> 3) & 15u, m = b & 7u;
+    float v = e == 0 ? ldexpf((float)m, -9) : ((e == 15 && m == 7) ? NAN : ldexpf(1.0f + (float)m / 8.0f, (int)e - 7));
+    return (b & 0x80u) ? -v : v;
+}
+typedef float emul_f32x2 __attribute__((ext_vector_type(2)));
+static inline emul_f32x2 emul_cvt_pk_f32_fp8(int src, bool hi) {
+    const unsigned u = (unsigned)src >> (hi ? 16 : 0);
+    emul_f32x2 r = {emul_fp8_e4m3(u & 0xffu), emul_fp8_e4m3((u >> 8) & 0xffu)};
+    return r;
+}
+#define __builtin_amdgcn_cvt_pk_f32_fp8(src, sel) emul_cvt_pk_f32_fp8((src), (sel))
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(order)
 // HW_REG_XCC_ID: a scrambled, uneven block -> "XCD" map (5 populated groups), so nothing may rely on a placement pattern
 #define __builtin_amdgcn_s_getreg(imm) ((unsigned)((blockIdx.x * 5u + 3u) % 7u % 5u))

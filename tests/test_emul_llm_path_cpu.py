@@ -353,3 +353,23 @@ def test_frame_ingest_kernels_match_the_oracle(E, H, W, R, layout, a):
     if H == W == R:
         assert np.array_equal(got, fr.transpose(0, 3, 1, 2))          # no resampling: bit-exact pass-through
     eng.close()
+
+
+@pytest.mark.parametrize("n,N,K", [(11, 64, 512), (3, 48, 1024), (16, 32, 2048)])
+def test_fp8_weight_image_gemv(E, n, N, K):
+    """The fp8 e4m3 weight image (two MFMA fragments per 16-byte lane load, e4m3 -> bf16 expansion in registers, per-output-channel
+    scale in the epilogue; csrc/gemv.hip, gemv_body.inc WQ = 1) against an fp64 matmul of the dequantised weights; quantisation by
+    checkpoint.quantize_fp8_per_channel == the oracle's fp8_dequantized_weights."""
+    from videollm_online_amd.checkpoint import quantize_fp8_per_channel
+    g = torch.Generator().manual_seed(n + N + K)
+    x = torch.randn(n, K, generator=g).bfloat16()
+    W = (torch.randn(N, K, generator=g) * K ** -0.5 * (1 + 3 * torch.rand(N, 1, generator=g))).bfloat16()
+    W[1] = 0                                                     # an all-zero row: scale 1, zeros
+    W[2, :8] = W[2].abs().max() * 2 ** -9                        # values that quantise to e4m3 subnormals
+    q, s = quantize_fp8_per_channel(W)
+    y = E.test_gemv_fp8(x, q, s)
+    Wd = q.float().double() * s.double()[:, None]
+    ref = x.double() @ Wd.T
+    assert (y.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()) * (K / 256) ** 0.5 + 1e-5
+    W2 = O.fp8_dequantized_weights({"lm_head.weight": W})["lm_head.weight"]
+    assert torch.equal(W2.double(), Wd.float().double())

@@ -78,6 +78,21 @@ def _adapter_maps(adapter_dir: str):
     return src, lora, extra, scale
 
 
+FP8_E4M3_MAX = 448.0
+
+
+def quantize_fp8_per_channel(W: torch.Tensor):
+    """Symmetric per-output-channel quantisation of a Linear weight [out, in] to OCP fp8 e4m3 (BASELINE.json configs[4],
+    SURVEY.md §8(f)-1 "fp8 + per-channel scales"): scale[n] = max|W[n]| / 448 (1 for an all-zero row),
+    q[n] = fp8_rne(W[n] / scale[n]).  Returns (q as torch.float8_e4m3fn [out, in], scale f32 [out]); W ~= q * scale[:, None].
+    The engine streams q (one byte per weight) and applies scale[n] to the fp32 dot product."""
+    Wf = W.float()
+    amax = Wf.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax / FP8_E4M3_MAX, torch.ones_like(amax))
+    q = (Wf / scale[:, None]).clamp_(-FP8_E4M3_MAX, FP8_E4M3_MAX).to(torch.float8_e4m3fn)
+    return q, scale
+
+
 def merge_lora(W: torch.Tensor, A: torch.Tensor, B: torch.Tensor, scale: float) -> torch.Tensor:
     """W [out,in] + scale * B [out,r] @ A [r,in], accumulated in fp32, rounded once to bf16."""
     return (W.float() + scale * (B.float() @ A.float())).to(torch.bfloat16)

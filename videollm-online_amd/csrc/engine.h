@@ -21,6 +21,8 @@ struct RawTensor {
 struct PackedLinear {
     void *Wp = nullptr;
     int N = 0, K = 0, NT = 0;
+    int wq = 0;               // 1: Wp is the fp8 e4m3 image (gemv.hip) and wscale holds the per-output-channel scales
+    float *wscale = nullptr;  // fp32 [NT * 16], packed row order
     GemvPlan plan{};
     Gemm64Plan plan64{};      // the 64-token block path over the same packed image (prefill.hip)
 };

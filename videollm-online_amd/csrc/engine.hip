@@ -66,7 +66,7 @@ __global__ void sum_partials_kernel(const float *P, int ksplit, int ld, float *y
     y[i] = s;
 }
 
-static size_t dt_size(int dt) { return dt == VLO_DT_F32 ? 4 : 2; }
+static size_t dt_size(int dt) { return dt == VLO_DT_F32 ? 4 : (dt == VLO_DT_FP8_E4M3 ? 1 : 2); }
 
 int dev_alloc(void **p, size_t bytes) {
     HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
@@ -89,6 +89,7 @@ int vlo_engine_create(const vlo_config *cfg, int device, vlo_engine **out) {
         return fail(VLO_E_INVALID, "bad Llama dimensions");
     const int hd = cfg->hidden_size / cfg->num_heads;
     if (hd != 64 && hd != 128) return fail(VLO_E_UNSUPPORTED, "head_dim must be 64 or 128");
+    if (cfg->weight_dtype != 0 && cfg->weight_dtype != 1) return fail(VLO_E_INVALID, "weight_dtype must be 0 (bf16) or 1 (fp8 e4m3)");
     if ((cfg->hidden_size & 31) || (cfg->intermediate_size & 31) || (cfg->vocab_size & 3))
         return fail(VLO_E_UNSUPPORTED, "hidden/intermediate must be multiples of 32, vocab of 4");
     const int T = cfg->tp_size > 1 ? cfg->tp_size : 1;
@@ -137,6 +138,15 @@ int vlo_engine_load_weight(vlo_engine *e, const char *name, const void *data, in
     // storage dtype inside the engine: LLM + connector bf16; ViT matmul weights f16, the rest of the ViT f32
     int ddt = VLO_DT_BF16;
     if (n == "rope.inv_freq") ddt = VLO_DT_F32;
+    if (dtype == VLO_DT_FP8_E4M3 || name_is(n, "_scale")) {
+        // fp8 storage of the streamed projections (vlo_config.weight_dtype = 1): quantised by the caller, kept as given
+        const bool streamed = n.rfind("vision.", 0) != 0 && n.rfind("connector.", 0) != 0 &&
+                              (name_is(n, "proj.weight") || n == "lm_head.weight" || name_is(n, "proj.weight_scale") || n == "lm_head.weight_scale");
+        if (e->cfg.weight_dtype != 1 || !streamed)
+            return fail(VLO_E_INVALID, n + ": fp8 weights / scales are accepted for the Llama projections of an engine created with weight_dtype = 1");
+        if (name_is(n, "_scale") ? dtype != VLO_DT_F32 : dtype != VLO_DT_FP8_E4M3) return fail(VLO_E_INVALID, n + ": expected fp8 e4m3 data and f32 scales");
+        ddt = dtype;
+    }
     if (n.rfind("vision.", 0) == 0) {
         const bool is_mat = name_is(n, "proj.weight") || name_is(n, "fc1.weight") || name_is(n, "fc2.weight") ||
                             name_is(n, "patch_embedding.weight") || name_is(n, "in_proj_weight");
@@ -181,28 +191,47 @@ static int take(vlo_engine *e, const std::string &name, std::vector<int64_t> sha
 
 // pack rows [row0, row0+N) x columns [col0, col0+K) of the full bf16 linear `name` [Nfull][Kfull] into dst tiles
 // (see gemv.hip); the slice is this rank's tensor-parallel shard (the whole matrix when tp_size == 1)
-static int pack_into(vlo_engine *e, const std::string &name, int Nfull, int Kfull, int row0, int N, int col0, int K, void *dst,
+static int pack_into(vlo_engine *e, const std::string &name, int Nfull, int Kfull, int row0, int N, int col0, int K, PackedLinear &pl,
                      int tile_stride, int tile_offset, int half = -1) {
     RawTensor t;
     int rc = take(e, name, {Nfull, Kfull}, &t);
     if (rc) return rc;
     const int NT = half < 0 ? (N + 15) / 16 : (N + 7) / 8;
+    if (pl.wq) {
+        RawTensor sc;
+        if (t.dtype != VLO_DT_FP8_E4M3) return fail(VLO_E_INVALID, name + ": this engine streams fp8 weights (weight_dtype = 1): load it as VLO_DT_FP8_E4M3 with its _scale");
+        if ((rc = take(e, name + "_scale", {Nfull}, &sc))) return rc;
+        const uint8_t *src = (const uint8_t *)t.ptr + (size_t)row0 * Kfull + col0;
+        HIP_TRY(pack_weight_fp8_launch(src, (const float *)sc.ptr + row0, pl.Wp, pl.wscale, N, K, Kfull, NT, tile_stride, tile_offset, half, 0));
+        return VLO_OK;
+    }
+    if (t.dtype != VLO_DT_BF16) return fail(VLO_E_INVALID, name + ": expected a bf16 matrix");
     const unsigned short *src = (const unsigned short *)t.ptr + (size_t)row0 * Kfull + col0;
-    HIP_TRY(pack_weight_launch(src, dst, N, K, Kfull, NT, tile_stride, tile_offset, half, 0));
+    HIP_TRY(pack_weight_launch(src, pl.Wp, N, K, Kfull, NT, tile_stride, tile_offset, half, 0));
     return VLO_OK;
 }
 
-static int make_linear(vlo_engine *e, PackedLinear *pl, int N, int K, bool allow_ksplit) {
+static int make_linear(vlo_engine *e, PackedLinear *pl, int N, int K, bool allow_ksplit, bool fp8 = false) {
     pl->N = N;
     pl->K = K;
     pl->NT = (N + 15) / 16;
+    pl->wq = fp8 ? 1 : 0;
     if (gemv_plan(K, allow_ksplit, &pl->plan)) return fail(VLO_E_UNSUPPORTED, "no GEMV plan for K=" + std::to_string(K));
-    if (gemm64_plan(K, &pl->plan64)) return fail(VLO_E_UNSUPPORTED, "no block-GEMM plan for K=" + std::to_string(K));
-    const size_t bytes = (size_t)pl->NT * 16 * K * 2;
+    if (fp8 && ((pl->plan.KF & 1) || pl->plan.NW != 8 || (K & 63)))
+        return fail(VLO_E_UNSUPPORTED, "fp8 weight image needs an even fragment count per wave (K=" + std::to_string(K) + ")");
+    // fp8 engines run every input through 16-row chunks (the 64-token block path streams the bf16 image only)
+    if (!fp8 && gemm64_plan(K, &pl->plan64)) return fail(VLO_E_UNSUPPORTED, "no block-GEMM plan for K=" + std::to_string(K));
+    const size_t bytes = (size_t)pl->NT * 16 * K * (fp8 ? 1 : 2);
     int rc = dev_alloc(&pl->Wp, bytes);
     if (rc) return rc;
     e->owned.push_back(pl->Wp);
     e->weight_bytes += (int64_t)bytes;
+    if (fp8) {
+        if ((rc = dev_alloc((void **)&pl->wscale, (size_t)pl->NT * 16 * 4))) return rc;
+        e->owned.push_back(pl->wscale);
+        HIP_TRY(hipMemset(pl->wscale, 0, (size_t)pl->NT * 16 * 4));
+        e->weight_bytes += (int64_t)pl->NT * 16 * 4;
+    }
     return VLO_OK;
 }
 
@@ -236,33 +265,36 @@ int vlo_engine_finalize(vlo_engine *e) {
     const int NqF = c.num_heads * hd, NkvF = c.num_kv_heads * hd;       // full projection widths
     const int Nq = e->nh_l * hd, Nkv = e->nkv_l * hd, Nqkv = Nq + 2 * Nkv;   // this rank's heads
     int rc;
+    const bool f8 = c.weight_dtype == 1;
     e->layers.resize(c.num_layers);
     for (int l = 0; l < c.num_layers; ++l) {
         LayerWeights &L = e->layers[l];
         const std::string p = "model.layers." + std::to_string(l) + ".";
-        if ((rc = make_linear(e, &L.qkv, Nqkv, H, false))) return rc;
-        if ((rc = pack_into(e, p + "self_attn.q_proj.weight", NqF, H, r * Nq, Nq, 0, H, L.qkv.Wp, 1, 0))) return rc;
-        if ((rc = pack_into(e, p + "self_attn.k_proj.weight", NkvF, H, r * Nkv, Nkv, 0, H, L.qkv.Wp, 1, Nq / 16))) return rc;
-        if ((rc = pack_into(e, p + "self_attn.v_proj.weight", NkvF, H, r * Nkv, Nkv, 0, H, L.qkv.Wp, 1, (Nq + Nkv) / 16))) return rc;
-        if ((rc = make_linear(e, &L.o, H, Nq, e->tp_size > 1))) return rc;          // TP: fp32 partial sums, all-reduced
-        if ((rc = pack_into(e, p + "self_attn.o_proj.weight", H, NqF, 0, H, r * Nq, Nq, L.o.Wp, 1, 0))) return rc;
-        if ((rc = make_linear(e, &L.gate_up, 2 * I, H, false))) return rc;       // SwiGLU epilogue needs whole K
+        if ((rc = make_linear(e, &L.qkv, Nqkv, H, false, f8))) return rc;
+        if ((rc = pack_into(e, p + "self_attn.q_proj.weight", NqF, H, r * Nq, Nq, 0, H, L.qkv, 1, 0))) return rc;
+        if ((rc = pack_into(e, p + "self_attn.k_proj.weight", NkvF, H, r * Nkv, Nkv, 0, H, L.qkv, 1, Nq / 16))) return rc;
+        if ((rc = pack_into(e, p + "self_attn.v_proj.weight", NkvF, H, r * Nkv, Nkv, 0, H, L.qkv, 1, (Nq + Nkv) / 16))) return rc;
+        if ((rc = make_linear(e, &L.o, H, Nq, e->tp_size > 1, f8))) return rc;          // TP: fp32 partial sums, all-reduced
+        if ((rc = pack_into(e, p + "self_attn.o_proj.weight", H, NqF, 0, H, r * Nq, Nq, L.o, 1, 0))) return rc;
+        if ((rc = make_linear(e, &L.gate_up, 2 * I, H, false, f8))) return rc;       // SwiGLU epilogue needs whole K
         if (I % 16) return fail(VLO_E_UNSUPPORTED, "intermediate_size (per rank) must be a multiple of 16");
         // gate and up share every tile (8 + 8 rows): I/8 single tiles, SwiGLU inside one tile
-        if ((rc = pack_into(e, p + "mlp.gate_proj.weight", Ifull, H, r * I, I, 0, H, L.gate_up.Wp, 1, 0, 0))) return rc;
-        if ((rc = pack_into(e, p + "mlp.up_proj.weight", Ifull, H, r * I, I, 0, H, L.gate_up.Wp, 1, 0, 1))) return rc;
-        if ((rc = make_linear(e, &L.down, H, I, true))) return rc;
-        if ((rc = pack_into(e, p + "mlp.down_proj.weight", H, Ifull, 0, H, r * I, I, L.down.Wp, 1, 0))) return rc;
+        if ((rc = pack_into(e, p + "mlp.gate_proj.weight", Ifull, H, r * I, I, 0, H, L.gate_up, 1, 0, 0))) return rc;
+        if ((rc = pack_into(e, p + "mlp.up_proj.weight", Ifull, H, r * I, I, 0, H, L.gate_up, 1, 0, 1))) return rc;
+        if ((rc = make_linear(e, &L.down, H, I, true, f8))) return rc;
+        if ((rc = pack_into(e, p + "mlp.down_proj.weight", H, Ifull, 0, H, r * I, I, L.down, 1, 0))) return rc;
         if ((rc = take_vec(e, p + "input_layernorm.weight", H, &L.ln_in))) return rc;
         if ((rc = take_vec(e, p + "post_attention_layernorm.weight", H, &L.ln_post))) return rc;
         HIP_TRY(hipDeviceSynchronize());
         for (const char *sfx : {"self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
-                                "self_attn.o_proj.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight"})
+                                "self_attn.o_proj.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight"}) {
             drop_raw(e, p + sfx);
+            drop_raw(e, p + sfx + "_scale");
+        }
     }
     if ((rc = take_vec(e, "model.norm.weight", H, &e->norm_w))) return rc;
-    if ((rc = make_linear(e, &e->lm_head, e->V_l, H, false))) return rc;
-    if ((rc = pack_into(e, "lm_head.weight", c.vocab_size, H, r * e->V_l, e->V_l, 0, H, e->lm_head.Wp, 1, 0))) return rc;
+    if ((rc = make_linear(e, &e->lm_head, e->V_l, H, false, f8))) return rc;
+    if ((rc = pack_into(e, "lm_head.weight", c.vocab_size, H, r * e->V_l, e->V_l, 0, H, e->lm_head, 1, 0))) return rc;
     {   // embedding table stays row-major (gather), replicated on every rank
         RawTensor t;
         if ((rc = take(e, "model.embed_tokens.weight", {c.vocab_size, H}, &t))) return rc;
@@ -274,15 +306,16 @@ int vlo_engine_finalize(vlo_engine *e) {
     if (e->raw.count("connector.0.weight")) {
         const int Hv = c.vision_hidden_size;
         if ((rc = make_linear(e, &e->conn0, H, Hv, false))) return rc;
-        if ((rc = pack_into(e, "connector.0.weight", H, Hv, 0, H, 0, Hv, e->conn0.Wp, 1, 0))) return rc;
+        if ((rc = pack_into(e, "connector.0.weight", H, Hv, 0, H, 0, Hv, e->conn0, 1, 0))) return rc;
         if ((rc = make_linear(e, &e->conn2, H, H, false))) return rc;
-        if ((rc = pack_into(e, "connector.2.weight", H, H, 0, H, 0, H, e->conn2.Wp, 1, 0))) return rc;
+        if ((rc = pack_into(e, "connector.2.weight", H, H, 0, H, 0, H, e->conn2, 1, 0))) return rc;
         if ((rc = take_vec(e, "connector.0.bias", H, &e->conn0_b))) return rc;
         if ((rc = take_vec(e, "connector.2.bias", H, &e->conn2_b))) return rc;
         e->has_connector = true;
     }
     HIP_TRY(hipDeviceSynchronize());
     drop_raw(e, "lm_head.weight");
+    drop_raw(e, "lm_head.weight_scale");
     drop_raw(e, "connector.0.weight");
     drop_raw(e, "connector.2.weight");
 
@@ -348,7 +381,11 @@ double vlo_step_algorithmic_bytes(const vlo_engine *e, int64_t Lc, int n) {
     const vlo_config &c = e->cfg;
     const double H = c.hidden_size, I = c.intermediate_size, hd = e->head_dim;
     const double per_layer = (H * (c.num_heads * hd) * 2 + H * (c.num_kv_heads * hd) * 2 + 3.0 * H * I) * 2.0;
-    const double W = per_layer * c.num_layers + (double)c.vocab_size * H * 2.0;
+    double W = per_layer * c.num_layers + (double)c.vocab_size * H * 2.0;
+    if (c.weight_dtype == 1) {      // fp8 image: one byte per weight + one fp32 scale per output channel
+        const double rows_per_layer = (c.num_heads + 2.0 * c.num_kv_heads) * hd + H + 2.0 * I + H;
+        W = W / 2.0 + (rows_per_layer * c.num_layers + c.vocab_size) * 4.0;
+    }
     const double kv = 2.0 * c.num_layers * c.num_kv_heads * hd * 2.0;
     return W + kv * (double)(Lc + n) + kv * n + 2.0 * n * H * 2.0;
 }
@@ -555,6 +592,8 @@ int vlo_profile_calibrate(vlo_engine *e, void *stream, double *empty_bracket_us)
 GemvArgs gemv_args(const PackedLinear &pl, const unsigned short *x, int ldx, int n_rows) {
     GemvArgs a{};
     a.Wp = pl.Wp;
+    a.wq = pl.wq;
+    a.wscale = pl.wscale;
     a.x = x;
     a.K = pl.K;
     a.ldx = ldx;
@@ -725,7 +764,7 @@ int vlo_llm_step(vlo_session *s, const void *embeds_dev, int n, void *last_logit
         const int left = n - c0;
         const unsigned short *src = (const unsigned short *)embeds_dev + (size_t)c0 * H;
         unsigned short *all = all_logits_dev ? (unsigned short *)all_logits_dev + (size_t)c0 * V : nullptr;
-        if (block_path && left > 16) {
+        if (block_path && left > 16 && e->cfg.weight_dtype != 1) {
             const int m = std::min(VLO_BLOCK_TOKENS, left);
             if ((rc = run_block(s, src, m, c0 + m == n, all, st))) return rc;
             c0 += m;
@@ -998,12 +1037,44 @@ int vlo_test_gemv(const void *x_dev, const void *W_dev, float *y_dev, int n, int
     return VLO_OK;
 }
 
+int vlo_test_gemv_fp8(const void *x_dev, const void *Wq_dev, const float *scale_dev, float *y_dev, int n, int N, int K, void *stream) {
+    if (!x_dev || !Wq_dev || !scale_dev || !y_dev || n <= 0 || n > 16 || N <= 0 || (N & 3)) return fail(VLO_E_INVALID, "bad test_gemv_fp8 arguments");
+    hipStream_t st = (hipStream_t)stream;
+    GemvPlan plan;
+    if (gemv_plan(K, true, &plan)) return fail(VLO_E_UNSUPPORTED, "no GEMV plan for K");
+    if ((plan.KF & 1) || plan.NW != 8 || (K & 63)) return fail(VLO_E_UNSUPPORTED, "fp8 weight image needs an even fragment count per wave for this K");
+    const int NT = (N + 15) / 16;
+    ScratchBufs sc;
+    void *Wp = nullptr, *xp = nullptr;
+    float *P = nullptr, *Y = nullptr, *sp = nullptr;
+    HIP_TRY(sc.alloc(&Wp, (size_t)NT * 16 * K));
+    HIP_TRY(sc.alloc(&xp, (size_t)32 * K * 2));
+    HIP_TRY(sc.alloc((void **)&sp, (size_t)NT * 16 * 4));
+    HIP_TRY(sc.alloc((void **)&P, (size_t)plan.ksplit * 16 * NT * 16 * 4));
+    HIP_TRY(sc.alloc((void **)&Y, (size_t)16 * NT * 16 * 4));
+    HIP_TRY(hipMemsetAsync(xp, 0, (size_t)32 * K * 2, st));
+    HIP_TRY(hipMemcpyAsync(xp, x_dev, (size_t)n * K * 2, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(pack_weight_fp8_launch(Wq_dev, scale_dev, Wp, sp, N, K, K, NT, 1, 0, -1, st));
+    GemvArgs a{};
+    a.Wp = Wp; a.wq = 1; a.wscale = sp; a.x = (const unsigned short *)xp; a.out_f32 = P;
+    a.K = K; a.ldx = K; a.ldo = NT * 16; a.NT = NT; a.N_valid = N; a.n_rows = n;
+    HIP_TRY(gemv_launch(a, plan, XSRC_PLAIN, EPI_PARTIAL_F32, st));
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((n * NT * 16 + 255) / 256), dim3(256), 0, st, P, plan.ksplit, NT * 16, Y, n, NT * 16);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy2DAsync(y_dev, (size_t)N * 4, Y, (size_t)NT * 16 * 4, (size_t)N * 4, n, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return VLO_OK;
+}
+
 int vlo_bench_gemv(int N, int K, int n_rows, int epi, int iters, int nbuf, double *avg_us) {
+    const int fp8 = (epi & 0x100) ? 1 : 0;          // bit 8 of `epi`: time the fp8 e4m3 weight image instead of the bf16 one
+    epi &= 0xff;
     if (N <= 0 || K <= 0 || n_rows <= 0 || n_rows > 16 || iters <= 0 || nbuf <= 0 || !avg_us) return fail(VLO_E_INVALID, "bad bench_gemv arguments");
     GemvPlan plan;
     if (gemv_plan(K, epi == EPI_PARTIAL_F32, &plan)) return fail(VLO_E_UNSUPPORTED, "no GEMV plan for K");
     const int NT = (N + 15) / 16;
-    const size_t wbytes = (size_t)NT * 16 * K * 2;
+    const size_t wbytes = (size_t)NT * 16 * K * (fp8 ? 1 : 2);
+    if (fp8 && ((plan.KF & 1) || plan.NW != 8)) return fail(VLO_E_UNSUPPORTED, "no fp8 GEMV for this K");
     ScratchBufs sc;
     std::vector<void *> Wp(nbuf, nullptr);
     void *x = nullptr, *o32 = nullptr, *o16 = nullptr, *hbuf = nullptr, *sq = nullptr, *nw = nullptr, *tab = nullptr, *kvp = nullptr;
@@ -1029,6 +1100,12 @@ int vlo_bench_gemv(int N, int K, int n_rows, int epi, int iters, int nbuf, doubl
     HIP_TRY(sc.alloc((void **)&pt, 64));
     HIP_TRY(hipMemset(pt, 0, 64));
     GemvArgs a{};
+    void *wsc = nullptr;
+    if (fp8) {
+        HIP_TRY(sc.alloc(&wsc, (size_t)NT * 16 * 4));
+        HIP_TRY(hipMemset(wsc, 0x3c, (size_t)NT * 16 * 4));
+        a.wq = 1; a.wscale = (const float *)wsc;
+    }
     a.x = (const unsigned short *)x; a.out_f32 = (float *)o32; a.out_bf16 = (unsigned short *)o16;
     a.K = K; a.ldx = K; a.ldo = (epi == EPI_SWIGLU) ? NT * 8 : NT * 16; a.NT = NT; a.N_valid = N; a.n_rows = n_rows;   // SwiGLU: 8 output columns per tile
     int xsrc = XSRC_PLAIN;

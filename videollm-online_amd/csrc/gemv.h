@@ -22,6 +22,8 @@ enum {
 
 struct GemvArgs {
     const void *Wp;               // packed weights (see gemv.hip)
+    int wq;                       // 0: bf16 image;  1: fp8 e4m3 image + per-output-channel scales
+    const float *wscale;          // wq: fp32 [NT * 16] in packed row order (row r of tile t at t * 16 + r)
     const unsigned short *x;      // XSRC_PLAIN: bf16 [16][ldx];  XSRC_NORM: residual stream h, bf16 [16][ldx]
     float *out_f32;               // EPI_PARTIAL_F32
     unsigned short *out_bf16;     // EPI_BF16 / GELU / SWIGLU: [16][ldo];  EPI_ROPE: q buffer [16][nh*hd]
@@ -58,5 +60,8 @@ hipError_t gemv_launch(GemvArgs a, const GemvPlan &p, int xsrc, int epi, hipStre
 hipError_t gemv_prepare(GemvArgs *a, const GemvPlan &p, int epi, int *grid_x, int *grid_y, size_t *lds_bytes);
 // source tiles [0,NT) of row-major W[N_valid][K] (row stride ldw elements) -> packed tiles t*tile_stride + tile_offset of Wp
 // half = -1: 16-row tiles; half = 0/1: 8-row interleave of two matrices into one tile (gate / up)
+// fp8 e4m3 source [N_valid][K] (row stride ldw BYTES) + per-row scales -> fp8 image and scales in packed row order
+hipError_t pack_weight_fp8_launch(const void *W, const float *scale, void *Wp, float *scale_p, int N_valid, int K, int ldw, int NT,
+                                  int tile_stride, int tile_offset, int half, hipStream_t st);
 hipError_t pack_weight_launch(const void *W, void *Wp, int N_valid, int K, int ldw, int NT, int tile_stride, int tile_offset,
                               int half, hipStream_t st);

@@ -67,6 +67,45 @@ __global__ void pack_weight_kernel(const bf16_t *__restrict__ W, uint4 *__restri
     }
 }
 
+// fp8 e4m3 image (vlo_config.weight_dtype = 1): half the bytes per weight, the same one-16-byte-load-per-lane stream:
+//   Wp8[tile][kf2][lane] : 16 bytes = W[tile*16 + (lane&15)][(2*kf2)*32 + (lane>>4)*8 .. +8]  ++  the same 8 of fragment 2*kf2+1
+// so one load feeds TWO MFMAs (expanded to bf16 in registers, exactly); the per-output-channel scale is applied to the
+// reduced fp32 sums in the epilogue, in packed row order.
+__global__ void pack_weight_fp8_kernel(const uint8_t *__restrict__ W, uint4 *__restrict__ Wp, int N_valid, int K, int ldw,
+                                       int NT, int KF2tot, int tile_stride, int tile_offset, int half) {
+    const size_t total = (size_t)NT * KF2tot * 64;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const size_t t = i >> 6;
+        const int kf2 = (int)(t % KF2tot);
+        const int tile = (int)(t / KF2tot);
+        const int k = kf2 * 64 + (lane >> 4) * 8;
+        const int r16 = lane & 15;
+        int n;
+        if (half < 0) n = tile * 16 + r16;
+        else if ((r16 >> 3) != half) continue;
+        else n = tile * 8 + (r16 & 7);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (n < N_valid) {
+            const uint2 lo = *reinterpret_cast<const uint2 *>(W + (size_t)n * ldw + k);
+            const uint2 hi = *reinterpret_cast<const uint2 *>(W + (size_t)n * ldw + k + 32);
+            v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+        Wp[((size_t)(tile * tile_stride + tile_offset) * KF2tot + kf2) * 64 + lane] = v;
+    }
+}
+__global__ void pack_scale_kernel(const float *__restrict__ scale, float *__restrict__ dst, int N_valid, int NT, int tile_stride,
+                                  int tile_offset, int half) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NT * 16) return;
+    const int tile = i >> 4, r16 = i & 15;
+    int n;
+    if (half < 0) n = tile * 16 + r16;
+    else if ((r16 >> 3) != half) return;
+    else n = tile * 8 + (r16 & 7);
+    dst[(size_t)(tile * tile_stride + tile_offset) * 16 + r16] = n < N_valid ? scale[n] : 0.f;
+}
+
 // ------------------------------------------------------------------------------------
 // epilogue math (rounding points follow the reference's bf16 CPU path)
 // ------------------------------------------------------------------------------------
@@ -82,8 +121,25 @@ VLO_DEV float gelu_python_bf16(float x) {    // HF GELUActivation(use_gelu_pytho
     return rbf(a * s);
 }
 VLO_DEV float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+VLO_DEV float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 
-template <int KF, int NW, int XSRC, int EPI>
+// fp8 e4m3 (OCP, gfx950's native format) -> bf16, exact: every e4m3 value is a bf16 value, so the f32 the converter
+// returns is truncated, not rounded.  One 16-byte register = the 8 + 8 weights of two consecutive MFMA fragments.
+typedef __attribute__((ext_vector_type(2))) float f32x2_cv;
+template <bool HI>
+VLO_DEV unsigned fp8x2_to_bf16x2(unsigned src) {          // bytes 0,1 (HI = false) or 2,3 of src
+    const f32x2_cv v = __builtin_amdgcn_cvt_pk_f32_fp8((int)src, HI);
+    return (__float_as_uint(v[0]) >> 16) | (__float_as_uint(v[1]) & 0xffff0000u);
+}
+VLO_DEV void fp8x16_to_bf16(frag_ab raw, frag_ab &f0, frag_ab &f1) {
+    const uint4 u = __builtin_bit_cast(uint4, raw);
+    f0 = __builtin_bit_cast(frag_ab, make_uint4(fp8x2_to_bf16x2<false>(u.x), fp8x2_to_bf16x2<true>(u.x),
+                                                  fp8x2_to_bf16x2<false>(u.y), fp8x2_to_bf16x2<true>(u.y)));
+    f1 = __builtin_bit_cast(frag_ab, make_uint4(fp8x2_to_bf16x2<false>(u.z), fp8x2_to_bf16x2<true>(u.z),
+                                                  fp8x2_to_bf16x2<false>(u.w), fp8x2_to_bf16x2<true>(u.w)));
+}
+
+template <int KF, int NW, int XSRC, int EPI, int WQ>
 __global__ __launch_bounds__(NW * 64) void gemv16_kernel(GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 red[];      // [2][NW][CTG][64] float4, then scratch
 #define VLO_GEMV_BX blockIdx.x
@@ -158,10 +214,17 @@ int gemv_grid_x(const GemvArgs &a, const GemvPlan &p, int epi) {
 template <int KF, int NW>
 static hipError_t launch_variant(const GemvArgs &a, int xsrc, int epi, dim3 grid, size_t lds, hipStream_t st) {
     dim3 block(NW * 64);
-#define VLO_GO(XS, EP)                                                                    \
-    do {                                                                                  \
-        hipLaunchKernelGGL((gemv16_kernel<KF, NW, XS, EP>), grid, block, lds, st, a);     \
-        return hipGetLastError();                                                         \
+#define VLO_GO(XS, EP)                                                                            \
+    do {                                                                                          \
+        if (a.wq) {                                                                               \
+            if constexpr ((KF & 1) == 0 && NW == 8)                                               \
+                hipLaunchKernelGGL((gemv16_kernel<KF, NW, XS, EP, 1>), grid, block, lds, st, a);  \
+            else                                                                                  \
+                return hipErrorInvalidValue;      /* fp8 image: two fragments per 16-byte load */ \
+        } else {                                                                                  \
+            hipLaunchKernelGGL((gemv16_kernel<KF, NW, XS, EP, 0>), grid, block, lds, st, a);      \
+        }                                                                                         \
+        return hipGetLastError();                                                                 \
     } while (0)
     if (xsrc == XSRC_NORM) {
         if (epi == EPI_SWIGLU) VLO_GO(XSRC_NORM, EPI_SWIGLU);
@@ -200,6 +263,20 @@ hipError_t gemv_launch(GemvArgs a, const GemvPlan &p, int xsrc, int epi, hipStre
     VLO_CASE(4, 14) VLO_CASE(4, 11) VLO_CASE(4, 1) VLO_CASE(2, 11) VLO_CASE(1, 1)
 #undef VLO_CASE
     return hipErrorInvalidValue;
+}
+
+hipError_t pack_weight_fp8_launch(const void *W, const float *scale, void *Wp, float *scale_p, int N_valid, int K, int ldw, int NT,
+                                  int tile_stride, int tile_offset, int half, hipStream_t st) {
+    if (K & 63) return hipErrorInvalidValue;
+    const int KF2tot = K >> 6;
+    const size_t total = (size_t)NT * KF2tot * 64;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(pack_weight_fp8_kernel, dim3(blocks), dim3(256), 0, st, (const uint8_t *)W, (uint4 *)Wp, N_valid, K, ldw, NT, KF2tot,
+                       tile_stride, tile_offset, half);
+    hipLaunchKernelGGL(pack_scale_kernel, dim3((NT * 16 + 255) / 256), dim3(256), 0, st, scale, scale_p, N_valid, NT, tile_stride,
+                       tile_offset, half);
+    return hipGetLastError();
 }
 
 hipError_t pack_weight_launch(const void *W, void *Wp, int N_valid, int K, int ldw, int NT, int tile_stride, int tile_offset,

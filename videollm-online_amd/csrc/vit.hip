@@ -57,8 +57,15 @@ __global__ __launch_bounds__(WM * WN * 64) void vit_gemm_kernel(GemmArgs a) {
     constexpr bool GLDS = (DEPTH == 0);
     constexpr int RING = GLDS ? 1 : DEPTH;
     constexpr int MI = BM / (WM * 16), NI = BN / (WN * 16);    // 16x16 MFMA tiles per wave along m / n (WM x WN waves)
-    __shared__ __attribute__((aligned(16))) f16_t sX[2][BM * GEMM_BK];
-    __shared__ __attribute__((aligned(16))) f16_t sW[2][BN * GEMM_BK];
+    // ONE shared object (a second one makes hipcc drain the direct-to-LDS queue before every k-step, cdna guide §5 trap 4a):
+    // NBUF stages of [X tile | W tile].  Direct-to-LDS path: 4 stages = 3 K tiles in flight per block — with ~1 block per
+    // CU (M = 576 B rows give 288..1152 tiles) nothing else hides the L2 -> LDS latency (2 stages measured 1.4 us per K tile
+    // against 0.2 us of MFMA work: 15 % matrix-core utilisation).
+    constexpr int NBUF = GLDS ? 4 : 2;
+    constexpr int STAGE = (BM + BN) * GEMM_BK;
+    __shared__ __attribute__((aligned(16))) f16_t smem[NBUF * STAGE];
+#define sX(buf) (smem + (buf) * STAGE)
+#define sW(buf) (smem + (buf) * STAGE + BM * GEMM_BK)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w / WN, wn = w % WN;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -110,11 +117,11 @@ __global__ __launch_bounds__(WM * WN * 64) void vit_gemm_kernel(GemmArgs a) {
     do {                                                                                                              \
         _Pragma("unroll") for (int i = 0; i < XCH; ++i) {                                                             \
             const int id = tid + i * NTHR, row = id >> 3, c = id & 7;                                                  \
-            *reinterpret_cast<uint4 *>(&sX[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]) = rx[slot][i];               \
+            *reinterpret_cast<uint4 *>(&sX(buf)[row * GEMM_BK + ((c ^ (row & 7)) << 3)]) = rx[slot][i];               \
         }                                                                                                             \
         _Pragma("unroll") for (int i = 0; i < WCH; ++i) {                                                             \
             const int id = tid + i * NTHR, row = id >> 3, c = id & 7;                                                  \
-            *reinterpret_cast<uint4 *>(&sW[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]) = rw[slot][i];               \
+            *reinterpret_cast<uint4 *>(&sW(buf)[row * GEMM_BK + ((c ^ (row & 7)) << 3)]) = rw[slot][i];               \
         }                                                                                                             \
     } while (0)
 
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(WM * WN * 64) void vit_gemm_kernel(GemmArgs a) {
                 const int m = min(m0 + piece * 8 + lrow, a.M - 1);          // clamp: rows past M are computed and dropped
                 const f16_t *g = a.X + (size_t)m * a.ldx + k0 + lc * 8;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                                 (__attribute__((address_space(3))) void *)&sX[buf][piece * 8 * GEMM_BK], 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)&sX(buf)[piece * 8 * GEMM_BK], 16, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < WI; ++i) {
@@ -145,15 +152,24 @@ __global__ __launch_bounds__(WM * WN * 64) void vit_gemm_kernel(GemmArgs a) {
                 const int n = min(n0 + piece * 8 + lrow, a.N - 1);
                 const f16_t *g = a.W + (size_t)n * a.K + k0 + lc * 8;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                                 (__attribute__((address_space(3))) void *)&sW[buf][piece * 8 * GEMM_BK], 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)&sW(buf)[piece * 8 * GEMM_BK], 16, 0, 0);
             }
         };
-        issue(0, kbeg);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // NBUF-stage pipeline, one raw barrier per K tile.  Iteration kt: wait until THIS wave's pieces of tile kt have landed
+        // (counted vmcnt: the younger tiles stay in flight), barrier (everybody's pieces have landed AND everybody is done
+        // reading tile kt-1), refill the stage tile kt-1 occupied with tile kt+NBUF-1, compute tile kt.
+        constexpr int PER_TILE = XI + WI;                   // direct-to-LDS instructions per wave per K tile
+#pragma unroll
+        for (int j = 0; j < NBUF - 1; ++j)
+            if (j < nk) issue(j, kbeg + j * GEMM_BK);
         for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < nk) issue(buf ^ 1, kbeg + (kt + 1) * GEMM_BK);
+            const int buf = kt % NBUF;
+            const int ahead = min(nk, kt + NBUF - 1) - kt - 1;        // younger tiles already issued: 0 .. NBUF-2
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_TILE) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + NBUF - 1 < nk) issue((kt + NBUF - 1) % NBUF, kbeg + (kt + NBUF - 1) * GEMM_BK);
 #pragma unroll
             for (int kk = 0; kk < GEMM_BK / 32; ++kk) {
                 frag_ab fx[MI], fw[NI];
@@ -161,20 +177,18 @@ __global__ __launch_bounds__(WM * WN * 64) void vit_gemm_kernel(GemmArgs a) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     const int row = wm * (BM / WM) + i * 16 + r16;
-                    fx[i] = *reinterpret_cast<const frag_ab *>(&sX[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]);
+                    fx[i] = *reinterpret_cast<const frag_ab *>(&sX(buf)[row * GEMM_BK + ((c ^ (row & 7)) << 3)]);
                 }
 #pragma unroll
                 for (int jn = 0; jn < NI; ++jn) {
                     const int row = wn * (BN / WN) + jn * 16 + r16;
-                    fw[jn] = *reinterpret_cast<const frag_ab *>(&sW[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]);
+                    fw[jn] = *reinterpret_cast<const frag_ab *>(&sW(buf)[row * GEMM_BK + ((c ^ (row & 7)) << 3)]);
                 }
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int jn = 0; jn < NI; ++jn) acc[i][jn] = mfma_f16(fw[jn], fx[i], acc[i][jn]);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile kt+1 has landed (issued a whole compute phase ago)
-            __syncthreads();                                      // and every wave is done reading tile kt
         }
     } else {
     // prologue: DEPTH tiles in flight; the first one lands in LDS buffer 0
@@ -199,12 +213,12 @@ __global__ __launch_bounds__(WM * WN * 64) void vit_gemm_kernel(GemmArgs a) {
 #pragma unroll
                     for (int i = 0; i < MI; ++i) {
                         const int row = wm * (BM / WM) + i * 16 + r16;
-                        fx[i] = *reinterpret_cast<const frag_ab *>(&sX[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]);
+                        fx[i] = *reinterpret_cast<const frag_ab *>(&sX(buf)[row * GEMM_BK + ((c ^ (row & 7)) << 3)]);
                     }
 #pragma unroll
                     for (int jn = 0; jn < NI; ++jn) {
                         const int row = wn * (BN / WN) + jn * 16 + r16;
-                        fw[jn] = *reinterpret_cast<const frag_ab *>(&sW[buf][row * GEMM_BK + ((c ^ (row & 7)) << 3)]);
+                        fw[jn] = *reinterpret_cast<const frag_ab *>(&sW(buf)[row * GEMM_BK + ((c ^ (row & 7)) << 3)]);
                     }
 #pragma unroll
                     for (int i = 0; i < MI; ++i)
@@ -219,6 +233,8 @@ __global__ __launch_bounds__(WM * WN * 64) void vit_gemm_kernel(GemmArgs a) {
     }
 #undef LOAD_TILE
 #undef STORE_TILE
+#undef sX
+#undef sW
 
     // epilogue: lane holds out[m][n .. n+3], m = tile row (lane&15), n = tile col (lane>>4)*4
 #pragma unroll

@@ -32,6 +32,10 @@ class EngineConfig:
     # tensor parallel shard held by this engine (see TpGroup)
     tp_rank: int = 0
     tp_size: int = 1
+    # storage of the streamed Llama projections: "bf16", or "fp8" = e4m3 + one fp32 scale per output channel
+    # (BASELINE.json configs[4]; include/vlo.h vlo_config.weight_dtype).  bf16 weights handed to an fp8 engine are quantised
+    # on the way in (checkpoint.quantize_fp8_per_channel)
+    weight_dtype: str = "bf16"
 
     def to_c(self) -> _C.VloConfig:
         c = _C.VloConfig()
@@ -43,6 +47,9 @@ class EngineConfig:
         c.pool_h, c.pool_w = self.frame_token_pooled
         c.kv_pool_tokens = self.kv_pool_tokens
         c.tp_rank, c.tp_size = self.tp_rank, self.tp_size
+        if self.weight_dtype not in ("bf16", "fp8"):
+            raise ValueError("weight_dtype must be 'bf16' or 'fp8'")
+        c.weight_dtype = 1 if self.weight_dtype == "fp8" else 0
         if self.vit:
             v = self.vit
             c.has_vit = 1
@@ -130,12 +137,26 @@ class Engine:
         self._sessions = weakref.WeakSet()      # sessions borrow the engine's KV pool: closed before the engine is
 
     # ---- weights -------------------------------------------------------------------------
+    _STREAMED = ("q_proj.weight", "k_proj.weight", "v_proj.weight", "o_proj.weight", "gate_proj.weight", "up_proj.weight",
+                 "down_proj.weight")
+
     def load_weight(self, name: str, t: torch.Tensor):
         t = t.detach().contiguous()
-        if t.dtype not in _DT:
+        streamed = (name.startswith("model.layers.") and name.endswith(self._STREAMED)) or name == "lm_head.weight"
+        if self.cfg.weight_dtype == "fp8" and streamed and t.dtype != torch.float8_e4m3fn:
+            from .checkpoint import quantize_fp8_per_channel
+            q, scale = quantize_fp8_per_channel(t.to(self.device))
+            self.load_weight(name, q)
+            self.load_weight(name + "_scale", scale)
+            return
+        if t.dtype == torch.float8_e4m3fn:
+            dt, t = _C.DT_FP8_E4M3, t.view(torch.uint8)
+        elif t.dtype in _DT:
+            dt = _DT[t.dtype]
+        else:
             raise TypeError(f"{name}: unsupported dtype {t.dtype}")
         shape = (C.c_int64 * t.dim())(*t.shape)
-        _C.check(_C.lib().vlo_engine_load_weight(self._h, name.encode(), _ptr(t), _DT[t.dtype], shape, t.dim()))
+        _C.check(_C.lib().vlo_engine_load_weight(self._h, name.encode(), _ptr(t), dt, shape, t.dim()))
 
     def load_weights(self, weights: dict):
         for k, v in weights.items():
@@ -330,6 +351,14 @@ def test_gemv(x: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def test_gemv_fp8(x: torch.Tensor, Wq: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """y[n,N] f32 = (x[n,K] @ Wq[N,K]^T) * scale[N] through the fp8 e4m3 weight image (unit tests)."""
+    x, Wq, scale = x.contiguous(), Wq.contiguous().view(torch.uint8), scale.float().contiguous()
+    y = torch.empty(x.shape[0], Wq.shape[0], dtype=torch.float32, device=x.device)
+    _C.check(_C.lib().vlo_test_gemv_fp8(_ptr(x), _ptr(Wq), _ptr(scale), _ptr(y), x.shape[0], Wq.shape[0], Wq.shape[1], _stream_handle()))
+    return y
+
+
 class TpSession:
     """KV handle of a tensor-parallel group: one KV shard (this rank's kv heads) per local rank."""
 
@@ -415,6 +444,14 @@ class TpGroup:
         return buf.raw
 
     def load_weight(self, name: str, t: torch.Tensor):
+        e0 = self.engines[0]
+        streamed = (name.startswith("model.layers.") and name.endswith(e0._STREAMED)) or name == "lm_head.weight"
+        if self.cfg.weight_dtype == "fp8" and streamed and t.dtype != torch.float8_e4m3fn:
+            from .checkpoint import quantize_fp8_per_channel      # once for all local ranks (scales are per FULL output row)
+            q, scale = quantize_fp8_per_channel(t.to(self.device))
+            self.load_weight(name, q)
+            self.load_weight(name + "_scale", scale)
+            return
         for i, e in enumerate(self.engines):
             if name.startswith("vision.") and i > 0:
                 continue                      # the vision tower lives on the first local engine only
