@@ -182,8 +182,9 @@ def run_tp_leg(args, rank, world, local, allreduce="rccl", port_offset=17):
     if child.returncode != 0 or line is None:
         return {"error": f"child exit code {child.returncode}", "stderr_tail": (se or "")[-400:]}
     d = json.loads(line)
-    keep = ("value", "unit", "ms_per_step", "p50_frame_latency_ms", "p95_frame_latency_ms", "steps", "scaling")
+    keep = ("value", "unit", "ms_per_step", "p50_frame_latency_ms", "p95_frame_latency_ms", "steps", "scaling", "full_stream")
     r = {k: d.get(k) for k in keep}
+    r["rccl_comm"] = d["config"].get("rccl_comm")
     how = ("RCCL all-reduce x2 per layer + logits all-gather" if allreduce == "rccl" else
            "one-shot peer-to-peer all-reduce over xGMI fused with residual add + RMSNorm, x2 per layer, + p2p logits gather; no RCCL")
     r.update(parallelism=d["config"]["parallelism"], stream_hbm_roofline=d.get("stream_hbm_roofline"), wall_s=round(time.time() - t0, 1),
@@ -409,7 +410,10 @@ def main():
                        "frames": K, "stream_frames": total, "preroll_frames": preroll, "kv_tokens_at_start": kv_start,
                        "final_kv_tokens": final_len, "llm_steps": llm_steps, "prefetch_encode": not args.no_prefetch, "prefetch_frames": args.prefetch_frames,
                        "parallelism": f"tp{world}" if tp else f"replicas{world}",
+                       **({"rccl_comm": eng.comm_info()} if tp else {}),
                        **({"tp_exchange": dict(kind=args.tp_allreduce, us_per_exchange=tp_exchange_us,
+                                                message="fp32 [n, H] partial sums (180 KB at n = 11, 16 KB at n = 1): summed in fp32 as inside one GEMM, "
+                                                        "the exchange is latency-bound at this size",
                                                 **(eng.p2p_status() if args.tp_allreduce == "p2p" else {}))} if tp else {})},
             "encode_stage": {"batch": max(1, args.prefetch_frames), "ms_per_frame": round(vit_ms, 4),
                              "tflops": round(VIT_GFLOP_PER_FRAME / vit_ms, 1), "mfma_peak_tflops": MFMA_PEAK_TFLOPS,
@@ -433,6 +437,18 @@ def main():
             dist.barrier()                     # every rank's first child is gone before the second leg claims the GPUs
         tp_p2p_leg = run_tp_leg(args, rank, world, local, "p2p", 29)
     if rank == 0:
+        # north_star's multi-GPU number is ONE stream tensor-parallel over the N GPUs.  Next to the replica `value` (N independent
+        # streams, trivially ~N x), each TP leg carries the strong-scaling figures against the one-GPU single-stream rate measured
+        # in THIS run (the replica line / N): SURVEY.md §8e definition (1), end-to-end.  Definitions (2) all-reduce bus efficiency
+        # and (3) latency vs the measured exchange floor are what `exchange.us_per_exchange` (64 exchanges per step) is for.
+        for leg in (tp_leg, tp_p2p_leg):
+            if leg and leg.get("value"):
+                one = out["value"] / world
+                leg["one_gpu_stream_frames_per_s"] = round(one, 3)
+                leg["speedup_vs_one_gpu_stream"] = round(leg["value"] / one, 4)
+                leg["scaling_efficiency"] = round(leg["value"] / one / world, 4)
+                leg["efficiency_definition"] = ("end-to-end strong scaling of ONE stream: frames/s on N GPUs / (N x frames/s of one stream on "
+                                                "one GPU, same run); the >= 0.85 target of BASELINE.json is read as this number")
         if tp_leg is not None:
             out["tp"] = tp_leg
         if tp_p2p_leg is not None:

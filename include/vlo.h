@@ -244,6 +244,9 @@ int  vlo_tp_p2p_status(vlo_tp_group *g, int *enabled, int *timed_out, int *uncac
  * decoder layer issues twice), `iters` back to back on `stream`, average microseconds; RCCL or peer-to-peer, whichever the group
  * uses.  Every rank of the group makes the same call.  The session's residual stream is scratch afterwards (reset it). */
 int  vlo_tp_bench_exchange(vlo_tp_session *t, int m, int iters, double *avg_us, void *stream);
+/* what RCCL reports for the group's communicator (ncclCommCount / ncclCommUserRank): 0 / -1 when the group has none (logical
+ * ranks, peer-to-peer exchange).  The RCCL library is dlopen'ed; VLO_RCCL_LIBRARY names a specific build. */
+int  vlo_tp_comm_info(vlo_tp_group *g, int *nranks, int *rank);
 /* host-side mailbox geometry of the exchange above (no GPU needed; unit tests): for a group of T ranks, hidden size H,
  * vocabulary shard Vl, the seq-th exchange of a region (seq counts from 0 per region) and the tag `epoch` of the previous
  * exchange, out6 = {first granule of the reduce slot, granules between two sources of a reduce slot, first granule of the

@@ -69,5 +69,20 @@ def build(force=False, sanitize=None):
     return lib
 
 
+def build_rccl_shim():
+    """tests/hip_emul/rccl_shim.cpp -> _build/librccl_shim.so: the shared-memory stand-in for librccl (VLO_RCCL_LIBRARY)."""
+    cc = clang() or shutil.which("g++")
+    if cc is None:
+        return None
+    os.makedirs(os.path.join(HERE, "_build"), exist_ok=True)
+    src, lib = os.path.join(HERE, "rccl_shim.cpp"), os.path.join(HERE, "_build", "librccl_shim.so")
+    if not os.path.exists(lib) or os.path.getmtime(src) > os.path.getmtime(lib):
+        r = subprocess.run([cc, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", src, "-lrt", "-o", lib],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"rccl shim build failed:\n{r.stdout[-3000:]}")
+    return lib
+
+
 if __name__ == "__main__":
     print(build(force=True))

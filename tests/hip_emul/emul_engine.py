@@ -237,6 +237,44 @@ class EmulTpGroup:
             e.close()
 
 
+class EmulTpRankRccl:
+    """ONE rank of a one-process-per-GPU group exchanging through the RCCL entry points (include/vlo.h: n_local = 1 and a
+    unique id), which VLO_RCCL_LIBRARY points at the shared-memory stand-in tests/hip_emul/rccl_shim.cpp."""
+
+    def __init__(self, spec, T, rank, weights, inv_freq, unique_id, kv_pool_tokens=1024):
+        self.spec, self.T, self.rank = spec, T, rank
+        self.engine = EmulEngine(spec, kv_pool_tokens, rank, T).load_weights(weights, inv_freq)
+        arr = (C.c_void_p * 1)(self.engine._h)
+        g = C.c_void_p()
+        check(lib().vlo_tp_group_create(arr, 1, C.create_string_buffer(unique_id, 128), C.byref(g)))
+        self._g = g
+        h = C.c_void_p()
+        check(lib().vlo_tp_session_create(g, 0, C.byref(h)))
+        self._s = h
+
+    def comm_info(self):
+        n, r = C.c_int(0), C.c_int(-1)
+        check(lib().vlo_tp_comm_info(self._g, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
+    def llm_step(self, embeds, want_all=True):
+        return EmulTpGroup.llm_step(self, self._s, embeds, want_all)
+
+    def bench_exchange(self, m, iters):
+        return EmulTpGroup.bench_exchange(self, self._s, m, iters)
+
+    def close(self):
+        lib().vlo_tp_session_destroy(self._s)
+        lib().vlo_tp_group_destroy(self._g)
+        self.engine.close()
+
+
+def unique_id():
+    buf = C.create_string_buffer(128)
+    check(lib().vlo_tp_unique_id(buf))
+    return buf.raw
+
+
 class EmulTpRank:
     """ONE rank of a one-process-per-GPU group (include/vlo.h: n_local = 1) with the peer-to-peer exchange and no RCCL.
     ``exchange`` takes this rank's 64-byte mailbox handle and returns every rank's, in rank order."""

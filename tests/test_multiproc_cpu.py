@@ -96,3 +96,74 @@ def test_bench_tp_leg_child_failure_is_recorded_not_fatal():
             else:
                 os.environ[k] = v
     assert isinstance(r, dict) and "error" in r and "value" not in r
+
+
+def _tp_rccl_worker(rank, world, port, q):
+    """bench.py --tp's bootstrap and data path, one process per rank, on the CPU: the engine's SOURCES compiled for the host
+    (tests/hip_emul), the RCCL entry points served by the shared-memory stand-in, gloo for the unique-id broadcast."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from tests.hip_emul import build_emul
+    os.environ["VLO_RCCL_LIBRARY"] = build_emul.build_rccl_shim()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import vlo_oracle as O
+    from tests.hip_emul import emul_engine as E
+    spec = O.LlmSpec(128, 192, 2, 2, 2, 256, 10000.0, 1e-5, vision_hidden_size=128)
+    w = O.init_llm_weights(spec, seed=6)
+    toks = O.default_tokens(spec)
+    ref = O.LlamaOracle(spec, w, torch.bfloat16)
+    uid = [E.unique_id() if rank == 0 else None]            # rank 0's ncclGetUniqueId, broadcast by the host (bench.py --tp)
+    dist.broadcast_object_list(uid, src=0)
+    r = E.EmulTpRankRccl(spec, world, rank, w, O.rope_inv_freq(spec.head_dim, spec.rope_theta), bytes(uid[0]))
+    g = torch.Generator().manual_seed(3)
+    steps = [torch.cat([ref.embed(torch.tensor(toks.start_ids)), torch.randn(10, spec.hidden_size, generator=g).bfloat16()]),
+             torch.cat([ref.embed(torch.tensor([toks.interval_id])), torch.randn(10, spec.hidden_size, generator=g).bfloat16()]),
+             ref.embed(torch.tensor([17]))]
+    outs = [r.llm_step(x)[1].float().numpy() for x in steps]
+    us = r.bench_exchange(3, 2)
+    q.put((rank, outs, r.comm_info(), us))
+    dist.barrier()
+    r.close()
+    dist.destroy_process_group()
+
+
+def test_tp_data_path_two_processes_rccl_standin():
+    """The one-process-per-rank tensor-parallel data path — communicator from a broadcast unique id, 2 all-reduces per layer of
+    the fp32 partial sums, all-gather of the logits shards — across TWO processes, against the oracle (VERDICT r1 item 6:
+    the multi-process test covered only the timing reduction and the unique-id broadcast)."""
+    import numpy as np
+    from oracle import vlo_oracle as O
+    from tests.hip_emul import build_emul
+    if build_emul.clang() is None:
+        import pytest
+        pytest.skip("no host clang for the CPU emulation")
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_tp_rccl_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = {}
+    for _ in range(world):
+        rank, outs, info, us = q.get(timeout=900)
+        res[rank] = (outs, info, us)
+    [p.join(120) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    assert res[0][1] == (2, 0) and res[1][1] == (2, 1)                       # what the communicator itself reports
+    spec = O.LlmSpec(128, 192, 2, 2, 2, 256, 10000.0, 1e-5, vision_hidden_size=128)
+    w = O.init_llm_weights(spec, seed=6)
+    toks = O.default_tokens(spec)
+    ref, gold = O.LlamaOracle(spec, w, torch.bfloat16), O.LlamaOracle(spec, w, torch.float32)
+    g = torch.Generator().manual_seed(3)
+    steps = [torch.cat([ref.embed(torch.tensor(toks.start_ids)), torch.randn(10, spec.hidden_size, generator=g).bfloat16()]),
+             torch.cat([ref.embed(torch.tensor([toks.interval_id])), torch.randn(10, spec.hidden_size, generator=g).bfloat16()]),
+             ref.embed(torch.tensor([17]))]
+    rc = gc = None
+    for i, x in enumerate(steps):
+        rl, rc = ref.forward(x, rc)
+        gl, gc = gold.forward(x, gc)
+        a, b = res[0][0][i], res[1][0][i]
+        assert np.array_equal(a, b), f"step {i}: the two ranks hold different logits"
+        e = np.abs(a - gl.numpy()).max()
+        r = (rl.float() - gl).abs().max().item()
+        assert e <= 1.5 * r + 1e-3 * gl.abs().max().item(), f"step {i}: engine err {e} vs reference-bf16 err {r}"
+    assert res[0][2] >= 0.0 and res[1][2] >= 0.0

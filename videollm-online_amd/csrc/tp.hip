@@ -47,6 +47,8 @@ typedef int (*fn_ncclCommInitRank)(void **, int, NcclUid, int);
 typedef int (*fn_ncclAllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
 typedef int (*fn_ncclAllGather)(const void *, void *, size_t, int, void *, hipStream_t);
 typedef int (*fn_ncclCommDestroy)(void *);
+typedef int (*fn_ncclCommCount)(void *, int *);
+typedef int (*fn_ncclCommUserRank)(void *, int *);
 typedef const char *(*fn_ncclGetErrorString)(int);
 enum { kNcclInt8 = 0, kNcclFloat32 = 7, kNcclSum = 0 };
 
@@ -57,6 +59,8 @@ struct Rccl {
     fn_ncclAllReduce AllReduce = nullptr;
     fn_ncclAllGather AllGather = nullptr;
     fn_ncclCommDestroy CommDestroy = nullptr;
+    fn_ncclCommCount CommCount = nullptr;
+    fn_ncclCommUserRank CommUserRank = nullptr;
     fn_ncclGetErrorString GetErrorString = nullptr;
 };
 static Rccl g_rccl;
@@ -69,10 +73,15 @@ static std::string rccl_err(const char *what, int code) {
 
 static int rccl_load() {
     if (g_rccl.dl) return VLO_OK;
-    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // VLO_RCCL_LIBRARY: a specific RCCL build — or, in the CPU test of the one-process-per-rank data path, a stand-in that
+    // implements the same seven entry points over shared memory (tests/hip_emul/rccl_shim.cpp)
+    const char *names[] = {getenv("VLO_RCCL_LIBRARY"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void *dl = nullptr;
-    for (const char *n : names)
-        if ((dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    for (const char *n : names) {
+        if (!n || !*n) continue;
+        dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (dl) break;
+    }
     if (!dl) return vlo_fail(VLO_E_UNSUPPORTED, std::string("cannot dlopen librccl: ") + dlerror());
     g_rccl.GetUniqueId = (fn_ncclGetUniqueId)dlsym(dl, "ncclGetUniqueId");
     g_rccl.CommInitRank = (fn_ncclCommInitRank)dlsym(dl, "ncclCommInitRank");
@@ -80,6 +89,8 @@ static int rccl_load() {
     g_rccl.AllGather = (fn_ncclAllGather)dlsym(dl, "ncclAllGather");
     g_rccl.CommDestroy = (fn_ncclCommDestroy)dlsym(dl, "ncclCommDestroy");
     g_rccl.GetErrorString = (fn_ncclGetErrorString)dlsym(dl, "ncclGetErrorString");
+    g_rccl.CommCount = (fn_ncclCommCount)dlsym(dl, "ncclCommCount");
+    g_rccl.CommUserRank = (fn_ncclCommUserRank)dlsym(dl, "ncclCommUserRank");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather || !g_rccl.CommDestroy)
         return vlo_fail(VLO_E_UNSUPPORTED, "librccl lacks an expected symbol");
     g_rccl.dl = dl;
@@ -217,6 +228,17 @@ int vlo_tp_group_create(vlo_engine **engines, int n_local, const void *rccl_uniq
         }
     }
     *out = g;
+    return VLO_OK;
+}
+
+int vlo_tp_comm_info(vlo_tp_group *g, int *nranks, int *rank) {
+    if (!g) return vlo_fail(VLO_E_INVALID, "null group");
+    int n = 0, r = -1;
+    if (g->comm && g_rccl.CommCount && g_rccl.CommUserRank) {      // what RCCL itself reports for the communicator
+        if (g_rccl.CommCount(g->comm, &n) != 0 || g_rccl.CommUserRank(g->comm, &r) != 0) return vlo_fail(VLO_E_HIP, "ncclCommCount / ncclCommUserRank failed");
+    }
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
     return VLO_OK;
 }
 

@@ -51,24 +51,37 @@ VLO_DEV float rh(float x) { return h2f(f2h(x)); }     // fp16 rounding point
 // no ds_write pass); the destination of a wave instruction is linear (base + lane*16 B), so the XOR swizzle of the
 // 16-byte chunks is applied to the per-lane SOURCE address — it permutes chunks inside one 128-B row segment, i.e.
 // coalescing is unchanged — and again on the fragment reads (cdna guide rule 21).  Two LDS buffers, one barrier per K tile.
-template <int BM, int BN, int WM, int WN, int EP, int DEPTH>
+template <int BM, int BN, int WM, int WN, int EP, int DEPTH, int STAGES = 2>
 __global__ __launch_bounds__(WM * WN * 64) void vit_gemm_kernel(GemmArgs a) {
     constexpr int NTHR = WM * WN * 64;
     constexpr bool GLDS = (DEPTH == 0);
     constexpr int RING = GLDS ? 1 : DEPTH;
     constexpr int MI = BM / (WM * 16), NI = BN / (WN * 16);    // 16x16 MFMA tiles per wave along m / n (WM x WN waves)
     // ONE shared object (a second one makes hipcc drain the direct-to-LDS queue before every k-step, cdna guide §5 trap 4a):
-    // NBUF stages of [X tile | W tile].  Direct-to-LDS path: 4 stages = 3 K tiles in flight per block — with ~1 block per
-    // CU (M = 576 B rows give 288..1152 tiles) nothing else hides the L2 -> LDS latency (2 stages measured 1.4 us per K tile
-    // against 0.2 us of MFMA work: 15 % matrix-core utilisation).
-    constexpr int NBUF = GLDS ? 4 : 2;
+    // NBUF stages of [X tile | W tile].  Direct-to-LDS path: STAGES - 1 K tiles in flight per block (2 stages = 64 KiB, two
+    // blocks per CU; 4 stages = 128 KiB, one block per CU with three tiles in flight).
+    constexpr int NBUF = GLDS ? STAGES : 2;
     constexpr int STAGE = (BM + BN) * GEMM_BK;
     __shared__ __attribute__((aligned(16))) f16_t smem[NBUF * STAGE];
 #define sX(buf) (smem + (buf) * STAGE)
 #define sW(buf) (smem + (buf) * STAGE + BM * GEMM_BK)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w / WN, wn = w % WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order.  Workgroups are handed to the 8 XCDs round-robin in dispatch order (x fastest), each XCD has its
+    // own 4 MiB L2.  With the plain (x, y) -> tile map and a grid whose width is a multiple of 8, XCD i computes column tiles
+    // i, i+8, ... of EVERY row: all eight L2s stream the whole activation matrix (fc2 at 8 frames: 8 x 37.7 MB from the
+    // memory side for 38.6 GFLOP).  Instead XCD i takes a CONTIGUOUS run of the row-major tile list (a band of rows x all
+    // columns): its concurrent blocks share a few activation row-tiles and the weight matrix, K slice by K slice, out of one L2.
+    int tile_x = blockIdx.x, tile_y = blockIdx.y;
+    {
+        const int ntx = gridDim.x, nt = gridDim.x * gridDim.y;
+        const int L = blockIdx.y * ntx + blockIdx.x, xcd = L & 7, j = L >> 3;
+        const int q = nt >> 3, r = nt & 7;                      // XCD x owns q + (x < r) tiles (bijective for any nt)
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        tile_y = t / ntx;
+        tile_x = t - tile_y * ntx;
+    }
+    const int m0 = tile_y * BM, n0 = tile_x * BN;
     const int r16 = lane & 15, qd = lane >> 4;
     constexpr int XCH = BM * 8 / NTHR, WCH = BN * 8 / NTHR;   // 16-byte chunks per thread per tile
     // DEPTH = K tiles in flight (register ring)
@@ -308,8 +321,13 @@ static hipError_t gemm_launch(GemmArgs a, hipStream_t st) {
         // half the L2->LDS bytes per FLOP of the 64x64 kernel, which is L2-bandwidth-bound (~450 TFLOP/s ceiling)
         dim3 grid(a.N / 128, (a.M + 127) / 128, 1);
         static const bool use_glds = getenv("VLO_VIT_GLDS") ? atoi(getenv("VLO_VIT_GLDS")) != 0 : true;
-        if (use_glds && EP != EP_PATCH)
-            hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 4, EP, 0>), grid, dim3(512), 0, st, a);
+        static const int stages = getenv("VLO_VIT_STAGES") ? atoi(getenv("VLO_VIT_STAGES")) : 2;
+        if (use_glds && EP != EP_PATCH && stages >= 4)
+            hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 4, EP, 0, 4>), grid, dim3(512), 0, st, a);
+        else if (use_glds && EP != EP_PATCH && stages == 3)
+            hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 4, EP, 0, 3>), grid, dim3(512), 0, st, a);
+        else if (use_glds && EP != EP_PATCH)
+            hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 4, EP, 0, 2>), grid, dim3(512), 0, st, a);
         else
             hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 4, EP, 2>), grid, dim3(512), 0, st, a);
     } else {
@@ -322,39 +340,52 @@ static hipError_t gemm_launch(GemmArgs a, hipStream_t st) {
 // ------------------------------------------------------------------------------------
 // LayerNorm (fp32 in, fp32 stats) -> fp16 (matmul operand) and optionally fp32
 // ------------------------------------------------------------------------------------
+// one WAVE per token row (4 rows per block): the row lives in registers (D / 64 floats per lane, coalesced float4 loads), mean and
+// variance are two wave reductions — no LDS, no block barrier; D <= 2048, D % 4 == 0
+#define LN_MAXC 8
 __global__ __launch_bounds__(256) void vit_layernorm_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                             const float *__restrict__ b, f16_t *__restrict__ out16,
-                                                            float *__restrict__ out32, int D, float eps) {
-    __shared__ float sm[16];
-    const float *xr = x + (size_t)blockIdx.x * D;
-    float v[8];
-    int cnt = 0;
+                                                            float *__restrict__ out32, int M, int D, float eps) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float *xr = x + (size_t)row * D;
+    float4 v[LN_MAXC];
     float s = 0.f;
-    for (int i = threadIdx.x * 4; i < D; i += 1024, ++cnt) {
-        const float4 t = *reinterpret_cast<const float4 *>(xr + i);
-        v[cnt * 4] = t.x; v[cnt * 4 + 1] = t.y; v[cnt * 4 + 2] = t.z; v[cnt * 4 + 3] = t.w;
-        s += t.x + t.y + t.z + t.w;
-    }
-    const float mean = block_sum(s, sm) / (float)D;
-    float q = 0.f;
-    for (int c = 0; c < cnt * 4; ++c) {
-        const float d = v[c] - mean;
-        q += d * d;
-    }
-    const float var = block_sum(q, sm) / (float)D;
-    const float rs = 1.0f / sqrtf(var + eps);
-    cnt = 0;
-    for (int i = threadIdx.x * 4; i < D; i += 1024, ++cnt) {
-        const float4 wv = *reinterpret_cast<const float4 *>(w + i);
-        const float4 bv = *reinterpret_cast<const float4 *>(b + i);
-        const float o0 = (v[cnt * 4] - mean) * rs * wv.x + bv.x, o1 = (v[cnt * 4 + 1] - mean) * rs * wv.y + bv.y;
-        const float o2 = (v[cnt * 4 + 2] - mean) * rs * wv.z + bv.z, o3 = (v[cnt * 4 + 3] - mean) * rs * wv.w + bv.w;
-        if (out16) {
-            ushort4 o;
-            o.x = f2h(o0); o.y = f2h(o1); o.z = f2h(o2); o.w = f2h(o3);
-            *reinterpret_cast<ushort4 *>(out16 + (size_t)blockIdx.x * D + i) = o;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int i = (c * 64 + lane) * 4;
+        v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < D) {
+            v[c] = *reinterpret_cast<const float4 *>(xr + i);
+            s += v[c].x + v[c].y + v[c].z + v[c].w;
         }
-        if (out32) *reinterpret_cast<float4 *>(out32 + (size_t)blockIdx.x * D + i) = make_float4(o0, o1, o2, o3);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int i = (c * 64 + lane) * 4;
+        if (i < D) {
+            const float d0 = v[c].x - mean, d1 = v[c].y - mean, d2 = v[c].z - mean, d3 = v[c].w - mean;
+            q += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
+    }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int i = (c * 64 + lane) * 4;
+        if (i < D) {
+            const float4 wv = *reinterpret_cast<const float4 *>(w + i);
+            const float4 bv = *reinterpret_cast<const float4 *>(b + i);
+            const float o0 = (v[c].x - mean) * rs * wv.x + bv.x, o1 = (v[c].y - mean) * rs * wv.y + bv.y;
+            const float o2 = (v[c].z - mean) * rs * wv.z + bv.z, o3 = (v[c].w - mean) * rs * wv.w + bv.w;
+            if (out16) {
+                ushort4 o;
+                o.x = f2h(o0); o.y = f2h(o1); o.z = f2h(o2); o.w = f2h(o3);
+                *reinterpret_cast<ushort4 *>(out16 + (size_t)row * D + i) = o;
+            }
+            if (out32) *reinterpret_cast<float4 *>(out32 + (size_t)row * D + i) = make_float4(o0, o1, o2, o3);
+        }
     }
 }
 
@@ -368,7 +399,7 @@ __global__ __launch_bounds__(256) void vit_layernorm_kernel(const float *__restr
 //   O^T[d][q]  += V^T[d][key].P^T[key][q]   (V^T rows = A operand; P^T stays in the producing lanes)
 // ------------------------------------------------------------------------------------
 template <int HD>
-__global__ __launch_bounds__(256) void vit_attn_kernel(const f16_t *__restrict__ qk, const f16_t *__restrict__ vT,
+__global__ __launch_bounds__(256, 2) void vit_attn_kernel(const f16_t *__restrict__ qk, const f16_t *__restrict__ vT,
                                                        f16_t *__restrict__ out, int S, int D, int nheads, float scale) {
     constexpr int NKK = HD / 32, NDT = HD / 16, QS = 4;
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];     // [4 waves][QS][NDT][64] O partials, then m/l
@@ -402,24 +433,30 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const f16_t *__restrict__
         for (int dt = 0; dt < NDT; ++dt) O[qs][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-    for (int kt0 = w * 32; kt0 < S; kt0 += 128) {
-        frag_ab kf[2][NKK];
+    // K / V^T fragments of the NEXT 32-key block are fetched while the current block's MFMAs and softmax run (register double
+    // buffer): with one wave per SIMD and two blocks per CU nothing else covers the L2 latency of these 64-byte-per-row gathers
+    auto load_kv = [&](int kt, frag_ab (&kf_)[2][NKK], frag_ab (&vf_)[NDT]) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int key = min(kt0 + t * 16 + qrow, S - 1);
+            const int key = min(kt + t * 16 + qrow, S - 1);
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk)
-                kf[t][kk] = *reinterpret_cast<const frag_ab *>(kbase + (size_t)key * ld + kk * 32 + qd * 8);
+                kf_[t][kk] = *reinterpret_cast<const frag_ab *>(kbase + (size_t)key * ld + kk * 32 + qd * 8);
         }
-        frag_ab vf[NDT];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
-            const f16_t *vr = vbase + (size_t)(dt * 16 + qrow) * S + kt0 + qd * 4;
+            const f16_t *vr = vbase + (size_t)(dt * 16 + qrow) * S + kt + qd * 4;
             uint2 lo = make_uint2(0, 0), hi = make_uint2(0, 0);
-            if (kt0 + qd * 4 < S) lo = *reinterpret_cast<const uint2 *>(vr);
-            if (kt0 + 16 + qd * 4 < S) hi = *reinterpret_cast<const uint2 *>(vr + 16);
-            vf[dt] = __builtin_bit_cast(frag_ab, make_uint4(lo.x, lo.y, hi.x, hi.y));
+            if (kt + qd * 4 < S) lo = *reinterpret_cast<const uint2 *>(vr);
+            if (kt + 16 + qd * 4 < S) hi = *reinterpret_cast<const uint2 *>(vr + 16);
+            vf_[dt] = __builtin_bit_cast(frag_ab, make_uint4(lo.x, lo.y, hi.x, hi.y));
         }
+    };
+    frag_ab kf[2][NKK], vf[NDT], kn[2][NKK], vn[NDT];
+    if (w * 32 < S) load_kv(w * 32, kf, vf);
+    for (int kt0 = w * 32; kt0 < S; kt0 += 128) {
+        const bool more = kt0 + 128 < S;
+        if (more) load_kv(kt0 + 128, kn, vn);
         const int kb = kt0 + qd * 4;
 #pragma unroll
         for (int qs = 0; qs < QS; ++qs) {
@@ -458,6 +495,14 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const f16_t *__restrict__
                 o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
                 O[qs][dt] = mfma_f16(vf[dt], pb, o);
             }
+        }
+        if (more) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) kf[t][kk] = kn[t][kk];
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) vf[dt] = vn[dt];
         }
     }
     // publish this wave's partial state
@@ -654,7 +699,7 @@ int vit_finalize(vlo_engine *e) {
     v->hd = v->D / v->nh; v->R = c.vit_image_size; v->P = c.vit_patch_size; v->G = v->R / v->P; v->S = v->G * v->G;
     v->ph = c.pool_h; v->pw = c.pool_w; v->eps = c.vit_ln_eps;
     const int D = v->D, I = v->I;
-    if (v->hd != 64 || (D % 64) || (I % 64) || ((3 * v->P * v->P) % 64) || (v->P % 8) || c.vision_hidden_size != D ||
+    if (v->hd != 64 || (D % 64) || D > 2048 || (I % 64) || ((3 * v->P * v->P) % 64) || (v->P % 8) || c.vision_hidden_size != D ||
         c.frame_num_tokens != 1 + v->ph * v->pw || (v->S % 4))
         { delete v; return vlo_fail(VLO_E_UNSUPPORTED, "vision tower shape not covered by the kernels (need head_dim 64, dims % 64 == 0)"); }
     int rc;
@@ -781,7 +826,7 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
     }
     for (int l = 0; l < v->L; ++l) {
         const VitLayer &Ly = v->layers[l];
-        hipLaunchKernelGGL(vit_layernorm_kernel, dim3(M), dim3(256), 0, st, v->h, Ly.ln1_w, Ly.ln1_b, v->x16, (float *)nullptr, D, v->eps);
+        hipLaunchKernelGGL(vit_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, v->h, Ly.ln1_w, Ly.ln1_b, v->x16, (float *)nullptr, M, D, v->eps);
         {
             GemmArgs a{};
             a.X = v->x16; a.W = Ly.wqkv; a.bias = Ly.bqkv; a.out16 = v->qk16; a.outVT = v->vT;
@@ -795,7 +840,7 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
             a.M = M; a.N = D; a.K = D; a.ldx = D;
             VIT_TRY(gemm_launch<EP_RESID>(a, st));
         }
-        hipLaunchKernelGGL(vit_layernorm_kernel, dim3(M), dim3(256), 0, st, v->h, Ly.ln2_w, Ly.ln2_b, v->x16, (float *)nullptr, D, v->eps);
+        hipLaunchKernelGGL(vit_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, v->h, Ly.ln2_w, Ly.ln2_b, v->x16, (float *)nullptr, M, D, v->eps);
         {
             GemmArgs a{};
             a.X = v->x16; a.W = Ly.w1; a.bias = Ly.b1; a.out16 = v->mid16;
@@ -810,7 +855,7 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
         }
     }
     // post layernorm: fp32 (pooling input) + fp16 (head K/V operand)
-    hipLaunchKernelGGL(vit_layernorm_kernel, dim3(M), dim3(256), 0, st, v->h, v->post_w, v->post_b, v->x16, v->last, D, v->eps);
+    hipLaunchKernelGGL(vit_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, v->h, v->post_w, v->post_b, v->x16, v->last, M, D, v->eps);
     {   // MAP head: K,V = last @ Wkv^T + bkv
         GemmArgs a{};
         a.X = v->x16; a.W = v->in_proj_w + (size_t)D * D; a.bias = v->in_proj_b + D; a.out16 = v->kv16;
@@ -825,7 +870,7 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
         VIT_TRY(gemm_launch<EP_F16>(a, st));
     }
     hipLaunchKernelGGL(f16_to_f32_kernel, dim3((B * D + 255) / 256), dim3(256), 0, st, v->ho16, v->tmp32, B * D);
-    hipLaunchKernelGGL(vit_layernorm_kernel, dim3(B), dim3(256), 0, st, v->tmp32, v->hln_w, v->hln_b, v->hx16, (float *)nullptr, D, v->eps);
+    hipLaunchKernelGGL(vit_layernorm_kernel, dim3((B + 3) / 4), dim3(256), 0, st, v->tmp32, v->hln_w, v->hln_b, v->hx16, (float *)nullptr, B, D, v->eps);
     {
         GemmArgs a{};
         a.X = v->hx16; a.W = v->hfc1_w; a.bias = v->hfc1_b; a.out16 = v->hmid16;

@@ -481,6 +481,12 @@ class TpGroup:
                 _C.check(_C.lib().vlo_tp_p2p_enable(g, C.create_string_buffer(b"".join(handles), 64 * self.tp_size)))
         return self
 
+    def comm_info(self) -> dict:
+        """{nranks, rank} as RCCL reports them for the group's communicator (0 / -1 without one)."""
+        n, r = C.c_int(0), C.c_int(-1)
+        _C.check(_C.lib().vlo_tp_comm_info(self._g, C.byref(n), C.byref(r)))
+        return dict(nranks=n.value, rank=r.value)
+
     def p2p_status(self) -> dict:
         """{enabled, timed_out, uncached_mailbox} of the peer-to-peer exchange (all 0 when it is not in use)."""
         en, to, uc = C.c_int(0), C.c_int(0), C.c_int(0)
