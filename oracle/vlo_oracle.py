@@ -365,7 +365,7 @@ FP8_STREAMED = ("q_proj.weight", "k_proj.weight", "v_proj.weight", "o_proj.weigh
 
 def fp8_dequantized_weights(weights: dict) -> dict:
     """BASELINE.json configs[4] ("fp8 MFMA weights"): the streamed Llama projections replaced by what an fp8 e4m3 store with one
-    scale per output channel holds — W' = fp8_rne(W / s) * s, s[n] = max|W[n]| / 448 — as fp32 tensors; everything else
+    scale per output channel holds — W' = e4m3_rne(W / s) * s, s[n] = max|W[n]| * (1/448) — as fp32 tensors; everything else
     untouched.  The reference has no fp8 path (config 5 exceeds the reference); the parity target of the fp8
     engine is the reference arithmetic run on these weights: LlamaOracle keeps fp32 weights in fp32 and rounds the Linear's
     OUTPUT to the activation dtype, like a bf16 Linear does."""
@@ -374,8 +374,13 @@ def fp8_dequantized_weights(weights: dict) -> dict:
         if k.endswith(FP8_STREAMED) and not k.startswith(("vision.", "connector.")):
             Wf = v.float()
             amax = Wf.abs().amax(dim=1)
-            s = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
-            out[k] = (Wf / s[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float() * s[:, None]
+            s = torch.where(amax > 0, amax * (1.0 / 448.0), torch.ones_like(amax))
+            x = (Wf / s[:, None]).clamp(-448.0, 448.0)
+            _, ex = torch.frexp(x)                      # e4m3 round-to-nearest-even: 8 steps per binade, 2^-9 below 2^-6
+            step_exp = (ex - 4).clamp_min(-9)
+            q = torch.ldexp(torch.round(torch.ldexp(x, -step_exp)), step_exp).clamp(-448.0, 448.0)
+            assert torch.equal(q, q.to(torch.float8_e4m3fn).float())     # every q is an e4m3 value
+            out[k] = q * s[:, None]
         else:
             out[k] = v
     return out

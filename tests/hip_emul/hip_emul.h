@@ -98,6 +98,18 @@ template <class T> static inline T __shfl_up(T v, unsigned delta, int /*width*/ 
     return emul_shfl_from(v, lane >= (int)delta ? lane - (int)delta : lane);
 }
 template <class T> static inline T __shfl(T v, int src, int /*width*/ = 64) { return emul_shfl_from(v, src & 63); }
+// wave vote: every lane publishes its predicate, every lane ORs the 64 slots
+static inline int __any(int pred) {
+    emul_wave_ctx &W = emul_ctx->waves[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    const int p = pred ? 1 : 0;
+    memcpy(&W.slot[lane], &p, 4);
+    pthread_barrier_wait(&W.bar);
+    int r = 0;
+    for (int i = 0; i < 64; ++i) { int q; memcpy(&q, &W.slot[i], 4); r |= q; }
+    pthread_barrier_wait(&W.bar);
+    return r;
+}
 
 // v_mfma_f32_16x16x32_{bf16,f16}: D[16x16] = A[16x32] . B[32x16] + C, register maps of csrc/common.cuh:
 //   A[m][k]: lane l holds m = l & 15, k = (l >> 4) * 8 + j      B[k][n]: lane l holds n = l & 15, k = (l >> 4) * 8 + j
@@ -127,6 +139,8 @@ static inline V4 emul_mfma_16x16x32(V8 a, V8 b, V4 c) {
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 #define __expf(x) expf(x)                // glibc declares __expf but does not export it
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
+#define __frcp_rn(x) (1.0f / (x))
 static inline long long wall_clock64() {      // s_memrealtime: a 100 MHz counter
     return (long long)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10);
 }

@@ -33,9 +33,11 @@ def test_fp8_gemv_matches_dequantized_matmul(n, N, K):
 
 
 def test_quantizer_on_the_gpu_matches_the_oracle_restatement():
-    """checkpoint.quantize_fp8_per_channel run on the GPU against the oracle's CPU restatement of the same rule (scale = max|row| /
-    448, round-to-nearest-even to e4m3).  The two devices may round a division differently in the last place, which can move a
-    value that sits on a rounding boundary by ONE fp8 step: such cases are counted and bounded, never silently accepted as equal."""
+    """checkpoint.quantize_fp8_per_channel run on the GPU against the oracle's CPU restatement of the same rule (scale = max|row| *
+    (1/448), round-to-nearest-even to e4m3 written out with frexp / ldexp / round — torch's own float -> float8 conversion
+    disagreed between the GPU and the CPU on 6e-4 of the values in the first hardware run).  What may remain: the two devices
+    rounding the division W / scale differently in the last place, which can move a value that sits on a rounding boundary by
+    ONE fp8 step: counted and bounded, never silently accepted as equal."""
     from videollm_online_amd.checkpoint import quantize_fp8_per_channel
     g = torch.Generator().manual_seed(1)
     for N, K in ((4096, 14336), (1024, 8192), (2048, 2048)):

@@ -81,16 +81,26 @@ def _adapter_maps(adapter_dir: str):
 FP8_E4M3_MAX = 448.0
 
 
+def round_to_e4m3(x: torch.Tensor) -> torch.Tensor:
+    """fp32 values in [-448, 448] rounded to the nearest OCP e4m3 value, ties to even, returned as fp32.  Written out with
+    frexp / ldexp / round so that every device rounds alike (the first hardware run showed torch's own float -> float8
+    conversion on the GPU disagreeing with its CPU conversion on ~6e-4 of the values, sub-normals included): a binade
+    [2^e, 2^(e+1)) holds 8 steps of 2^(e-3); below 2^-6 the step is 2^-9."""
+    _, ex = torch.frexp(x)                              # |x| = m * 2^ex, m in [0.5, 1)  ->  e = ex - 1
+    step_exp = (ex - 4).clamp_min(-9)
+    return torch.ldexp(torch.round(torch.ldexp(x, -step_exp)), step_exp).clamp_(-FP8_E4M3_MAX, FP8_E4M3_MAX)
+
+
 def quantize_fp8_per_channel(W: torch.Tensor):
     """Symmetric per-output-channel quantisation of a Linear weight [out, in] to OCP fp8 e4m3 (BASELINE.json configs[4],
-    SURVEY.md §8(f)-1 "fp8 + per-channel scales"): scale[n] = max|W[n]| / 448 (1 for an all-zero row),
-    q[n] = fp8_rne(W[n] / scale[n]).  Returns (q as torch.float8_e4m3fn [out, in], scale f32 [out]); W ~= q * scale[:, None].
+    SURVEY.md §8(f)-1 "fp8 + per-channel scales"): scale[n] = max|W[n]| * (1/448) (1 for an all-zero row),
+    q[n] = e4m3_rne(W[n] / scale[n]).  Returns (q as torch.float8_e4m3fn [out, in], scale f32 [out]); W ~= q * scale[:, None].
     The engine streams q (one byte per weight) and applies scale[n] to the fp32 dot product."""
     Wf = W.float()
     amax = Wf.abs().amax(dim=1)
-    scale = torch.where(amax > 0, amax / FP8_E4M3_MAX, torch.ones_like(amax))
-    q = (Wf / scale[:, None]).clamp_(-FP8_E4M3_MAX, FP8_E4M3_MAX).to(torch.float8_e4m3fn)
-    return q, scale
+    scale = torch.where(amax > 0, amax * (1.0 / FP8_E4M3_MAX), torch.ones_like(amax))
+    q = round_to_e4m3((Wf / scale[:, None]).clamp_(-FP8_E4M3_MAX, FP8_E4M3_MAX))
+    return q.to(torch.float8_e4m3fn), scale                # exact: q already holds e4m3 values
 
 
 def merge_lora(W: torch.Tensor, A: torch.Tensor, B: torch.Tensor, scale: float) -> torch.Tensor:

@@ -88,7 +88,8 @@ struct vlo_session {
     float *partial_o = nullptr;                  // TP: o_proj partial sums [16][H] awaiting the all-reduce
     int64_t *tok = nullptr;
     float *sample_scratch = nullptr;
-    int64_t *host_tok = nullptr;
+    int64_t *host_tok = nullptr;                 // pinned, 8 slots: tokens read back by the greedy loop (double-buffered)
+    hipEvent_t tok_ev[2] = {nullptr, nullptr};   // "token i is on the host" (created on first use)
     int *page_table = nullptr, *host_pt = nullptr;
     // workspaces of the 64-token block path (allocated on first use): residual stream, normed rows, q, attention out, MLP act
     unsigned short *bh = nullptr, *bx = nullptr, *bq = nullptr, *battn = nullptr, *bact = nullptr;

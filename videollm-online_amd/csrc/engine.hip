@@ -475,6 +475,7 @@ void vlo_session_destroy(vlo_session *s) {
     vlo_session_reset(s);
     for (void *p : s->owned) hipFree(p);
     if (s->host_tok) hipHostFree(s->host_tok);
+    for (hipEvent_t ev : s->tok_ev) if (ev) hipEventDestroy(ev);
     if (s->host_pt) hipHostFree(s->host_pt);
     delete s;
 }
@@ -828,19 +829,43 @@ int vlo_greedy_generate(vlo_session *s, const void *embeds_dev, int m, int eos_t
     if (force_len > max_new) force_len = max_new;
     int rc = vlo_llm_step(s, embeds_dev, m, nullptr, nullptr, stream);
     if (rc) return rc;
+    for (hipEvent_t &ev : s->tok_ev)
+        if (!ev) HIP_TRY(hipEventCreate(&ev));
+    const bool forced = force_len > 0;
     int i = 0;
     for (;; ++i) {
         int mode = 0;
-        if (force_len > 0) mode = (i == force_len - 1) ? 2 : 1;
+        if (forced) mode = (i == force_len - 1) ? 2 : 1;
         HIP_TRY(greedy_sample_launch(s->last_logits, V, out_ids_dev + i, eos_token_id, mode, s->sample_scratch, st));
-        // the reference reads the token on the host every step (`if new_token_id == eos_token_id`, :179)
-        HIP_TRY(hipMemcpyAsync(s->host_tok, out_ids_dev + i, 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (*s->host_tok == eos_token_id) break;
-        if (i == max_new - 1) break;
-        HIP_TRY(embed_gather_launch((const unsigned short *)e->embed, out_ids_dev + i, 1, e->cfg.hidden_size, V, s->emb1, st));
-        if ((rc = vlo_llm_step(s, s->emb1, 1, nullptr, nullptr, stream))) return rc;
+        const bool last = (i == max_new - 1) || (forced && i == force_len - 1);
+        if (forced) {
+            // scheduled speech (throughput runs): the token count is known, the host never has to look at a token
+            if (last) break;
+            HIP_TRY(embed_gather_launch((const unsigned short *)e->embed, out_ids_dev + i, 1, e->cfg.hidden_size, V, s->emb1, st));
+            if ((rc = vlo_llm_step(s, s->emb1, 1, nullptr, nullptr, stream))) return rc;
+            continue;
+        }
+        // the reference reads every token on the host (`if new_token_id == eos_token_id`, :179).  Here the read is asynchronous
+        // and the NEXT step is enqueued before the host waits for it, so the GPU never idles across the host round trip; if the
+        // token turns out to be EOS, the speculative step is undone by forgetting its one KV position (nothing reads it again).
+        volatile int64_t *slot = s->host_tok + (i & 1);
+        HIP_TRY(hipMemcpyAsync((void *)slot, out_ids_dev + i, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(s->tok_ev[i & 1], st));
+        if (!last) {
+            HIP_TRY(embed_gather_launch((const unsigned short *)e->embed, out_ids_dev + i, 1, e->cfg.hidden_size, V, s->emb1, st));
+            if ((rc = vlo_llm_step(s, s->emb1, 1, nullptr, nullptr, stream))) return rc;
+        }
+        HIP_TRY(hipEventSynchronize(s->tok_ev[i & 1]));
+        if (*slot == eos_token_id) {
+            if (!last) {
+                s->len -= 1;                 // the EOS token is never fed to the model (:179-181)
+                s->has_logits = false;
+            }
+            break;
+        }
+        if (last) break;
     }
+    HIP_TRY(hipStreamSynchronize(st));        // the ids are read by the caller right away
     if (n_written) *n_written = i + 1;
     return VLO_OK;
 }

@@ -719,18 +719,23 @@ int vlo_tp_greedy_generate(vlo_tp_session *t, const void *embeds_dev, int m, int
     if (force_len > max_new) force_len = max_new;
     int rc = vlo_tp_llm_step(t, embeds_dev, m, nullptr, nullptr, stream);
     if (rc) return rc;
+    const bool forced = force_len > 0;
     int i = 0;
     for (;; ++i) {
         int mode = 0;
-        if (force_len > 0) mode = (i == force_len - 1) ? 2 : 1;
+        if (forced) mode = (i == force_len - 1) ? 2 : 1;
         TP_TRY(greedy_sample_launch(s->last_logits, V, out_ids_dev + i, eos_token_id, mode, s->sample_scratch, st));
-        TP_TRY(hipMemcpyAsync(s->host_tok, out_ids_dev + i, 8, hipMemcpyDeviceToHost, st));
-        TP_TRY(hipStreamSynchronize(st));
-        if (*s->host_tok == eos_token_id) break;
-        if (i == max_new - 1) break;
+        const bool last = (i == max_new - 1) || (forced && i == force_len - 1);
+        if (!forced) {          // every rank reads the same token (the logits are gathered on every rank)
+            TP_TRY(hipMemcpyAsync(s->host_tok, out_ids_dev + i, 8, hipMemcpyDeviceToHost, st));
+            TP_TRY(hipStreamSynchronize(st));
+            if (*s->host_tok == eos_token_id) break;
+        }
+        if (last) break;
         TP_TRY(embed_gather_launch((const unsigned short *)e->embed, out_ids_dev + i, 1, e->cfg.hidden_size, V, s->emb1, st));
         if ((rc = vlo_tp_llm_step(t, s->emb1, 1, nullptr, nullptr, stream))) return rc;
     }
+    TP_TRY(hipStreamSynchronize(st));
     if (n_written) *n_written = i + 1;
     return VLO_OK;
 }

@@ -40,8 +40,11 @@ struct GemmArgs {
 };
 
 VLO_DEV float gelu_tanh_f(float x) {
+    // 0.5 x (1 + tanh(u)) = x / (1 + exp(-2u)), u = k0 (x + k1 x^3): one v_exp_f32 + one v_rcp_f32 instead of libm's tanhf (the
+    // fc1 epilogue evaluates 32 of these per lane); relative error ~1e-6, three orders below the fp16 rounding of the result
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    return 0.5f * x * (1.0f + tanhf(k0 * (x + k1 * x * x * x)));
+    const float u = k0 * (x + k1 * x * x * x);
+    return x * __frcp_rn(1.0f + __expf(-2.0f * u));
 }
 VLO_DEV float rh(float x) { return h2f(f2h(x)); }     // fp16 rounding point
 
@@ -322,7 +325,14 @@ static hipError_t gemm_launch(GemmArgs a, hipStream_t st) {
         dim3 grid(a.N / 128, (a.M + 127) / 128, 1);
         static const bool use_glds = getenv("VLO_VIT_GLDS") ? atoi(getenv("VLO_VIT_GLDS")) != 0 : true;
         static const int stages = getenv("VLO_VIT_STAGES") ? atoi(getenv("VLO_VIT_STAGES")) : 2;
-        if (use_glds && EP != EP_PATCH && stages >= 4)
+        // VLO_VIT_WAVES=4: 4 waves of 64x64 (16 MFMAs per 8 fragment reads) instead of 8 waves of 64x32 (8 per 6): a third less
+        // LDS read traffic per FLOP, and 2-3 blocks per CU instead of 2
+        static const int waves = getenv("VLO_VIT_WAVES") ? atoi(getenv("VLO_VIT_WAVES")) : 8;
+        if (use_glds && EP != EP_PATCH && waves == 4 && stages >= 3)
+            hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 2, EP, 0, 3>), grid, dim3(256), 0, st, a);
+        else if (use_glds && EP != EP_PATCH && waves == 4)
+            hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 2, EP, 0, 2>), grid, dim3(256), 0, st, a);
+        else if (use_glds && EP != EP_PATCH && stages >= 4)
             hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 4, EP, 0, 4>), grid, dim3(512), 0, st, a);
         else if (use_glds && EP != EP_PATCH && stages == 3)
             hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 4, EP, 0, 3>), grid, dim3(512), 0, st, a);
@@ -399,7 +409,7 @@ __global__ __launch_bounds__(256) void vit_layernorm_kernel(const float *__restr
 //   O^T[d][q]  += V^T[d][key].P^T[key][q]   (V^T rows = A operand; P^T stays in the producing lanes)
 // ------------------------------------------------------------------------------------
 template <int HD>
-__global__ __launch_bounds__(256, 2) void vit_attn_kernel(const f16_t *__restrict__ qk, const f16_t *__restrict__ vT,
+__global__ __launch_bounds__(256) void vit_attn_kernel(const f16_t *__restrict__ qk, const f16_t *__restrict__ vT,
                                                        f16_t *__restrict__ out, int S, int D, int nheads, float scale) {
     constexpr int NKK = HD / 32, NDT = HD / 16, QS = 4;
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];     // [4 waves][QS][NDT][64] O partials, then m/l
@@ -433,30 +443,24 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(const f16_t *__restric
         for (int dt = 0; dt < NDT; ++dt) O[qs][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-    // K / V^T fragments of the NEXT 32-key block are fetched while the current block's MFMAs and softmax run (register double
-    // buffer): with one wave per SIMD and two blocks per CU nothing else covers the L2 latency of these 64-byte-per-row gathers
-    auto load_kv = [&](int kt, frag_ab (&kf_)[2][NKK], frag_ab (&vf_)[NDT]) {
+    for (int kt0 = w * 32; kt0 < S; kt0 += 128) {
+        frag_ab kf[2][NKK];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int key = min(kt + t * 16 + qrow, S - 1);
+            const int key = min(kt0 + t * 16 + qrow, S - 1);
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk)
-                kf_[t][kk] = *reinterpret_cast<const frag_ab *>(kbase + (size_t)key * ld + kk * 32 + qd * 8);
+                kf[t][kk] = *reinterpret_cast<const frag_ab *>(kbase + (size_t)key * ld + kk * 32 + qd * 8);
         }
+        frag_ab vf[NDT];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
-            const f16_t *vr = vbase + (size_t)(dt * 16 + qrow) * S + kt + qd * 4;
+            const f16_t *vr = vbase + (size_t)(dt * 16 + qrow) * S + kt0 + qd * 4;
             uint2 lo = make_uint2(0, 0), hi = make_uint2(0, 0);
-            if (kt + qd * 4 < S) lo = *reinterpret_cast<const uint2 *>(vr);
-            if (kt + 16 + qd * 4 < S) hi = *reinterpret_cast<const uint2 *>(vr + 16);
-            vf_[dt] = __builtin_bit_cast(frag_ab, make_uint4(lo.x, lo.y, hi.x, hi.y));
+            if (kt0 + qd * 4 < S) lo = *reinterpret_cast<const uint2 *>(vr);
+            if (kt0 + 16 + qd * 4 < S) hi = *reinterpret_cast<const uint2 *>(vr + 16);
+            vf[dt] = __builtin_bit_cast(frag_ab, make_uint4(lo.x, lo.y, hi.x, hi.y));
         }
-    };
-    frag_ab kf[2][NKK], vf[NDT], kn[2][NKK], vn[NDT];
-    if (w * 32 < S) load_kv(w * 32, kf, vf);
-    for (int kt0 = w * 32; kt0 < S; kt0 += 128) {
-        const bool more = kt0 + 128 < S;
-        if (more) load_kv(kt0 + 128, kn, vn);
         const int kb = kt0 + qd * 4;
 #pragma unroll
         for (int qs = 0; qs < QS; ++qs) {
@@ -495,14 +499,6 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(const f16_t *__restric
                 o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
                 O[qs][dt] = mfma_f16(vf[dt], pb, o);
             }
-        }
-        if (more) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int kk = 0; kk < NKK; ++kk) kf[t][kk] = kn[t][kk];
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) vf[dt] = vn[dt];
         }
     }
     // publish this wave's partial state
