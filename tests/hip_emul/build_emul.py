@@ -39,14 +39,23 @@ def build(force=False, sanitize=None):
              "-I", HERE, "-I", CSRC]
     san = ["-fsanitize=" + sanitize, "-fno-omit-frame-pointer", "-g"] if sanitize else []
     flags = [f for f in flags if not (san and f == "-g0")] + san
-    for s in SOURCES:
-        src = open(os.path.join(CSRC, s)).read()
+    def patch(src):
         # dynamic shared memory: `extern __shared__ T name[]` refers to an array the harness defines (emul_stubs.cpp)
         src = re.sub(r"extern\s+__shared__", "extern", src)
-        # GPU assembly (explicit s_waitcnt around direct-to-LDS loads): the emulated loads are synchronous
+        # GPU assembly (explicit s_waitcnt around direct-to-LDS loads / release sequences): the emulated loads are synchronous
         src = re.sub(r'asm volatile\("s_waitcnt[^"]*"\s*:::\s*"memory"\);', ";", src)
         src = re.sub(r'asm volatile\("s_waitcnt vmcnt\(%0\)"\s*::\s*"n"\([^;]*\)\s*:\s*"memory"\);', ";", src)   # counted form
         src = re.sub(r'asm volatile\(""\s*:\s*"\+v"\(\w+\)\);', ";", src)      # optimisation barrier on a VGPR value
+        return src
+
+    # textually included kernel bodies are patched too: the copies in OUT shadow the originals (quote includes resolve next to
+    # the including file first)
+    for inc in os.listdir(CSRC):
+        if inc.endswith(".inc"):
+            with open(os.path.join(OUT, inc), "w") as f:
+                f.write(f'#line 1 "{os.path.join(CSRC, inc)}"\n' + patch(open(os.path.join(CSRC, inc)).read()))
+    for s in SOURCES:
+        src = patch(open(os.path.join(CSRC, s)).read())
         patched = os.path.join(OUT, s.replace(".hip", "_emul.cpp"))
         with open(patched, "w") as f:
             f.write(f'#line 1 "{os.path.join(CSRC, s)}"\n' + src)

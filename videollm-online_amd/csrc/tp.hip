@@ -73,8 +73,7 @@ static std::string rccl_err(const char *what, int code) {
 
 static int rccl_load() {
     if (g_rccl.dl) return VLO_OK;
-    // VLO_RCCL_LIBRARY: a specific RCCL build — or, in the CPU test of the one-process-per-rank data path, a stand-in that
-    // implements the same seven entry points over shared memory (tests/hip_emul/rccl_shim.cpp)
+    // VLO_RCCL_LIBRARY: a specific RCCL build (any library that exports the same entry points)
     const char *names[] = {getenv("VLO_RCCL_LIBRARY"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void *dl = nullptr;
     for (const char *n : names) {

@@ -70,13 +70,14 @@ __global__ __launch_bounds__(WM * WN * 64) void vit_gemm_kernel(GemmArgs a) {
 #define sW(buf) (smem + (buf) * STAGE + BM * GEMM_BK)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w / WN, wn = w % WN;
-    // XCD-aware tile order.  Workgroups are handed to the 8 XCDs round-robin in dispatch order (x fastest), each XCD has its
-    // own 4 MiB L2.  With the plain (x, y) -> tile map and a grid whose width is a multiple of 8, XCD i computes column tiles
-    // i, i+8, ... of EVERY row: all eight L2s stream the whole activation matrix (fc2 at 8 frames: 8 x 37.7 MB from the
-    // memory side for 38.6 GFLOP).  Instead XCD i takes a CONTIGUOUS run of the row-major tile list (a band of rows x all
-    // columns): its concurrent blocks share a few activation row-tiles and the weight matrix, K slice by K slice, out of one L2.
+    // XCD-aware tile order.  Workgroups are handed to the 8 XCDs round-robin in dispatch order (x fastest); each XCD has its own
+    // 4 MiB L2.  A grid whose width is a multiple of 8 therefore gives XCD i the column tiles i, i+8, ... of EVERY row: its slice of
+    // W stays in its L2 and the activations stream through all eight L2s (memory-side reads ~ 8 |X| + |W|).  Right for the wide
+    // GEMMs (qkv, fc1: |W| > L2), wrong for the narrow ones with long K (fc2 at 8 frames: 8 x 37.7 MB for 38.6 GFLOP; out-proj):
+    // there XCD i takes a CONTIGUOUS run of the row-major tile list instead (a band of rows x all columns, ~ |X| + 8 |W|).
+    // fc2: 92 -> 68 us.  Grids whose width is not a multiple of 8 (no clean column ownership) take the band order too.
     int tile_x = blockIdx.x, tile_y = blockIdx.y;
-    {
+    if (gridDim.x <= 8 || (gridDim.x & 7)) {
         const int ntx = gridDim.x, nt = gridDim.x * gridDim.y;
         const int L = blockIdx.y * ntx + blockIdx.x, xcd = L & 7, j = L >> 3;
         const int q = nt >> 3, r = nt & 7;                      // XCD x owns q + (x < r) tiles (bijective for any nt)
@@ -324,19 +325,9 @@ static hipError_t gemm_launch(GemmArgs a, hipStream_t st) {
         // half the L2->LDS bytes per FLOP of the 64x64 kernel, which is L2-bandwidth-bound (~450 TFLOP/s ceiling)
         dim3 grid(a.N / 128, (a.M + 127) / 128, 1);
         static const bool use_glds = getenv("VLO_VIT_GLDS") ? atoi(getenv("VLO_VIT_GLDS")) != 0 : true;
-        static const int stages = getenv("VLO_VIT_STAGES") ? atoi(getenv("VLO_VIT_STAGES")) : 2;
-        // VLO_VIT_WAVES=4: 4 waves of 64x64 (16 MFMAs per 8 fragment reads) instead of 8 waves of 64x32 (8 per 6): a third less
-        // LDS read traffic per FLOP, and 2-3 blocks per CU instead of 2
-        static const int waves = getenv("VLO_VIT_WAVES") ? atoi(getenv("VLO_VIT_WAVES")) : 8;
-        if (use_glds && EP != EP_PATCH && waves == 4 && stages >= 3)
-            hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 2, EP, 0, 3>), grid, dim3(256), 0, st, a);
-        else if (use_glds && EP != EP_PATCH && waves == 4)
-            hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 2, EP, 0, 2>), grid, dim3(256), 0, st, a);
-        else if (use_glds && EP != EP_PATCH && stages >= 4)
-            hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 4, EP, 0, 4>), grid, dim3(512), 0, st, a);
-        else if (use_glds && EP != EP_PATCH && stages == 3)
-            hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 4, EP, 0, 3>), grid, dim3(512), 0, st, a);
-        else if (use_glds && EP != EP_PATCH)
+        // measured alternatives that lost at 8-14 frames: 3 / 4 direct-to-LDS stages (one block per CU), 4 waves of
+        // 64x64 per block
+        if (use_glds && EP != EP_PATCH)
             hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 4, EP, 0, 2>), grid, dim3(512), 0, st, a);
         else
             hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 4, EP, 2>), grid, dim3(512), 0, st, a);
