@@ -160,7 +160,7 @@ def run_tp_leg(args, rank, world, local, allreduce="rccl", port_offset=17):
     steps = max(20, min(args.steps, args.tp_leg_steps))
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(steps), "--warmup", "10", "--tp",
            "--tp-allreduce", allreduce, "--no-cpu-baseline", "--model", args.model, "--mode", args.mode, "--fps", str(args.fps),
-           "--prefetch-frames", str(args.prefetch_frames)]
+           "--prefetch-frames", str(args.prefetch_frames), "--tp-vit", getattr(args, "tp_vit", "frame-parallel")]
     log(f"tp leg: {' '.join(cmd[1:])}")
     t0 = time.time()
     try:
@@ -219,6 +219,9 @@ def main():
     ap.add_argument("--tp-allreduce", default="rccl", choices=["rccl", "p2p"],
                     help="--tp exchanges: RCCL all-reduce / all-gather, or the one-shot peer-to-peer all-reduce over xGMI fused "
                          "with the residual add + RMSNorm (csrc/tp.hip, no RCCL)")
+    ap.add_argument("--tp-vit", default="frame-parallel", choices=["frame-parallel", "replicated"],
+                    help="--tp over RCCL: rank r encodes frames r, r + N, ... of a pending batch and one all-gather distributes the "
+                         "[10, H] frame embeddings (north_star), or every rank encodes every frame")
     ap.add_argument("--no-tp-leg", action="store_true",
                     help="N > 1: skip the extra tensor-parallel measurement (run in child processes after the replica run)")
     ap.add_argument("--tp-leg-steps", type=int, default=300)
@@ -271,7 +274,7 @@ def main():
         else:
             uid = [TpGroup.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
-            eng = TpGroup(cfg, world, device=local, rank=rank, unique_id=uid[0])
+            eng = TpGroup(cfg, world, device=local, rank=rank, unique_id=uid[0], frame_parallel=args.tp_vit == "frame-parallel")
         gpu_random_weights(eng, cfg, seed=0)
     else:
         eng = Engine(cfg, local)
@@ -404,7 +407,8 @@ def main():
                                       f"(frames 0..{preroll - 1} pre-rolled un-timed through the same engine steps on the same session; KV at "
                                       f"{kv_start} tokens when the clock starts, {final_len} when it stops), "
                                       if preroll else f"all {K} frames of a {minutes:g} min @ {args.fps:g} FPS 384x384 uint8 stream (KV 0 -> {final_len} tokens), ")
-                                   + (f"ONE stream, Llama TP={world} ({'RCCL' if args.tp_allreduce == 'rccl' else 'one-shot p2p'} all-reduce x2/layer), ViT replicated, "
+                                   + (f"ONE stream, Llama TP={world} ({'RCCL' if args.tp_allreduce == 'rccl' else 'one-shot p2p'} all-reduce x2/layer), ViT "
+                                      f"{'frame-parallel + all-gather of the frame embeddings' if (args.tp_allreduce == 'rccl' and args.tp_vit == 'frame-parallel') else 'replicated'}, "
                                       if tp else f"TP=1, one stream per GPU ({world} replica(s)), ") + f"mode={args.mode} "
                                    f"(16-token response every 10th frame + t=0 query), random-init weights at true shapes",
                        "frames": K, "stream_frames": total, "preroll_frames": preroll, "kv_tokens_at_start": kv_start,

@@ -247,6 +247,11 @@ int  vlo_tp_bench_exchange(vlo_tp_session *t, int m, int iters, double *avg_us, 
 /* what RCCL reports for the group's communicator (ncclCommCount / ncclCommUserRank): 0 / -1 when the group has none (logical
  * ranks, peer-to-peer exchange).  The RCCL library is dlopen'ed; VLO_RCCL_LIBRARY names a specific build. */
 int  vlo_tp_comm_info(vlo_tp_group *g, int *nranks, int *rank);
+/* byte all-gather over the group's RCCL communicator (one process per GPU): recv = rank 0's bytes | rank 1's | ...  Used for the
+ * frame-parallel vision tower under TP: rank r encodes frames r, r + T, ... of a pending batch (models/modeling_live.py:21-27 per
+ * frame), the gather gives every rank every frame's [frame_num_tokens, hidden] embedding — BASELINE.json north_star's "broadcasting
+ * the 10-token frame embedding each step" (81 920 B per frame for Llama-3-8B). */
+int  vlo_tp_allgather(vlo_tp_group *g, const void *send_dev, void *recv_dev, int64_t bytes_per_rank, void *stream);
 /* host-side mailbox geometry of the exchange above (no GPU needed; unit tests): for a group of T ranks, hidden size H,
  * vocabulary shard Vl, the seq-th exchange of a region (seq counts from 0 per region) and the tag `epoch` of the previous
  * exchange, out6 = {first granule of the reduce slot, granules between two sources of a reduce slot, first granule of the

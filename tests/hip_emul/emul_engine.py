@@ -241,9 +241,9 @@ class EmulTpRankRccl:
     """ONE rank of a one-process-per-GPU group exchanging through the RCCL entry points (include/vlo.h: n_local = 1 and a
     unique id), which VLO_RCCL_LIBRARY points at the shared-memory stand-in tests/hip_emul/rccl_shim.cpp."""
 
-    def __init__(self, spec, T, rank, weights, inv_freq, unique_id, kv_pool_tokens=1024):
+    def __init__(self, spec, T, rank, weights, inv_freq, unique_id, kv_pool_tokens=1024, vit=None):
         self.spec, self.T, self.rank = spec, T, rank
-        self.engine = EmulEngine(spec, kv_pool_tokens, rank, T).load_weights(weights, inv_freq)
+        self.engine = EmulEngine(spec, kv_pool_tokens, rank, T, vit=vit).load_weights(weights, inv_freq)
         arr = (C.c_void_p * 1)(self.engine._h)
         g = C.c_void_p()
         check(lib().vlo_tp_group_create(arr, 1, C.create_string_buffer(unique_id, 128), C.byref(g)))
@@ -256,6 +256,20 @@ class EmulTpRankRccl:
         n, r = C.c_int(0), C.c_int(-1)
         check(lib().vlo_tp_comm_info(self._g, C.byref(n), C.byref(r)))
         return n.value, r.value
+
+    def visual_embed_frame_parallel(self, frames_u8):
+        """engine.TpGroup.visual_embed(frame_parallel=True) on the emulated library: this rank encodes frames rank, rank + T, ...,
+        one vlo_tp_allgather, frame i comes back from rank i % T as its (i // T)-th frame"""
+        T, r = self.T, self.rank
+        B, rows, H = frames_u8.shape[0], self.engine.vit.frame_num_tokens, self.spec.hidden_size
+        k = (B + T - 1) // T
+        mine = frames_u8[r::T].contiguous()
+        send = torch.zeros(k * rows, H, dtype=torch.bfloat16)
+        if mine.shape[0]:
+            send[:mine.shape[0] * rows] = self.engine.visual_embed(mine)
+        recv = torch.zeros(T, k * rows, H, dtype=torch.bfloat16)
+        check(lib().vlo_tp_allgather(self._g, _ptr(send), _ptr(recv), send.numel() * 2, None))
+        return recv.view(T, k, rows, H).transpose(0, 1).reshape(T * k, rows, H)[:B].reshape(B * rows, H)
 
     def llm_step(self, embeds, want_all=True):
         return EmulTpGroup.llm_step(self, self._s, embeds, want_all)

@@ -114,14 +114,20 @@ def _tp_rccl_worker(rank, world, port, q):
     ref = O.LlamaOracle(spec, w, torch.bfloat16)
     uid = [E.unique_id() if rank == 0 else None]            # rank 0's ncclGetUniqueId, broadcast by the host (bench.py --tp)
     dist.broadcast_object_list(uid, src=0)
-    r = E.EmulTpRankRccl(spec, world, rank, w, O.rope_inv_freq(spec.head_dim, spec.rope_theta), bytes(uid[0]))
+    vspec = O.VIT_SPECS["toy"]
+    w = dict(w, **O.init_vit_weights(vspec, seed=1))
+    r = E.EmulTpRankRccl(spec, world, rank, w, O.rope_inv_freq(spec.head_dim, spec.rope_theta), bytes(uid[0]), vit=vspec)
     g = torch.Generator().manual_seed(3)
     steps = [torch.cat([ref.embed(torch.tensor(toks.start_ids)), torch.randn(10, spec.hidden_size, generator=g).bfloat16()]),
              torch.cat([ref.embed(torch.tensor([toks.interval_id])), torch.randn(10, spec.hidden_size, generator=g).bfloat16()]),
              ref.embed(torch.tensor([17]))]
     outs = [r.llm_step(x)[1].float().numpy() for x in steps]
     us = r.bench_exchange(3, 2)
-    q.put((rank, outs, r.comm_info(), us))
+    # frame-parallel vision tower: 3 pending frames over 2 ranks (rank 0 encodes frames 0 and 2, rank 1 frame 1), one all-gather
+    frames = O.synthetic_frames(3, vspec.image_size, seed=77)
+    fp = r.visual_embed_frame_parallel(frames)
+    full = r.engine.visual_embed(frames)                     # the replicated tower on this rank
+    q.put((rank, outs, r.comm_info(), us, bool(torch.equal(fp, full)), float((fp.float() - full.float()).abs().max())))
     dist.barrier()
     r.close()
     dist.destroy_process_group()
@@ -143,9 +149,11 @@ def test_tp_data_path_two_processes_rccl_standin():
     ps = [ctx.Process(target=_tp_rccl_worker, args=(r, world, port, q)) for r in range(world)]
     [p.start() for p in ps]
     res = {}
+    vit = {}
     for _ in range(world):
-        rank, outs, info, us = q.get(timeout=900)
+        rank, outs, info, us, same, dmax = q.get(timeout=900)
         res[rank] = (outs, info, us)
+        vit[rank] = (same, dmax)
     [p.join(120) for p in ps]
     assert all(p.exitcode == 0 for p in ps)
     assert res[0][1] == (2, 0) and res[1][1] == (2, 1)                       # what the communicator itself reports
@@ -167,3 +175,5 @@ def test_tp_data_path_two_processes_rccl_standin():
         r = (rl.float() - gl).abs().max().item()
         assert e <= 1.5 * r + 1e-3 * gl.abs().max().item(), f"step {i}: engine err {e} vs reference-bf16 err {r}"
     assert res[0][2] >= 0.0 and res[1][2] >= 0.0
+    # frame-parallel encode + all-gather == every rank encoding every frame (north_star's frame-embedding broadcast)
+    assert all(v[0] for v in vit.values()), f"frame-parallel and replicated vision embeddings differ: {vit}"

@@ -37,7 +37,7 @@ EXPORTS = [
     "vlo_tp_unique_id", "vlo_tp_group_create", "vlo_tp_group_destroy", "vlo_tp_session_create", "vlo_tp_session_reset",
     "vlo_tp_session_len", "vlo_tp_session_destroy", "vlo_tp_llm_step", "vlo_tp_stream_sample", "vlo_tp_greedy_generate",
     "vlo_joint_embed", "vlo_logit_rows", "vlo_session_fork", "vlo_session_crop", "vlo_tp_selftest", "vlo_debug_gemm64_plan", "vlo_debug_pack64_elem",
-    "vlo_step_input", "vlo_build_id", "vlo_frame_ingest", "vlo_frame_ingest_geometry", "vlo_test_gemv_fp8", "vlo_tp_comm_info",
+    "vlo_step_input", "vlo_build_id", "vlo_frame_ingest", "vlo_frame_ingest_geometry", "vlo_test_gemv_fp8", "vlo_tp_comm_info", "vlo_tp_allgather",
     "vlo_tp_p2p_export", "vlo_tp_p2p_enable", "vlo_tp_p2p_status", "vlo_debug_p2p_layout", "vlo_tp_bench_exchange",
 ]
 
@@ -128,6 +128,7 @@ def bind(L):
     L.vlo_tp_p2p_status.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.vlo_tp_bench_exchange.argtypes = [vp, i32, i32, C.POINTER(C.c_double), vp]
     L.vlo_tp_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.vlo_tp_allgather.argtypes = [vp, vp, vp, i64, vp]
     L.vlo_debug_p2p_layout.argtypes = [i32, i32, i32, C.c_uint32, C.c_uint32, C.POINTER(i64)]
     L.vlo_profile_enable.argtypes = [vp, i32]
     L.vlo_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]

@@ -241,6 +241,18 @@ int vlo_tp_comm_info(vlo_tp_group *g, int *nranks, int *rank) {
     return VLO_OK;
 }
 
+// frame-parallel vision tower under tensor parallelism (north_star: "broadcasting the 10-token frame embedding each step"): every
+// rank encodes its share of the pending frames, one all-gather hands every rank all the [frame_num_tokens, H] embeddings
+// (81 920 B per frame for the 8B model).  One process per GPU over RCCL only; other groups keep the replicated tower.
+int vlo_tp_allgather(vlo_tp_group *g, const void *send_dev, void *recv_dev, int64_t bytes_per_rank, void *stream) {
+    if (!g || !send_dev || !recv_dev || bytes_per_rank <= 0) return vlo_fail(VLO_E_INVALID, "bad tp_allgather arguments");
+    if (!g->comm) return vlo_fail(VLO_E_STATE, "tp_allgather needs the RCCL communicator of a one-process-per-GPU group");
+    TP_TRY(hipSetDevice(g->eng[0]->device));
+    const int nrc = g_rccl.AllGather(send_dev, recv_dev, (size_t)bytes_per_rank, kNcclInt8, g->comm, (hipStream_t)stream);
+    if (nrc != 0) return vlo_fail(VLO_E_HIP, rccl_err("ncclAllGather", nrc));
+    return VLO_OK;
+}
+
 static void p2p_release(vlo_tp_group *g);
 void vlo_tp_group_destroy(vlo_tp_group *g) {
     if (!g) return;

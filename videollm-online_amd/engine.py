@@ -416,7 +416,7 @@ class TpGroup:
     Weights are given in FULL; every rank slices its shard.  ViT, connector and embeddings are replicated."""
 
     def __init__(self, cfg: EngineConfig, tp_size: int, device: int = 0, rank: int | None = None, unique_id: bytes | None = None,
-                 allreduce: str = "default", handle_allgather=None):
+                 allreduce: str = "default", handle_allgather=None, frame_parallel: bool = False):
         from dataclasses import replace
         self.cfg = cfg
         self.tp_size = tp_size
@@ -425,6 +425,7 @@ class TpGroup:
         if allreduce not in ("default", "rccl", "p2p"):
             raise ValueError(f"allreduce must be 'default', 'rccl' or 'p2p', not {allreduce!r}")
         self.allreduce = "p2p" if allreduce == "p2p" else ("rccl" if rank is not None else "kernel")
+        self.frame_parallel = frame_parallel
         self._handle_allgather = handle_allgather
         if rank is not None and tp_size > 1:
             if self.allreduce == "p2p" and handle_allgather is None:
@@ -529,7 +530,25 @@ class TpGroup:
         return self.engines[0].frame_ingest(frames, layout, resolution, cubic_a, out, stream)
 
     def visual_embed(self, frames_u8, stream=None, out=None):
-        return self.engines[0].visual_embed(frames_u8, stream, out)
+        """Replicated tower (every rank encodes every frame) unless this is a one-process-per-GPU group over RCCL with
+        ``frame_parallel`` set: then rank r encodes frames r, r + T, ... and ONE all-gather hands every rank all the
+        [frame_num_tokens, H] embeddings (north_star's frame-embedding broadcast; 81 920 B per frame for Llama-3-8B)."""
+        if not (self.frame_parallel and self.allreduce == "rccl" and len(self.engines) == 1 and self.tp_size > 1):
+            return self.engines[0].visual_embed(frames_u8, stream, out)
+        e, T, r = self.engines[0], self.tp_size, self.engines[0].cfg.tp_rank
+        B, rows, H = frames_u8.shape[0], self.cfg.frame_num_tokens, self.cfg.hidden_size
+        k = (B + T - 1) // T                                   # frames per rank, the last ranks' shares padded
+        mine = frames_u8[r::T]
+        send = torch.zeros(k * rows, H, dtype=torch.bfloat16, device=self.device)
+        if mine.shape[0]:
+            e.visual_embed(mine, stream, out=send[:mine.shape[0] * rows])
+        recv = torch.empty(T, k * rows, H, dtype=torch.bfloat16, device=self.device)
+        _C.check(_C.lib().vlo_tp_allgather(self._g, _ptr(send), _ptr(recv), send.numel() * 2, _stream_handle(stream)))
+        if out is None:
+            out = torch.empty(B * rows, H, dtype=torch.bfloat16, device=self.device)
+        # frame i was encoded by rank i % T as its (i // T)-th frame
+        out.view(B, rows, H).copy_(recv.view(T, k, rows, H).transpose(0, 1).reshape(T * k, rows, H)[:B])
+        return out
 
     def llm_step(self, session: TpSession, embeds: torch.Tensor, want_last=True, want_all=False, stream=None):
         embeds = embeds.to(device=self.device, dtype=torch.bfloat16).contiguous().view(-1, self.cfg.hidden_size)
