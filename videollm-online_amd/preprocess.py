@@ -78,7 +78,10 @@ def output_root(src_root: str, embed_mark: str, vision_pretrained: str) -> str:
 
 
 def my_files(src_root: str, rank: int, world_size: int) -> list[str]:
-    """data/utils.py:93-95: file i of the directory listing belongs to rank i % world_size."""
+    """data/utils.py:93-95: file i of the directory listing belongs to rank i % world_size.  The reference enumerates
+    `os.listdir(src_root)` as the OS returns it (arbitrary but identical on every rank of one node); here the listing is SORTED so
+    that ranks on different nodes, whose listings may be ordered differently, still partition the directory without overlap.
+    Which rank encodes which video therefore differs from the reference; the set of output files and their contents do not."""
     return [f for i, f in enumerate(sorted(os.listdir(src_root))) if i % world_size == rank]
 
 
