@@ -51,7 +51,7 @@ struct vlo_engine {
     std::vector<LayerWeights> layers;
     PackedLinear lm_head, conn0, conn2;
     void *norm_w = nullptr, *embed = nullptr, *conn0_b = nullptr, *conn2_b = nullptr;
-    void *conn_x = nullptr, *conn_mid = nullptr, *conn_out = nullptr;
+    void *conn_x = nullptr, *conn_mid = nullptr, *conn_out = nullptr;   // connector scratch: 2 slots of 32 rows each (two encode branches may run concurrently)
     void *cos_tab = nullptr, *sin_tab = nullptr;
     int64_t max_positions = 0;
 
@@ -102,4 +102,5 @@ int ensure_pages(vlo_session *s, int64_t new_len, hipStream_t st);
 GemvArgs gemv_args(const PackedLinear &pl, const unsigned short *x, int ldx, int n_rows);
 KvGeom kv_geom(const vlo_session *s);
 void ingest_destroy(vlo_engine *e);
+int connector_run(vlo_engine *e, int slot, const void *feats_dev, int rows, void *out_dev, hipStream_t st);   // slot 0 / 1: scratch set
 int vlo_fail(int code, const std::string &msg);   // sets the thread-local error string, returns code

@@ -875,14 +875,38 @@ int vlo_connector_reserve(vlo_engine *e) {
     if (e->conn_x) return VLO_OK;
     const int H = e->cfg.hidden_size, Hv = e->cfg.vision_hidden_size;
     int rc;
-    if ((rc = dev_alloc(&e->conn_x, (size_t)32 * Hv * 2))) return rc;
-    if ((rc = dev_alloc(&e->conn_mid, (size_t)32 * H * 2))) return rc;
-    if ((rc = dev_alloc(&e->conn_out, (size_t)32 * H * 2))) return rc;
+    if ((rc = dev_alloc(&e->conn_x, (size_t)2 * 32 * Hv * 2))) return rc;
+    if ((rc = dev_alloc(&e->conn_mid, (size_t)2 * 32 * H * 2))) return rc;
+    if ((rc = dev_alloc(&e->conn_out, (size_t)2 * 32 * H * 2))) return rc;
     e->owned.push_back(e->conn_x);
     e->owned.push_back(e->conn_mid);
     e->owned.push_back(e->conn_out);
-    HIP_TRY(hipMemset(e->conn_x, 0, (size_t)32 * Hv * 2));
-    HIP_TRY(hipMemset(e->conn_mid, 0, (size_t)32 * H * 2));
+    HIP_TRY(hipMemset(e->conn_x, 0, (size_t)2 * 32 * Hv * 2));
+    HIP_TRY(hipMemset(e->conn_mid, 0, (size_t)2 * 32 * H * 2));
+    return VLO_OK;
+}
+
+int connector_run(vlo_engine *e, int slot, const void *feats_dev, int rows, void *out_dev, hipStream_t st) {
+    const int H = e->cfg.hidden_size, Hv = e->cfg.vision_hidden_size;
+    int rc;
+    if ((rc = vlo_connector_reserve(e))) return rc;
+    unsigned short *cx = (unsigned short *)e->conn_x + (size_t)slot * 32 * Hv, *cm = (unsigned short *)e->conn_mid + (size_t)slot * 32 * H,
+                   *co = (unsigned short *)e->conn_out + (size_t)slot * 32 * H;
+    for (int r0 = 0; r0 < rows; r0 += 16) {
+        const int m = std::min(16, rows - r0);
+        HIP_TRY(copy_rows_launch((const unsigned short *)feats_dev + (size_t)r0 * Hv, cx, m, Hv, st));
+        {
+            GemvArgs a = gemv_args(e->conn0, cx, Hv, m);
+            a.out_bf16 = cm; a.ldo = H; a.bias = (const unsigned short *)e->conn0_b;
+            HIP_TRY(gemv_launch(a, e->conn0.plan, XSRC_PLAIN, EPI_BF16_GELU_ERF, st));
+        }
+        {
+            GemvArgs a = gemv_args(e->conn2, cm, H, m);
+            a.out_bf16 = co; a.ldo = H; a.bias = (const unsigned short *)e->conn2_b;
+            HIP_TRY(gemv_launch(a, e->conn2.plan, XSRC_PLAIN, EPI_BF16, st));
+        }
+        HIP_TRY(copy_rows_launch(co, (unsigned short *)out_dev + (size_t)r0 * H, m, H, st));
+    }
     return VLO_OK;
 }
 
@@ -890,26 +914,7 @@ int vlo_connector(vlo_engine *e, const void *feats_dev, int rows, void *out_dev,
     if (!e || !feats_dev || !out_dev || rows <= 0) return fail(VLO_E_INVALID, "bad connector arguments");
     if (!e->finalized || !e->has_connector) return fail(VLO_E_STATE, "connector weights not loaded");
     HIP_TRY(hipSetDevice(e->device));
-    hipStream_t st = (hipStream_t)stream;
-    const int H = e->cfg.hidden_size, Hv = e->cfg.vision_hidden_size;
-    int rc;
-    if ((rc = vlo_connector_reserve(e))) return rc;
-    for (int r0 = 0; r0 < rows; r0 += 16) {
-        const int m = std::min(16, rows - r0);
-        HIP_TRY(copy_rows_launch((const unsigned short *)feats_dev + (size_t)r0 * Hv, (unsigned short *)e->conn_x, m, Hv, st));
-        {
-            GemvArgs a = gemv_args(e->conn0, (const unsigned short *)e->conn_x, Hv, m);
-            a.out_bf16 = (unsigned short *)e->conn_mid; a.ldo = H; a.bias = (const unsigned short *)e->conn0_b;
-            HIP_TRY(gemv_launch(a, e->conn0.plan, XSRC_PLAIN, EPI_BF16_GELU_ERF, st));
-        }
-        {
-            GemvArgs a = gemv_args(e->conn2, (const unsigned short *)e->conn_mid, H, m);
-            a.out_bf16 = (unsigned short *)e->conn_out; a.ldo = H; a.bias = (const unsigned short *)e->conn2_b;
-            HIP_TRY(gemv_launch(a, e->conn2.plan, XSRC_PLAIN, EPI_BF16, st));
-        }
-        HIP_TRY(copy_rows_launch((const unsigned short *)e->conn_out, (unsigned short *)out_dev + (size_t)r0 * H, m, H, st));
-    }
-    return VLO_OK;
+    return connector_run(e, 0, feats_dev, rows, out_dev, (hipStream_t)stream);
 }
 
 int vlo_visual_embed(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_dev, void *stream) {
