@@ -209,7 +209,7 @@ def main():
                          "un-timed through the same engine steps on the same session, so the timed region sits at the "
                          "10-minute context the metric is defined on")
     ap.add_argument("--no-prefetch", action="store_true")
-    ap.add_argument("--prefetch-frames", type=int, default=14, help="frames encoded ahead per batched ViT call (14 x 576 rows = 63 row tiles of 128: 504 / 1512 / 2016 GEMM tiles, whole rounds of the 512 resident blocks)")
+    ap.add_argument("--prefetch-frames", type=int, default=16, help="frames encoded ahead per batched ViT call (16 = two parallel 8-frame branches of the captured encode graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=20)
     ap.add_argument("--prof-stride", type=int, default=8)

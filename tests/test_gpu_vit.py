@@ -173,15 +173,15 @@ def test_full_depth_siglip_l_vs_cpu_fp32_reference():
 
 
 def test_two_branch_batched_encode_matches_single_branch():
-    """From 8 frames up the captured encode runs as two parallel half-batch branches on two streams, each on its own slice of the
+    """From 12 frames up (VLO_VIT_SPLIT_MIN) the captured encode runs as two parallel half-batch branches on two streams, each on its own slice of the
     workspace and its own connector scratch (csrc/vit.hip::vit_visual_embed).  Same frames through the eager single-branch path
     (default stream) must give the same embeddings — the rows are independent, only which GEMM tile variant computes them differs."""
     spec, vspec = O.LLM_SPECS["tinyllama-2l"], O.VIT_SPECS["siglip-l16-384-2l"]
     w, vw = O.init_llm_weights(spec, seed=5), O.init_vit_weights(vspec, seed=1)
     eng = _engine(spec, vspec, w, vw)
-    frames = O.synthetic_frames(11, vspec.image_size, seed=21).cuda()
+    frames = O.synthetic_frames(13, vspec.image_size, seed=21).cuda()
     side = torch.cuda.Stream()
-    for B in (8, 11, 9):
+    for B in (13, 12, 9):
         eager = eng.visual_embed(frames[:B]).clone()                 # default stream: no graph, one branch
         for _ in range(2):                                            # capture, then replay
             with torch.cuda.stream(side):

@@ -909,10 +909,11 @@ int vit_visual_embed(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_
     if (it == v->graphs.end()) {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
-        // From VLO_VIT_SPLIT_MIN frames up (default 8) the batch is captured as TWO parallel branches (first half on the caller's
+        // From VLO_VIT_SPLIT_MIN frames up (default 12) the batch is captured as TWO parallel branches (first half on the caller's
         // stream, second half on an internal one, each on its own slice of the workspace): one half's tails, ramps and
-        // under-filled kernels overlap the other's — measured 455 vs 421 TFLOP/s at 8 frames, 590 vs 563 at 14, 606 vs 516 at 16.
-        static const int split_min = getenv("VLO_VIT_SPLIT_MIN") ? atoi(getenv("VLO_VIT_SPLIT_MIN")) : 8;
+        // under-filled kernels overlap the other's — measured 588 vs 572 TFLOP/s at 14 frames, 599 vs 520 at 16, 625 vs 578 at 32
+        // (448 vs 465 at 8: halves of 4 frames fall back to the 64x64 tiles); results are bit-identical.
+        static const int split_min = getenv("VLO_VIT_SPLIT_MIN") ? atoi(getenv("VLO_VIT_SPLIT_MIN")) : 12;
         const bool split = split_min > 0 && B >= split_min;
         if (split && !v->st2) {
             VIT_TRY(hipStreamCreateWithFlags(&v->st2, hipStreamNonBlocking));
