@@ -109,7 +109,10 @@ void    vlo_session_destroy(vlo_session *s);
 /* ---- model.visual_embed(frames) (models/modeling_live.py:21-27 ->
  *      models/vision_live.py:10-30 -> HF SiglipVisionModel -> connector
  *      models/live_llama/modeling_live_llama.py:18-22).
- *      frames_dev: uint8 [B,3,R,R] NCHW;  out_dev: bf16 [B*frame_num_tokens, hidden_size] */
+ *      frames_dev: uint8 [B,3,R,R] NCHW;  out_dev: bf16 [B*frame_num_tokens, hidden_size].
+ *      The encode workspace belongs to the ENGINE: encodes of one engine issued on different streams must be ordered by the caller
+ *      (LiveInfer issues all of them on its one encode stream).  From 12 frames up the batch runs as two parallel half-batch branches
+ *      (the second on an internal stream, joined back before the call's work on `stream` ends). */
 int vlo_visual_embed(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_dev, void *stream);
 /* ---- vision tokens only: `vision_encode(model, frames)` as the offline feature extraction uses it
  *      (data/utils.py:86-104 distributed_encode -> models/vision_live.py:10-30).

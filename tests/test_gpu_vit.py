@@ -66,6 +66,7 @@ def test_graph_replay_matches_eager():
     eng = _engine(spec, vspec, w, vw)
     frames = O.synthetic_frames(4, vspec.image_size, seed=7).cuda()
     eager = {B: eng.visual_embed(frames[:B]).clone() for B in (1, 3)}       # default stream -> eager path
+    torch.cuda.synchronize()                 # one encode workspace per engine: calls on different streams are ordered by the caller
     side = torch.cuda.Stream()
     for B in (1, 3, 1, 4, 3):
         with torch.cuda.stream(side):
@@ -183,6 +184,7 @@ def test_two_branch_batched_encode_matches_single_branch():
     side = torch.cuda.Stream()
     for B in (13, 12, 9):
         eager = eng.visual_embed(frames[:B]).clone()                 # default stream: no graph, one branch
+        torch.cuda.synchronize()             # the engine's encode workspace is shared: calls on different streams are ordered by the caller
         for _ in range(2):                                            # capture, then replay
             with torch.cuda.stream(side):
                 out = eng.visual_embed(frames[:B], stream=side)

@@ -891,6 +891,32 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
     return connector_run(e, conn_slot, w_tokens, B * (1 + v->ph * v->pw), out_dev, st);
 }
 
+// B frames as ONE branch, or — from VLO_VIT_SPLIT_MIN frames up (default 12) — as TWO parallel half-batch branches: first half on the
+// caller's stream, second half on an internal one, each on its own slice of the workspace and its own connector scratch, forked and
+// joined with events (inside a stream capture they become parallel branches of the graph).  One half's tails, ramps and
+// under-filled kernels overlap the other's: measured 588 vs 572 TFLOP/s at 14 frames, 599 vs 520 at 16, 625 vs 578 at 32 (448 vs
+// 465 at 8: halves of 4 frames fall back to the 64x64 tiles); results are bit-identical.
+static int vit_run_branches(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_dev, hipStream_t st, bool with_connector) {
+    VitState *v = e->vit;
+    static const int split_min = getenv("VLO_VIT_SPLIT_MIN") ? atoi(getenv("VLO_VIT_SPLIT_MIN")) : 12;
+    if (split_min <= 0 || B < split_min || st == nullptr) return vit_run(e, frames_dev, B, out_dev, st, with_connector);
+    if (!v->st2) {
+        VIT_TRY(hipStreamCreateWithFlags(&v->st2, hipStreamNonBlocking));
+        VIT_TRY(hipEventCreate(&v->ev_fork));
+        VIT_TRY(hipEventCreate(&v->ev_join));
+    }
+    const int B0 = B / 2;
+    const size_t frame_bytes = (size_t)3 * v->R * v->R;
+    const size_t out_elems = (size_t)(1 + v->ph * v->pw) * (with_connector ? e->cfg.hidden_size : v->D);
+    VIT_TRY(hipEventRecord(v->ev_fork, st));
+    VIT_TRY(hipStreamWaitEvent(v->st2, v->ev_fork, 0));
+    int rc = vit_run(e, frames_dev, B0, out_dev, st, with_connector, 0, 0);
+    if (!rc) rc = vit_run(e, frames_dev + B0 * frame_bytes, B - B0, (bf16_t *)out_dev + B0 * out_elems, v->st2, with_connector, B0, 1);
+    VIT_TRY(hipEventRecord(v->ev_join, v->st2));          // joined even after a failed launch: the second stream must leave the capture
+    VIT_TRY(hipStreamWaitEvent(st, v->ev_join, 0));
+    return rc;
+}
+
 // Entry point.  The launch sequence is static for a given B, so it is captured once into a hipGraph and
 // replayed (one host call instead of ~180; the host thread also feeds the Llama stream).  Frames are
 // staged into a fixed input buffer and the embeddings leave through a fixed output buffer so the
@@ -901,7 +927,7 @@ int vit_visual_embed(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_
     int rc;
     if ((rc = vit_reserve(e, v, B))) return rc;
     if ((rc = vlo_connector_reserve(e))) return rc;
-    if (!use_graph || st == nullptr) return vit_run(e, frames_dev, B, out_dev, st);    // the null stream cannot be captured
+    if (!use_graph || st == nullptr) return vit_run_branches(e, frames_dev, B, out_dev, st, true);    // the null stream cannot be captured (nor forked: one branch)
     const size_t in_bytes = (size_t)B * 3 * v->R * v->R;
     const size_t out_bytes = (size_t)B * (1 + v->ph * v->pw) * e->cfg.hidden_size * 2;
     VIT_TRY(hipMemcpyAsync(v->frames_in, frames_dev, in_bytes, hipMemcpyDeviceToDevice, st));
@@ -909,31 +935,8 @@ int vit_visual_embed(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_
     if (it == v->graphs.end()) {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
-        // From VLO_VIT_SPLIT_MIN frames up (default 12) the batch is captured as TWO parallel branches (first half on the caller's
-        // stream, second half on an internal one, each on its own slice of the workspace): one half's tails, ramps and
-        // under-filled kernels overlap the other's — measured 588 vs 572 TFLOP/s at 14 frames, 599 vs 520 at 16, 625 vs 578 at 32
-        // (448 vs 465 at 8: halves of 4 frames fall back to the 64x64 tiles); results are bit-identical.
-        static const int split_min = getenv("VLO_VIT_SPLIT_MIN") ? atoi(getenv("VLO_VIT_SPLIT_MIN")) : 12;
-        const bool split = split_min > 0 && B >= split_min;
-        if (split && !v->st2) {
-            VIT_TRY(hipStreamCreateWithFlags(&v->st2, hipStreamNonBlocking));
-            VIT_TRY(hipEventCreate(&v->ev_fork));
-            VIT_TRY(hipEventCreate(&v->ev_join));
-        }
         VIT_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-        if (split) {
-            const int B0 = B / 2;
-            const size_t frame_bytes = (size_t)3 * v->R * v->R, out_elems = (size_t)(1 + v->ph * v->pw) * e->cfg.hidden_size;
-            hipError_t he = hipEventRecord(v->ev_fork, st);
-            if (he == hipSuccess) he = hipStreamWaitEvent(v->st2, v->ev_fork, 0);
-            rc = he == hipSuccess ? vit_run(e, v->frames_in, B0, v->out_stage, st, true, 0, 0) : VLO_E_HIP;
-            if (!rc) rc = vit_run(e, v->frames_in + B0 * frame_bytes, B - B0, v->out_stage + B0 * out_elems, v->st2, true, B0, 1);
-            if (he == hipSuccess) he = hipEventRecord(v->ev_join, v->st2);
-            if (he == hipSuccess) he = hipStreamWaitEvent(st, v->ev_join, 0);
-            if (!rc && he != hipSuccess) rc = vlo_fail(VLO_E_HIP, std::string("two-branch encode capture: ") + hipGetErrorString(he));
-        } else {
-            rc = vit_run(e, v->frames_in, B, v->out_stage, st);
-        }
+        rc = vit_run_branches(e, v->frames_in, B, v->out_stage, st, true);
         hipError_t ce = hipStreamEndCapture(st, &graph);
         if (rc) {
             if (graph) hipGraphDestroy(graph);
@@ -953,7 +956,7 @@ int vit_vision_tokens(vlo_engine *e, const uint8_t *frames_dev, int B, void *out
     VitState *v = e->vit;
     int rc;
     if ((rc = vit_reserve(e, v, B))) return rc;
-    return vit_run(e, frames_dev, B, out_dev, st, false);
+    return vit_run_branches(e, frames_dev, B, out_dev, st, false);
 }
 
 void vit_destroy(vlo_engine *e) {

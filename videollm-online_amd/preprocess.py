@@ -45,7 +45,7 @@ def encode_frames(engine, frames: torch.Tensor, batch_size: int = 256) -> torch.
     T = frames.shape[0]
     dev = engine.device
     copy_stream = torch.cuda.Stream(device=dev)
-    main = torch.cuda.current_stream(dev)
+    main = torch.cuda.Stream(device=dev)         # a real (non-null) stream: large batches run as two parallel branches (csrc/vit.hip)
     staged = None
 
     def stage(i):
@@ -63,8 +63,10 @@ def encode_frames(engine, frames: torch.Tensor, batch_size: int = 256) -> torch.
         cur, ev = staged
         staged = stage(i + batch_size) if i + batch_size < T else None
         main.wait_event(ev)
-        outs.append(engine.vision_tokens(cur))
+        with torch.cuda.stream(main):
+            outs.append(engine.vision_tokens(cur, stream=main))
         cur.record_stream(main)
+    main.synchronize()
     if not outs:
         return torch.empty(0, engine.cfg.frame_num_tokens, engine.cfg.vision_hidden_size, dtype=torch.bfloat16)
     return torch.cat(outs).cpu()
