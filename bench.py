@@ -208,6 +208,9 @@ def main():
                          "The K timed steps are the LAST K frames of this stream; the frames before them are pre-rolled "
                          "un-timed through the same engine steps on the same session, so the timed region sits at the "
                          "10-minute context the metric is defined on")
+    ap.add_argument("--weight-dtype", default="bf16", choices=["bf16", "fp8"],
+                    help="storage of the streamed Llama projections; fp8 = e4m3 + per-channel scales (BASELINE.json configs[4]); the headline "
+                         "metric is quoted on bf16")
     ap.add_argument("--no-prefetch", action="store_true")
     ap.add_argument("--prefetch-frames", type=int, default=16, help="frames encoded ahead per batched ViT call (16 = two parallel 8-frame branches of the captured encode graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -259,7 +262,7 @@ def main():
     n_frames = max(total, Wm) + 2
     # KV: start prompt + 11 tokens per frame + responses (query + "]\nAssistant:" + 16 tokens, every 10th frame)
     kv_tokens = 64 + 11 * n_frames + (n_frames // 10 + 2) * 24 + 4096
-    cfg = EngineConfig(**shape, vision_hidden_size=1024, vit=VIT_SHAPE, kv_pool_tokens=kv_tokens)
+    cfg = EngineConfig(**shape, vision_hidden_size=1024, vit=VIT_SHAPE, kv_pool_tokens=kv_tokens, weight_dtype=args.weight_dtype)
     log(f"building engine ({args.model} + siglip-l16-384), kv pool {kv_tokens} tokens")
     tp = args.tp and world > 1
     if tp:
@@ -398,7 +401,8 @@ def main():
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "strong" if tp else "weak",
             "vs_baseline": None,
-            "dtype": "bf16", "vit_dtype": "fp16 operands / fp32 accumulate + fp32 residual stream (the reference's GPU autocast, models/vision_live.py:13)",
+            "dtype": "bf16" if args.weight_dtype == "bf16" else "bf16 activations / KV / accumulate-in-fp32, fp8 e4m3 weights (per-output-channel scales)",
+            "vit_dtype": "fp16 operands / fp32 accumulate + fp32 residual stream (the reference's GPU autocast, models/vision_live.py:13)",
             "data": "synthetic",
             "p50_frame_latency_ms": round(statistics.median(costs) * 1e3, 4),
             "p95_frame_latency_ms": round(sorted(costs)[int(0.95 * (len(costs) - 1))] * 1e3, 4),
@@ -425,9 +429,10 @@ def main():
                              "note": "SigLIP-L/16-384 + connector, 384.4 GFLOP/frame (SURVEY.md §8d), fp16 MFMA, measured alone"},
             **({"full_stream": full_stream} if full_stream else {}),
             "stream_hbm_roofline": {"algorithmic_llm_bytes": alg_bytes, "frac_of_hbm_peak": round(alg_bytes / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
-            "roofline": {"bound": "hbm", "kernel": "gemv16_kernel<KF,EPI_SWIGLU> (gate/up projection + SwiGLU)",
+            "roofline": {"bound": "hbm", "kernel": "gemv16_kernel<KF,EPI_SWIGLU> (gate/up projection + SwiGLU)" + (", fp8 weight image" if args.weight_dtype == "fp8" else ""),
                          "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                         "traffic": traffic if args.weight_dtype == "bf16" else None, "traffic_source": traffic_source if args.weight_dtype == "bf16" else None,
                          "launches_timed": n_launch, "avg_launch_us": round(net_ms * 1e3, 2), "avg_bracket_us_raw": round(avg_ms * 1e3, 2),
                          "empty_bracket_us": round(empty_us, 2), "bytes_per_launch": bytes_per_launch},
         }

@@ -557,7 +557,8 @@ int vlo_profile_read(vlo_engine *e, int64_t *launches, double *total_ms, double 
     if (bytes_per_launch) {
         // gate+up weights [2I][H] bf16 streamed once + h [n<=16][H] in + act [n][I] out (n = 11 nominal)
         const double H = e->cfg.hidden_size, I = e->cfg.intermediate_size;
-        *bytes_per_launch = 2.0 * I * H * 2.0 + 11.0 * H * 2.0 + 11.0 * I * 2.0;
+        const double wbytes = e->cfg.weight_dtype == 1 ? 2.0 * I * H + 2.0 * I * 4.0 : 2.0 * I * H * 2.0;   // fp8: codes + fp32 scales
+        *bytes_per_launch = wbytes + 11.0 * H * 2.0 + 11.0 * I * 2.0;
     }
     return VLO_OK;
 }
