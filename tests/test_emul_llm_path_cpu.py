@@ -300,6 +300,30 @@ def test_tensor_parallel_four_ranks_p2p_after_block_path(E):
     eng.close()
 
 
+GQA4 = O.LlmSpec(256, 192, 1, 4, 1, 256, 10000.0, 1e-5, vision_hidden_size=128)      # 4 query heads on one kv head, head_dim 64
+
+
+def test_column_packed_attention_kernel(E):
+    """attn_cols_kernel (llm_ops.hip): the (token, head) columns of a short step packed into 1, 2 and 3 MFMA column tiles (4 heads per kv
+    head: n = 1 / 4, 5 / 8, 9 / 12), the permuted key order inside a 32-key block, eight key sub-splits merged pairwise, two KV splits and a
+    page boundary (cache > 256 tokens), next to attn_chunk_kernel for n = 13 / 16 — all through vlo_llm_step against the oracle."""
+    spec = GQA4
+    w = O.init_llm_weights(spec, seed=31)
+    ref, gold = O.LlamaOracle(spec, w, torch.bfloat16), O.LlamaOracle(spec, w, torch.float32)
+    eng = E.EmulEngine(spec).load_weights(w, O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+    s = eng.new_session()
+    g = torch.Generator().manual_seed(5)
+    rc = gc = None
+    for i, n in enumerate([12, 1, 9, 200, 11, 13, 5, 1, 4, 8, 16, 3]):      # cache: 12, 13, 22, 222, 233, 246, 251, 252, 256, 264, 280, 283
+        x = (torch.randn(n, spec.hidden_size, generator=g) * 0.7).bfloat16()
+        rl, rc = ref.forward(x, rc)
+        gl, gc = gold.forward(x, gc)
+        last, allr = eng.llm_step(s, x)
+        assert eng.session_len(s) == len(rc)
+        _three_way(f"column-packed attention n={n} L={len(rc)}", i, allr, rl, gl)
+    eng.close()
+
+
 @pytest.mark.skipif(not FULL, reason="longer emulation cases: VLO_EMUL_FULL=1")
 @pytest.mark.parametrize("n", [17, 64, 65, 81])
 def test_step_chunking_boundaries(E, n):

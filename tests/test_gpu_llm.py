@@ -404,8 +404,9 @@ def test_full_depth_tinyllama_parity():
 @pytest.mark.parametrize("Lc", [13245, 66000])
 def test_attention_at_stream_length_vs_torch_fp32(Lc):
     """BASELINE configs 2 and 3 end at ~13.2 k and ~66 k cached tokens.  At those lengths (52 / 258 KV pages, the maximum
-    number of KV splits) the chunk attention of a live frame step (n = 11) is checked against plain fp32 torch attention
-    computed on the GPU from the engine's own q and paged K / V^T (read back), last layer, true 8B head geometry.  The
+    number of KV splits) the attention of live steps (frame step n = 11, decode n = 1, and the other column-tile counts / the chunk
+    kernel's range) is checked against plain fp32 torch attention computed on the GPU from the engine's own q and paged K / V^T
+    (read back), last layer, true 8B head geometry.  The
     cache is filled through the 64-token block path."""
     import ctypes as C
     from videollm_online_amd import _C
@@ -419,31 +420,33 @@ def test_attention_at_stream_length_vs_torch_fp32(Lc):
     fill = (torch.randn(Lc, H, generator=g, device="cuda") * 0.5).bfloat16()
     eng.llm_step(sess, fill, want_last=False)
     del fill
-    n = 11
-    eng.llm_step(sess, (torch.randn(n, H, generator=g, device="cuda") * 0.5).bfloat16())
-    L = len(sess)
-    assert L == Lc + n
-    q = torch.empty(16, nh * hd, dtype=torch.bfloat16, device="cuda")
-    a = torch.empty(16, nh * hd, dtype=torch.bfloat16, device="cuda")
-    _C.check(_C.lib().vlo_debug_read(sess._h, 0, _ptr(q), q.numel() * 2, _stream_handle()))
-    _C.check(_C.lib().vlo_debug_read(sess._h, 1, _ptr(a), a.numel() * 2, _stream_handle()))
-    q = q[:n].view(n, nh, hd).float()
-    a = a[:n].view(n, nh, hd).float()
     layer = spec.num_layers - 1
-    pos = torch.arange(Lc, Lc + n, device="cuda")
     worst = 0.0
-    for kvh in range(nkv):
-        K = sess.read_kv(layer, 0, kvh, 0, L).float()                     # [L, hd]
-        V = sess.read_kv(layer, 1, kvh, 0, L).float()
-        for h in range(kvh * (nh // nkv), (kvh + 1) * (nh // nkv)):
-            s = (q[:, h] @ K.T) * hd ** -0.5                              # [n, L]
-            s = s.masked_fill(torch.arange(L, device="cuda")[None, :] > pos[:, None], float("-inf"))
-            ref = torch.softmax(s, dim=-1) @ V                            # [n, hd]
-            err = (a[:, h] - ref).abs().max().item()
-            scale = ref.abs().max().item()
-            worst = max(worst, err / scale)
-            # bf16 output rounding (2^-9 relative) + bf16 P in the P.V MFMA (2^-9 per term, averaged over many keys)
-            assert err <= 2 ** -7 * scale + 1e-4, (Lc, kvh, h, err, scale)
+    L = Lc
+    # n = 11 / 1 / 4 / 8: the column-packed kernel with 3 / 1 / 1 / 2 column tiles (4 heads per kv head); 13 / 16: the chunk kernel
+    for n in (11, 1, 4, 8, 13, 16, 12):
+        eng.llm_step(sess, (torch.randn(n, H, generator=g, device="cuda") * 0.5).bfloat16())
+        pos = torch.arange(L, L + n, device="cuda")
+        L += n
+        assert len(sess) == L
+        q = torch.empty(16, nh * hd, dtype=torch.bfloat16, device="cuda")
+        a = torch.empty(16, nh * hd, dtype=torch.bfloat16, device="cuda")
+        _C.check(_C.lib().vlo_debug_read(sess._h, 0, _ptr(q), q.numel() * 2, _stream_handle()))
+        _C.check(_C.lib().vlo_debug_read(sess._h, 1, _ptr(a), a.numel() * 2, _stream_handle()))
+        q = q[:n].view(n, nh, hd).float()
+        a = a[:n].view(n, nh, hd).float()
+        for kvh in range(nkv):
+            K = sess.read_kv(layer, 0, kvh, 0, L).float()                     # [L, hd]
+            V = sess.read_kv(layer, 1, kvh, 0, L).float()
+            for h in range(kvh * (nh // nkv), (kvh + 1) * (nh // nkv)):
+                s = (q[:, h] @ K.T) * hd ** -0.5                              # [n, L]
+                s = s.masked_fill(torch.arange(L, device="cuda")[None, :] > pos[:, None], float("-inf"))
+                ref = torch.softmax(s, dim=-1) @ V                            # [n, hd]
+                err = (a[:, h] - ref).abs().max().item()
+                scale = ref.abs().max().item()
+                worst = max(worst, err / scale)
+                # bf16 output rounding (2^-9 relative) + bf16 P in the P.V MFMA (2^-9 per term, averaged over many keys)
+                assert err <= 2 ** -7 * scale + 1e-4, (Lc, n, kvh, h, err, scale)
     print(f"[attention Lc={Lc}] worst relative error {worst:.2e}")
     eng.close()
 

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--model", default="llama-3-8b")
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--weight-dtype", default="bf16")
+    ap.add_argument("--lens", default="0,4096,12288", help="cache lengths to time at")
     args = ap.parse_args()
     cfg = EngineConfig(**SHAPES[args.model], kv_pool_tokens=65536, weight_dtype=args.weight_dtype)
     eng = Engine(cfg)
@@ -41,7 +42,7 @@ def main():
     sess = eng.new_session()
     fill = torch.randn(64, H, device="cuda").bfloat16()
     tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("VLO_")) or "defaults"
-    for Lc in (0, 4096, 12288):
+    for Lc in [int(v) for v in args.lens.split(",")]:
         while sess.get_seq_length() < Lc:
             eng.llm_step(sess, fill, want_last=False)
         print(f"[{tag}, {args.weight_dtype}] Lc~{Lc:6d}:  " + "  ".join(f"n={n}: {timed(eng, sess, torch.randn(n, H, device='cuda').bfloat16(), args.iters):.3f} ms"

@@ -40,7 +40,7 @@ hipError_t attention_launch(const unsigned short *q, KvGeom kv, int layer, int n
                             float *part_o, float *part_ml, unsigned short *out, hipStream_t st, int pack_row0 = -1);
 
 // launch geometry of the chunk attention for n new tokens at cache length pos0 (what attention_launch computes first)
-struct AttnGeom { int G, KS, hpw, nhg, nz, chunk, nsplit; float scale; size_t lds_bytes; };
+struct AttnGeom { int G, KS, hpw, nhg, nz, chunk, nsplit, nct; float scale; size_t lds_bytes; };
 hipError_t attention_geometry(const KvGeom &kv, int num_heads, int64_t pos0, int n, AttnGeom *g);
 
 hipError_t embed_gather_launch(const unsigned short *table, const int64_t *ids, int k, int H, int64_t vocab,

@@ -66,6 +66,186 @@ __global__ __launch_bounds__(512) void attn_chunk_kernel(const bf16_t *__restric
 #undef VLO_ATTN_EXIT
 }
 
+// ------------------------------------------------------------------------------------
+// column-packed chunk attention (short steps: G * n <= 16 * NCT columns).  The G query heads that share one kv head TIMES the n new
+// tokens are the COLUMNS of the MFMA tiles (column c = token c / G, head c % G), so one wave serves the whole GQA group and the 8
+// waves of a block all walk DIFFERENT 32-key blocks: every K / V^T byte is fetched by exactly one wave of the chip (in
+// attn_chunk_kernel the head-group waves of a block fetch the same pages twice, which halves the bytes in flight per CU).
+//   * keys are permuted inside a 32-key block so that the lane holding S rows qd*4..+4 of both 16-key tiles owns the 8 CONSECUTIVE
+//     keys qd*8..+8: P^T is a B operand as produced and a V^T fragment is one 16-byte load (two 8-byte loads in attn_chunk_kernel);
+//   * Q fragments live in LDS (shared by the 8 waves), not in registers: the accumulators of 3 column tiles are 96 registers;
+//   * the 8 partial states merge pairwise through LDS in three halving rounds; wave 0 writes the block's partial for the valid columns only.
+// ------------------------------------------------------------------------------------
+template <int HD, int NCT>
+__global__ __launch_bounds__(512) void attn_cols_kernel(const bf16_t *__restrict__ q, KvGeom kv, int layer, int nh, int G, int64_t pos0, int n,
+                                                        int chunk, float scale, float *__restrict__ part_o, float *__restrict__ part_ml) {
+    constexpr int NKK = HD / 32, NDT = HD / 16, KS = 8;
+    extern __shared__ __attribute__((aligned(16))) float4 lds_o[];         // the block's one dynamic LDS array (shared name with attn_chunk_kernel)
+    uint4 *qs = reinterpret_cast<uint4 *>(lds_o);                          // [NCT][NKK][64]   Q fragments (MFMA B operand)
+    float4 *lds_po = lds_o + NCT * NKK * 64;                               // [4][NCT][NDT][64] partial O of the merge rounds
+    float *lds_ml = reinterpret_cast<float *>(lds_po + 4 * NCT * NDT * 64); // [4][NCT][16][2]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int split = blockIdx.x, kvh = blockIdx.y;
+    const int col = lane & 15, qd = lane >> 4;
+    const int L = (int)(pos0 + n);
+    const int c0 = split * chunk, c1 = min(L, c0 + chunk);
+
+    for (int i = w; i < NCT * NKK; i += KS) {
+        const int ct = i / NKK, kk = i - ct * NKK;
+        const int cc = ct * 16 + col, qi = cc / G, h = cc - qi * G;
+        uint4 z = make_uint4(0, 0, 0, 0);
+        if (qi < n) z = *reinterpret_cast<const uint4 *>(q + (size_t)qi * nh * HD + (size_t)(kvh * G + h) * HD + kk * 32 + qd * 8);
+        qs[i * 64 + lane] = z;
+    }
+    int qpos[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) qpos[ct] = (int)pos0 + min((ct * 16 + col) / G, n - 1);
+
+    f32x4 O[NCT][NDT];
+    float mrun[NCT], lrun[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        mrun[ct] = -INFINITY;
+        lrun[ct] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) O[ct][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bf16_t *kbase = kv.k_pool + (size_t)layer * kv.layer_stride;
+    const bf16_t *vbase = kv.vt_pool + (size_t)layer * kv.layer_stride;
+    const int krow = (col >> 2) * 8 + (col & 3);                           // S row `col` of tile t is key krow + 4 t of the block
+    auto load_k = [&](int kt0, frag_ab (&dst)[2][NKK]) {
+        const int page = kv.page_table[kt0 / VLO_PAGE_TOKENS];
+        const bf16_t *kp = kbase + (size_t)page * kv.page_elems + ((size_t)kvh * VLO_PAGE_TOKENS + kt0 % VLO_PAGE_TOKENS) * HD;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk)
+                dst[t][kk] = *reinterpret_cast<const frag_ab *>(kp + (size_t)(krow + 4 * t) * HD + kk * 32 + qd * 8);
+    };
+    frag_ab kf[2][NKK], kn[2][NKK];
+    const int kfirst = c0 + w * 32;
+    if (kfirst < c1) load_k(kfirst, kf);
+    __syncthreads();                                                        // Q fragments staged
+    for (int kt0 = kfirst; kt0 < c1; kt0 += KS * 32) {
+        const int page = kv.page_table[kt0 / VLO_PAGE_TOKENS];
+        const bf16_t *vp = vbase + (size_t)page * kv.page_elems + ((size_t)kvh * HD) * VLO_PAGE_TOKENS + kt0 % VLO_PAGE_TOKENS;
+        frag_ab vf[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) vf[dt] = *reinterpret_cast<const frag_ab *>(vp + (size_t)(dt * 16 + col) * VLO_PAGE_TOKENS + qd * 8);
+        const bool more = kt0 + KS * 32 < c1;
+        if (more) load_k(kt0 + KS * 32, kn);
+        asm volatile("" ::: "memory");                                     // the Q fragments are re-read from LDS every block, never hoisted into registers
+        const int kb = kt0 + qd * 8;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const frag_ab qf = __builtin_bit_cast(frag_ab, qs[(ct * NKK + kk) * 64 + lane]);
+                s0 = mfma_bf16(kf[0][kk], qf, s0);
+                s1 = mfma_bf16(kf[1][kk], qf, s1);
+            }
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = (kb + r <= qpos[ct]) ? s0[r] * scale : -INFINITY;
+                v[4 + r] = (kb + 4 + r <= qpos[ct]) ? s1[r] * scale : -INFINITY;
+            }
+            float tmax = v[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) tmax = fmaxf(tmax, v[j]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(mrun[ct], tmax);
+            const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __expf(mrun[ct] - m_safe);
+            mrun[ct] = m_new;
+            float psum = 0.f;
+            float p[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                p[j] = __expf(v[j] - m_safe);
+                psum += p[j];
+            }
+            const uint4 pk = make_uint4(pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7]));
+            const frag_ab pb = __builtin_bit_cast(frag_ab, pk);
+            lrun[ct] = lrun[ct] * alpha + psum;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                f32x4 o = O[ct][dt];
+                o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
+                O[ct][dt] = mfma_bf16(vf[dt], pb, o);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) kf[t][kk] = kn[t][kk];
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        lrun[ct] += __shfl_xor(lrun[ct], 16, 64);
+        lrun[ct] += __shfl_xor(lrun[ct], 32, 64);
+    }
+    // ---- pairwise merge of the 8 partial states: wave w + half hands its state to wave w
+    for (int half = KS / 2; half >= 1; half >>= 1) {
+        if (w >= half && w < 2 * half) {
+            const int slot = w - half;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                if (qd == 0) {
+                    lds_ml[((slot * NCT + ct) * 16 + col) * 2] = mrun[ct];
+                    lds_ml[((slot * NCT + ct) * 16 + col) * 2 + 1] = lrun[ct];
+                }
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const f32x4 o = O[ct][dt];
+                    lds_po[((size_t)(slot * NCT + ct) * NDT + dt) * 64 + lane] = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+        __syncthreads();
+        if (w < half) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const float mo = lds_ml[((w * NCT + ct) * 16 + col) * 2], lo = lds_ml[((w * NCT + ct) * 16 + col) * 2 + 1];
+                const float M = fmaxf(mrun[ct], mo);
+                const float Ms = (M == -INFINITY) ? 0.f : M;
+                const float wa = __expf(mrun[ct] - Ms), wb = __expf(mo - Ms);          // -inf -> 0
+                lrun[ct] = lrun[ct] * wa + lo * wb;
+                mrun[ct] = M;
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const float4 o = lds_po[((size_t)(w * NCT + ct) * NDT + dt) * 64 + lane];
+                    O[ct][dt][0] = O[ct][dt][0] * wa + o.x * wb;
+                    O[ct][dt][1] = O[ct][dt][1] * wa + o.y * wb;
+                    O[ct][dt][2] = O[ct][dt][2] * wa + o.z * wb;
+                    O[ct][dt][3] = O[ct][dt][3] * wa + o.w * wb;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (w != 0) return;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const int cc = ct * 16 + col, qi = cc / G, h = cc - qi * G;
+        if (qi >= n) continue;
+        const size_t row = ((size_t)split * nh + kvh * G + h) * 16 + qi;
+        if (qd == 0) {
+            part_ml[row * 2] = mrun[ct];
+            part_ml[row * 2 + 1] = lrun[ct];
+        }
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            const f32x4 o = O[ct][dt];
+            *reinterpret_cast<float4 *>(part_o + row * HD + dt * 16 + qd * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 // grid = (nh, n); block = 256 threads = (256 / HD) split-lanes x HD columns
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restrict__ part_o, const float *__restrict__ part_ml,
                                                            int nsplit, int nh, int HD, bf16_t *__restrict__ out, int pack_row0) {
@@ -124,6 +304,13 @@ hipError_t attention_geometry(const KvGeom &kv, int num_heads, int64_t pos0, int
     // keys [0, pos0 + 16 z + n_z), splits beyond that write empty partials
     const int nz = (n + 15) / 16;
     if (nz > 4) return hipErrorInvalidValue;
+    // short steps whose G * n (head, token) columns fit 3 MFMA column tiles take the column-packed kernel: 8 key sub-splits per block
+    static const int cols_off = getenv("VLO_ATTN_COLS") ? !atoi(getenv("VLO_ATTN_COLS")) : 0;
+    g->nct = 0;
+    if (!cols_off && nz == 1 && G * n <= 48 && (hd == 128 || hd == 64)) {
+        g->nct = (G * n + 15) / 16;
+        KS = 8;
+    }
     // splits: ~one block per CU at long context; every wave should see at least one 32-key block
     int target = (L + KS * 32 - 1) / (KS * 32);
     static const int want_blocks = getenv("VLO_ATTN_BLOCKS") ? atoi(getenv("VLO_ATTN_BLOCKS")) : 256;
@@ -137,6 +324,7 @@ hipError_t attention_geometry(const KvGeom &kv, int num_heads, int64_t pos0, int
     g->nsplit = (L + chunk - 1) / chunk;
     g->scale = 1.0f / sqrtf((float)hd);
     g->lds_bytes = (size_t)(KS - 1) * nhg * hpw * ((size_t)(hd / 16) * 64 * 16 + 16 * 2 * 4);
+    if (g->nct) g->lds_bytes = (size_t)g->nct * ((size_t)(hd / 32) * 64 * 16 + 4 * ((size_t)(hd / 16) * 64 * 16 + 16 * 2 * 4));
     return hipSuccess;
 }
 
@@ -156,8 +344,30 @@ hipError_t attention_launch(const unsigned short *q, KvGeom kv, int layer, int n
         hipFuncSetAttribute((const void *)attn_chunk_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute((const void *)attn_chunk_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute((const void *)attn_chunk_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void *)attn_cols_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void *)attn_cols_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void *)attn_cols_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void *)attn_cols_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void *)attn_cols_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void *)attn_cols_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
         attr_done = true;
     }
+#define VLO_ATTN_COLS(HD_, NCT_) \
+    hipLaunchKernelGGL((attn_cols_kernel<HD_, NCT_>), grid, dim3(512), lds, st, q, kv, layer, num_heads, G, pos0, n, chunk, scale, part_o, part_ml)
+    if (ag.nct) {
+        if (hd == 128 && ag.nct == 1) VLO_ATTN_COLS(128, 1);
+        else if (hd == 128 && ag.nct == 2) VLO_ATTN_COLS(128, 2);
+        else if (hd == 128) VLO_ATTN_COLS(128, 3);
+        else if (ag.nct == 1) VLO_ATTN_COLS(64, 1);
+        else if (ag.nct == 2) VLO_ATTN_COLS(64, 2);
+        else VLO_ATTN_COLS(64, 3);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(attn_combine_kernel, dim3(num_heads, n), dim3(256), 0, st, part_o, part_ml, nsplit, num_heads, hd, out, pack_row0);
+        return hipGetLastError();
+    }
+#undef VLO_ATTN_COLS
 #define VLO_ATTN(HD_, HPW_) \
     hipLaunchKernelGGL((attn_chunk_kernel<HD_, HPW_>), grid, block, lds, st, q, kv, layer, num_heads, G, KS, pos0, n, chunk, scale, part_o, part_ml)
     if (hd == 128 && hpw == 2) VLO_ATTN(128, 2);
