@@ -32,7 +32,7 @@ class StreamTokens:
 class LiveInfer:
     def __init__(self, model: LiveModel, tokens: StreamTokens | None = None, tokenizer=None, frame_fps: float = 2,
                  system_prompt: str = "", prefetch: bool = True, prefetch_frames: int = 2, schedule=None,
-                 max_new_tokens: int = 100, record: int = 65536):
+                 max_new_tokens: int = 100, record: int = 65536, encode_stream=None):
         self.model = model
         self.engine = model.engine
         self.tokenizer = tokenizer
@@ -69,7 +69,9 @@ class LiveInfer:
         # batches all pending frames the same way, demo/inference.py:105-106); the video is fully loaded up front
         self.schedule = schedule           # frame_idx -> None | (speak: bool, num_tokens: int)  (throughput runs)
         self._main = torch.cuda.current_stream(dev)
-        self._enc = torch.cuda.Stream(dev)
+        # the encode stream: the caller's (e.g. the main stream itself: encodes then run BETWEEN Llama steps instead of beside
+        # them), or a dedicated one
+        self._enc = encode_stream if encode_stream is not None else torch.cuda.Stream(dev)
         self._tok_dev = torch.zeros(1, dtype=torch.long, device=dev)
         self._p_dev = torch.zeros(1, dtype=torch.float32, device=dev)
         self._tok_host = torch.zeros(1, dtype=torch.long).pin_memory()
