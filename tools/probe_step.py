@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--weight-dtype", default="bf16")
     ap.add_argument("--lens", default="0,4096,12288", help="cache lengths to time at")
+    ap.add_argument("--ns", default="1,11", help="new tokens per step")
     args = ap.parse_args()
     cfg = EngineConfig(**SHAPES[args.model], kv_pool_tokens=65536, weight_dtype=args.weight_dtype)
     eng = Engine(cfg)
@@ -46,7 +47,7 @@ def main():
         while sess.get_seq_length() < Lc:
             eng.llm_step(sess, fill, want_last=False)
         print(f"[{tag}, {args.weight_dtype}] Lc~{Lc:6d}:  " + "  ".join(f"n={n}: {timed(eng, sess, torch.randn(n, H, device='cuda').bfloat16(), args.iters):.3f} ms"
-                                                   for n in (1, 11)), flush=True)
+                                                   for n in [int(v) for v in args.ns.split(",")]), flush=True)
 
 
 if __name__ == "__main__":
