@@ -103,3 +103,59 @@ def test_frame_ring_feeds_liveinfer_like_a_resident_video():
     assert ring.head == 12 and ring.tail >= 10 and ring.frames.shape[0] == 8
     li.reset()
     eng.close()
+
+
+FAKE_DECODER = (
+    "import sys, numpy as np\n"
+    "n, H, W, seed = map(int, sys.argv[1:5])\n"
+    "rng = np.random.default_rng(seed)\n"
+    "base = rng.integers(0, 256, (n, H // 6 + 1, W // 6 + 1, 3), dtype=np.uint8)\n"
+    "f = np.repeat(np.repeat(base, 6, axis=1), 6, axis=2)[:, :H, :W]\n"
+    "sys.stdout.buffer.write(np.ascontiguousarray(f).tobytes())\n")
+
+
+@pytest.mark.gpu
+def test_decoder_pipe_feeds_liveinfer():
+    """An external decoder process (a Python stand-in for `ffmpeg ... -f rawvideo -pix_fmt rgb24 -`) writes 14 packed RGB24 frames to a
+    pipe; DecoderFeed pushes them into a 6-frame ring from its own thread under back-pressure while LiveInfer consumes the stream and
+    waits for frames that have not arrived yet: same events as load_video on the same frames held resident."""
+    import sys
+    import numpy as np
+    from videollm_online_amd.ingest import DecoderFeed, FrameRing
+    spec, vspec = O.LLM_SPECS["toy128"], O.VIT_SPECS["toy"]
+    w, vw = O.init_llm_weights(spec, seed=3), O.init_vit_weights(vspec, seed=1)
+    toks = O.default_tokens(spec, seed=7, n_start=19)
+    n, H, W = 14, 72, 128
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, (n, H // 6 + 1, W // 6 + 1, 3), dtype=np.uint8)
+    raw = torch.from_numpy(np.ascontiguousarray(np.repeat(np.repeat(base, 6, axis=1), 6, axis=2)[:, :H, :W]))
+    eng, li = _build(spec, vspec, w, vw, toks, prefetch=True, prefetch_frames=2, max_new_tokens=4)
+    q = "Please narrate the video in real time."
+
+    def drive():
+        li.input_query_stream(q, video_time=0.0)
+        for i in range(n):
+            li.input_video_stream(i / 2)
+            li()
+        return list(li.trace)
+
+    li.reset()
+    li.load_video(raw.cuda())
+    a = drive()
+    li.reset()
+    ring = FrameRing(eng, H, W, capacity=6, chunk=4)
+    feed = DecoderFeed([sys.executable, "-c", FAKE_DECODER, str(n), str(H), str(W), "5"], ring)
+    li.load_video(ring)
+    b = drive()
+    feed.join(30)
+    assert feed.frames == n and ring.closed and ring.head == n
+    assert a == b and len(a) >= n
+    li.reset()
+    # a decoder that dies mid-frame is an error, not a shorter video
+    ring2 = FrameRing(eng, H, W, capacity=6, chunk=4)
+    bad = DecoderFeed([sys.executable, "-c", "import sys; sys.stdout.buffer.write(b'x' * 1000)"], ring2)
+    with pytest.raises(IOError):
+        bad.join(30)
+    assert ring2.closed and ring2.head == 0
+    eng.close()
+

@@ -41,3 +41,69 @@ def test_ingest_layout_identity_and_pad():
     fr = rng.integers(0, 256, (1, 90, 160, 3), dtype=np.uint8)
     out = G.ingest(fr, 64)                                           # 160x90 -> 64x36, y0 = 14
     assert out.shape == (1, 3, 64, 64) and not out[:, :, :14].any() and not out[:, :, 50:].any() and out[:, :, 14:50].any()
+
+
+def test_raw_frame_reader_and_decoder_command():
+    """The host half of the decoder pipe (videollm-online_amd/ingest.py): whole frames out of a byte stream in chunks, a short last
+    chunk, a stream that ends inside a frame; the decoder argv is the reference's `ffmpeg -i src -r fps` (data/utils.py:62-64) minus
+    its scale / pad filter, writing packed RGB24 to stdout."""
+    import io
+    import threading
+    import pytest
+    import torch
+    from videollm_online_amd import ingest
+    H, W, n = 6, 10, 7
+    data = np.random.default_rng(0).integers(0, 256, (n, H, W, 3), dtype=np.uint8)
+    chunks = list(ingest.read_raw_frames(io.BytesIO(data.tobytes()), H, W, chunk=3))
+    assert [c.shape[0] for c in chunks] == [3, 3, 1]
+    assert np.array_equal(torch.cat(chunks).numpy(), data)
+    assert list(ingest.read_raw_frames(io.BytesIO(b""), H, W, chunk=3)) == []
+    with pytest.raises(IOError):
+        list(ingest.read_raw_frames(io.BytesIO(data.tobytes()[:-5]), H, W, chunk=3))
+
+    class DribblingPipe:                                   # a pipe returns what is there, not what was asked for
+        def __init__(self, b):
+            self.b, self.i = b, 0
+
+        def read(self, k):
+            k = min(k, 37)
+            out = self.b[self.i:self.i + k]
+            self.i += len(out)
+            return out
+    assert np.array_equal(torch.cat(list(ingest.read_raw_frames(DribblingPipe(data.tobytes()), H, W, chunk=4))).numpy(), data)
+
+    cmd = ingest.decoder_command("v.mp4", 2, "./ffmpeg/ffmpeg")
+    assert cmd[0] == "./ffmpeg/ffmpeg" and cmd[cmd.index("-i") + 1] == "v.mp4" and cmd[cmd.index("-r") + 1] == "2"
+    assert cmd[-5:] == ["-f", "rawvideo", "-pix_fmt", "rgb24", "-"] and "-vf" not in cmd
+    assert ingest.probe_command("v.mp4")[-1] == "v.mp4"
+
+    class FakeRing:                                        # the feeder thread against a ring without a GPU
+        layout, chunk = "THWC", 3
+
+        def __init__(self):
+            self.got, self.closed, self.frames = [], False, torch.zeros(1)
+            self.H, self.W = H, W
+
+        def wait_free(self, k, timeout=None):
+            return True
+
+        def push(self, f):
+            self.got.append(f.clone())
+
+        def close(self):
+            self.closed = True
+    import sys
+    ring = FakeRing()
+    code = "import sys; sys.stdout.buffer.write(bytes(range(256)) * 100)"      # 25 600 bytes = 142.2 frames of 180 bytes
+    feed = ingest.DecoderFeed([sys.executable, "-c", code], ring)
+    with pytest.raises(IOError):
+        feed.join(30)
+    assert ring.closed and sum(f.shape[0] for f in ring.got) == 141               # whole chunks before the torn one
+    ring = FakeRing()
+    ok = ingest.DecoderFeed([sys.executable, "-c", "import sys; sys.stdout.buffer.write(bytes(180 * 5))"], ring)
+    ok.join(30)
+    assert ok.frames == 5 and ring.closed
+    bad_exit = ingest.DecoderFeed([sys.executable, "-c", "import sys; sys.stdout.buffer.write(bytes(180)); sys.exit(3)"], FakeRing())
+    with pytest.raises(RuntimeError):
+        bad_exit.join(30)
+

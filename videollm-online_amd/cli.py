@@ -19,7 +19,8 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=100)                 # demo/cli.py:31 runs 100 iterations
     ap.add_argument("--frame_fps", type=float, default=2.0)
-    ap.add_argument("--video", default=None, help="torch-saved uint8 tensor [T,3,384,384]; default: synthetic frames")
+    ap.add_argument("--video", default=None, help="torch-saved uint8 frames (.pt: [T,3,384,384] prepared, or decoded [T,H,W,3] of any size), or "
+                                                  "a video file decoded by an ffmpeg binary through a pipe (ingest.open_video); default: synthetic frames")
     ap.add_argument("--query", default="Please narrate the video in real time.")
     ap.add_argument("--out", default="history.json")
     ap.add_argument("--base", default=None)
@@ -52,7 +53,12 @@ def main(argv=None):
     interval = toks.interval_id if toks is not None else tokenizer.convert_tokens_to_ids(",")
     model = LiveModel(eng, eos_token_id=eos, frame_token_interval_id=interval)
     liveinfer = LiveInfer(model, tokens=toks, tokenizer=tokenizer, frame_fps=args.frame_fps)
-    video = torch.load(args.video) if args.video else B.gpu_synthetic_frames(args.frames + 1)
+    feed = None
+    if args.video and not args.video.endswith(".pt"):
+        from .ingest import open_video                  # demo/cli.py:13-22: ffmpeg at frame_fps; scale + pad happen on the device
+        video, feed = open_video(eng, args.video, args.frame_fps)
+    else:
+        video = torch.load(args.video) if args.video else B.gpu_synthetic_frames(args.frames + 1)
     liveinfer.load_video(video)
     liveinfer.input_query_stream(args.query, video_time=0.0)                      # demo/cli.py:23
     if toks is not None and args.query not in toks.query_ids:
@@ -75,6 +81,8 @@ def main(argv=None):
             print(response)
         if not query and not response:
             history["conversation"].append({"time": liveinfer.video_time, "fps": fps, "cost": timecosts[-1]})
+    if feed is not None:
+        feed.proc.kill()                                 # the loop may stop before the file ends
     json.dump(history, open(args.out, "w"), indent=4)
     print(f"Average Processing FPS: {fps:.1f}.  The conversation history has been saved to {args.out}.")
     return history

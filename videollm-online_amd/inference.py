@@ -65,6 +65,7 @@ class LiveInfer:
         self._added_stream_generation_ids = list(tokens.stream_generation_ids)
         # device plumbing
         self.prefetch = prefetch
+        self.frame_wait_s = 10.0           # how long input_video_stream waits for a frame a FrameRing's feeder has not pushed yet
         self.prefetch_frames = max(1, prefetch_frames)   # frames encoded ahead in ONE batched ViT call (the reference
         # batches all pending frames the same way, demo/inference.py:105-106); the video is fully loaded up front
         self.schedule = schedule           # frame_idx -> None | (speak: bool, num_tokens: int)  (throughput runs)
@@ -181,6 +182,8 @@ class LiveInfer:
         frame_idx = int(video_time * self.frame_fps)
         if frame_idx > self.last_frame_idx:
             ranger = range(self.last_frame_idx + 1, frame_idx + 1)
+            if self._ring is not None and not self._ring.closed:
+                self._ring.wait_for(ranger.stop, self.frame_wait_s)   # a live feed: the frames of this instant may still be on their way
             self._encode_async(ranger.start, ranger.stop)
             for r in ranger:
                 if r not in self._encoded:
