@@ -161,6 +161,7 @@ static inline float atomicAdd(float *p, float v) {          // relaxed fp32 atom
 static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 #define __builtin_amdgcn_s_sleep(x) sched_yield()
 #define __builtin_amdgcn_s_barrier() __syncthreads()
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)      /* instruction-scheduling fence: nothing to order on the CPU */
 // OCP e4m3fn pair -> two floats (v_cvt_pk_f32_fp8): bytes 0,1 (sel = false) or 2,3 of src
 static inline float emul_fp8_e4m3(unsigned b) {
     const unsigned e = (b >> 3) & 15u, m = b & 7u;

@@ -379,7 +379,8 @@ def test_frame_ingest_kernels_match_the_oracle(E, H, W, R, layout, a):
     eng.close()
 
 
-@pytest.mark.parametrize("n,N,K", [(11, 64, 512), (3, 48, 1024), (16, 32, 2048)])
+@pytest.mark.parametrize("n,N,K", [(11, 64, 512), (3, 48, 1024), (16, 32, 2048),
+                                   (5, 8336, 512)])      # 521 tiles: two groups per block (both register sets re-loaded), last group has one tile
 def test_fp8_weight_image_gemv(E, n, N, K):
     """The fp8 e4m3 weight image (two MFMA fragments per 16-byte lane load, e4m3 -> bf16 expansion in registers, per-output-channel
     scale in the epilogue; csrc/gemv.hip, gemv_body.inc WQ = 1) against an fp64 matmul of the dequantised weights; quantisation by
