@@ -194,3 +194,25 @@ def test_two_branch_batched_encode_matches_single_branch():
             print(f"[two-branch encode B={B}] max |diff| {d:.3g} (scale {scale:.3g}), bit-equal {bool(torch.equal(out, eager))}")
             assert d <= 2 * 2 ** -8 * scale
     eng.close()
+
+
+def test_large_batch_tiles_match_small_batch_tiles():
+    """From 16 frames in one launch the wide GEMMs run on 256x256 tiles / 16 waves (csrc/vit.hip::gemm_launch); smaller batches on
+    128x128 tiles / 8 waves.  Every output element accumulates its K range in the same order on both, so 34 frames encoded at once
+    (two branches of 17: 9792 rows, a partial last tile) must agree with the same frames encoded 8 at a time."""
+    spec, vspec = O.LLM_SPECS["tinyllama-2l"], O.VIT_SPECS["siglip-l16-384-2l"]
+    w, vw = O.init_llm_weights(spec, seed=5), O.init_vit_weights(vspec, seed=1)
+    eng = _engine(spec, vspec, w, vw)
+    frames = O.synthetic_frames(34, vspec.image_size, seed=22).cuda()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        big = eng.visual_embed(frames, stream=st).float()
+    st.synchronize()                     # the engine's encode workspace is shared: order the two streams
+    small = torch.cat([eng.visual_embed(frames[i:i + 8]).float() for i in range(0, 34, 8)])
+    torch.cuda.synchronize()
+    d = (big - small).abs().max().item()
+    scale = small.abs().max().item()
+    print(f"[256-tile vs 128-tile encode] max |diff| {d:.3g} (scale {scale:.3g}), bit-equal {bool(torch.equal(big, small))}")
+    assert d <= 2 ** -7 * scale            # two bf16 ulps of the largest output; bit-equal expected
+    eng.close()
+

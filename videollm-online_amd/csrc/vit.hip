@@ -327,7 +327,15 @@ static hipError_t gemm_launch(GemmArgs a, hipStream_t st) {
         static const bool use_glds = getenv("VLO_VIT_GLDS") ? atoi(getenv("VLO_VIT_GLDS")) != 0 : true;
         // measured alternatives that lost at 8-14 frames: 3 / 4 direct-to-LDS stages (one block per CU), 4 waves of
         // 64x64 per block
-        if (use_glds && EP != EP_PATCH)
+        // from 16 frames in one launch (M >= 9216 rows): 256x256 tiles on SIXTEEN waves (4 x 4, each 64x64; 128 KiB of LDS, one block per
+        // CU).  The same waves per SIMD as two 128x128 blocks, half the L2 -> LDS bytes and a third less LDS read traffic per FLOP:
+        // 32 / 64 / 128 frames 646 / 621 / 611 -> 675 / 681 / 673 TFLOP/s, 16 frames in one branch 527 -> 564; below that the grid is too
+        // small for one block per CU (the same tile on 8 waves of 128x64 measured slower at every size)
+        static const int min256 = getenv("VLO_VIT_256_MIN_ROWS") ? atoi(getenv("VLO_VIT_256_MIN_ROWS")) : 9216;   // 0 = never
+        if (use_glds && EP != EP_PATCH && min256 > 0 && a.N % 256 == 0 && a.M >= min256) {
+            dim3 g2(a.N / 256, (a.M + 255) / 256, 1);
+            hipLaunchKernelGGL((vit_gemm_kernel<256, 256, 4, 4, EP, 0, 2>), g2, dim3(1024), 0, st, a);
+        } else if (use_glds && EP != EP_PATCH)
             hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 4, EP, 0, 2>), grid, dim3(512), 0, st, a);
         else
             hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 4, EP, 2>), grid, dim3(512), 0, st, a);
