@@ -17,6 +17,12 @@ independent, there is no exchange step) under torchrun, barrier + max-over-ranks
 GPUs (``--tp``) in child processes, once with RCCL all-reduces (``"tp"``) and once with the one-shot
 peer-to-peer all-reduce over xGMI (``"tp_p2p"``); a failure there is recorded, never fatal.
 
+The K timed steps are the LAST K frames of the configuration's stream (1200 frames = 10 min @ 2 FPS for the headline
+configuration): the first 1200 - K frames are streamed un-timed through the same engine steps on the same session (the
+pre-roll), frames encoded ahead are dropped at the boundary, and the clock runs over frames 1200-K .. 1199 at the context
+the metric is defined on (K = 20: KV 15.5 k -> 15.8 k tokens).  ``full_stream`` reports all 1200 frames.
+``--weight-dtype fp8`` streams the Llama projections as e4m3 + per-channel scales (BASELINE.json configs[4]'s LLM half).
+
 Prints ONE JSON line (rank 0) with the driver's contract keys plus ``roofline`` (dominant kernel =
 the gate/up weight-streaming GEMV, timed live with HIP events on its own stream) and
 ``cpu_baseline`` (the CPU oracle on a bounded sample of the same workload, rank 0, N=1 only).
