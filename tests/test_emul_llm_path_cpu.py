@@ -324,6 +324,45 @@ def test_column_packed_attention_kernel(E):
     eng.close()
 
 
+VIT256_CHILD = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from oracle import vlo_oracle as O
+from tests.hip_emul import emul_engine as E
+spec = O.LlmSpec(128, 192, 1, 2, 2, 256, 10000.0, 1e-5, vision_hidden_size=256)
+vspec = O.VitSpec(hidden_size=256, intermediate_size=512, num_layers=1, num_heads=4, image_size=96, patch_size=16, pooled=(3, 3))
+w, vw = O.init_llm_weights(spec, seed=3), O.init_vit_weights(vspec, seed=1)
+frames = O.synthetic_frames(3, vspec.image_size, seed=7)
+gold = O.LlamaOracle(spec, w, torch.float32).visual_embed(vw, vspec, frames)
+ref = O.LlamaOracle(spec, w, torch.bfloat16)
+amp = ref.visual_embed(vw, vspec, frames, mm_dtype=torch.float16)
+cpu = ref.visual_embed(vw, vspec, frames)
+eng = E.EmulEngine(spec, vit=vspec).load_weights({**w, **vw}, O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+out = eng.visual_embed(frames)
+scale = gold.abs().max().item()
+e = (out.float() - gold).abs().max().item()
+a = (amp.float() - gold).abs().max().item()
+r = (cpu.float() - gold).abs().max().item()
+print(f"[emul vit 256-tile] engine err {e:.4g} fp16-autocast err {a:.4g} cpu-ref err {r:.4g} scale {scale:.3g}")
+assert e <= 2.0 * max(a, r) + 2 * 2 ** -8 * scale, (e, a, r)
+eng.close()
+print("OK256")
+"""
+
+
+def test_vit_gemm_256_tile_kernel_in_emulation(E):
+    """vit_gemm_kernel<256,256,4,4,...> (16 waves, one 1024-thread block per tile; csrc/vit.hip::gemm_launch takes it from 9216 rows)
+    forced onto a small tower (hidden 256: N = 256 / 512 / 768, M = 108 rows = one partial tile) in a child process — the dispatch
+    thresholds are read once per process — against the oracle with the tolerance of the ViT tests."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VLO_VIT_BIG_TILES="1", VLO_VIT_256_MIN_ROWS="1")
+    r = subprocess.run([sys.executable, "-c", VIT256_CHILD % root], env=env, capture_output=True, text=True, timeout=900)
+    print(r.stdout[-600:])
+    assert r.returncode == 0 and "OK256" in r.stdout, r.stderr[-2000:]
+
+
 @pytest.mark.skipif(not FULL, reason="longer emulation cases: VLO_EMUL_FULL=1")
 @pytest.mark.parametrize("n", [17, 64, 65, 81])
 def test_step_chunking_boundaries(E, n):
