@@ -195,7 +195,8 @@ def run_tp_leg(args, rank, world, local, allreduce="rccl", port_offset=17):
            "one-shot peer-to-peer all-reduce over xGMI fused with residual add + RMSNorm, x2 per layer, + p2p logits gather; no RCCL")
     r.update(parallelism=d["config"]["parallelism"], stream_hbm_roofline=d.get("stream_hbm_roofline"), wall_s=round(time.time() - t0, 1),
              exchange=d["config"].get("tp_exchange"),
-             note=f"ONE stream, Llama tensor-parallel over the same GPUs ({how}), ViT replicated; measured by "
+             note=f"ONE stream, Llama tensor-parallel over the same GPUs ({how}), ViT "
+                  f"{'frame-parallel (one all-gather of the frame embeddings per batch)' if allreduce == 'rccl' and getattr(args, 'tp_vit', '') == 'frame-parallel' else 'replicated'}; measured by "
                   f"`bench.py --tp --tp-allreduce {allreduce}` in child processes")
     return r
 
