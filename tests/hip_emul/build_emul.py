@@ -43,8 +43,11 @@ def build(force=False, sanitize=None):
         # dynamic shared memory: `extern __shared__ T name[]` refers to an array the harness defines (emul_stubs.cpp)
         src = re.sub(r"extern\s+__shared__", "extern", src)
         # GPU assembly (explicit s_waitcnt around direct-to-LDS loads / release sequences): the emulated loads are synchronous
+        # vmcnt waits retire emulated direct-to-LDS loads (hip_emul.h: VLO_EMUL_GLDS=late lands them only there); other counters: nothing to wait for
+        src = re.sub(r'asm volatile\("s_waitcnt vmcnt\(0\)[^"]*"\s*:::\s*"memory"\);', "emul_vmcnt(0);", src)
+        src = re.sub(r'asm volatile\("s_waitcnt vmcnt\(%0\)"\s*::\s*"n"\(([^;]*)\)\s*:\s*"memory"\);', r"emul_vmcnt(\1);", src)   # counted form
         src = re.sub(r'asm volatile\("s_waitcnt[^"]*"\s*:::\s*"memory"\);', ";", src)
-        src = re.sub(r'asm volatile\("s_waitcnt vmcnt\(%0\)"\s*::\s*"n"\([^;]*\)\s*:\s*"memory"\);', ";", src)   # counted form
+        src = re.sub(r'asm volatile\("s_waitcnt lgkmcnt\(%0\)"\s*::\s*"n"\([^;]*\)\s*:\s*"memory"\);', ";", src)
         src = re.sub(r'asm volatile\(""\s*:\s*"\+v"\(\w+\)\);', ";", src)      # optimisation barrier on a VGPR value
         return src
 

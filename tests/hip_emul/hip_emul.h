@@ -78,7 +78,34 @@ struct emul_block_ctx {
 static thread_local emul_dim3 threadIdx, blockIdx, blockDim, gridDim;
 static thread_local emul_block_ctx *emul_ctx = nullptr;
 
-static inline void __syncthreads() { pthread_barrier_wait(&emul_ctx->block_bar); }
+// ---- direct-to-LDS loads (global_load_lds) ---------------------------------------------------------------------------------
+// Two landing models, chosen with VLO_EMUL_GLDS: "sync" (default) — the bytes land when the instruction issues, the EARLIEST the
+// hardware allows (a restage that comes too early overwrites data another thread still reads: TSan sees the race); "late" — the
+// bytes land only when the issuing thread executes the s_waitcnt vmcnt(N) that retires the load (oldest first, N stay in flight),
+// the LATEST the hardware allows: a fragment read that is not ordered behind the covering vmcnt + barrier reads stale LDS and the
+// parity tests fail deterministically.  The build patches `asm volatile("s_waitcnt vmcnt(N)")` into emul_vmcnt(N).
+struct emul_glds_op { void *dst; const void *src; int size; };
+static thread_local std::vector<emul_glds_op> emul_glds_q;
+static inline bool emul_glds_late() {
+    static const bool late = getenv("VLO_EMUL_GLDS") && !strcmp(getenv("VLO_EMUL_GLDS"), "late");
+    return late;
+}
+static inline void emul_vmcnt(int n) {
+    size_t done = 0;
+    while (emul_glds_q.size() - done > (size_t)n) {
+        const emul_glds_op &o = emul_glds_q[done++];
+        memcpy(o.dst, o.src, (size_t)o.size);
+    }
+    if (done) emul_glds_q.erase(emul_glds_q.begin(), emul_glds_q.begin() + (long)done);
+}
+static inline void emul_glds(const void *g, void *l, int size) {
+    if (emul_glds_late()) emul_glds_q.push_back({l, g, size});
+    else memcpy(l, g, (size_t)size);
+}
+// __syncthreads() = s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier (hipcc drains pending LDS writes before the workgroup barrier);
+// the raw __builtin_amdgcn_s_barrier() does not wait for anything
+static inline void emul_raw_barrier() { pthread_barrier_wait(&emul_ctx->block_bar); }
+static inline void __syncthreads() { emul_vmcnt(0); emul_raw_barrier(); }
 
 template <class T>
 static inline T emul_shfl_from(T v, int src_lane_of_me /* computed from my lane */) {
@@ -160,7 +187,9 @@ static inline float atomicAdd(float *p, float v) {          // relaxed fp32 atom
 }
 static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 #define __builtin_amdgcn_s_sleep(x) sched_yield()
-#define __builtin_amdgcn_s_barrier() __syncthreads()
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_s_barrier() emul_raw_barrier()
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)      /* instruction-scheduling fence: nothing to order on the CPU */
 // OCP e4m3fn pair -> two floats (v_cvt_pk_f32_fp8): bytes 0,1 (sel = false) or 2,3 of src
 static inline float emul_fp8_e4m3(unsigned b) {
@@ -181,7 +210,7 @@ static inline emul_f32x2 emul_cvt_pk_f32_fp8(int src, bool hi) {
 #define __builtin_nontemporal_load(p) (*(p))
 
 // direct-to-LDS load: every lane's `size` bytes land at the wave-uniform LDS base + lane * size
-#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) memcpy((char *)(l) + (threadIdx.x & 63) * (size), (const void *)(g), (size))
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emul_glds((const void *)(g), (char *)(l) + (threadIdx.x & 63) * (size), (size))
 
 // ---- stream capture / graphs: launches and copies issued while the host thread captures are recorded, a graph launch replays them
 struct emul_graph { std::vector<std::function<void()>> ops; };
@@ -218,6 +247,7 @@ static inline void emul_launch(emul_dim3 grid, emul_dim3 block, const std::funct
                     for (unsigned bx = 0; bx < grid.x; ++bx) {
                         blockIdx = emul_dim3(bx, by, bz);
                         body();
+                        emul_vmcnt(0);                       // a wave ends only when its loads have landed
                         pthread_barrier_wait(&end_bar);      // the block is over: its shared memory may be reused
                     }
         });
@@ -252,6 +282,7 @@ static inline void emul_launch_concurrent(emul_dim3 grid, emul_dim3 block, const
                             gridDim = grid;
                             emul_ctx = &ctx;
                             body();
+                            emul_vmcnt(0);
                         });
                     for (auto &th : ts) th.join();
                     _exit(0);

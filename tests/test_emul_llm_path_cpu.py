@@ -363,6 +363,66 @@ def test_vit_gemm_256_tile_kernel_in_emulation(E):
     assert r.returncode == 0 and "OK256" in r.stdout, r.stderr[-2000:]
 
 
+VITPP_CHILD = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from oracle import vlo_oracle as O
+from tests.hip_emul import emul_engine as E
+spec = O.LlmSpec(128, 192, 1, 2, 2, 256, 10000.0, 1e-5, vision_hidden_size=256)
+vspec = O.VitSpec(hidden_size=256, intermediate_size=512, num_layers=1, num_heads=4, image_size=96, patch_size=16, pooled=(3, 3))
+w, vw = O.init_llm_weights(spec, seed=3), O.init_vit_weights(vspec, seed=1)
+frames = O.synthetic_frames(8, vspec.image_size, seed=7)          # 288 token rows: one full 256-row tile + a partial one
+gold = O.LlamaOracle(spec, w, torch.float32).visual_embed(vw, vspec, frames)
+ref = O.LlamaOracle(spec, w, torch.bfloat16)
+amp = ref.visual_embed(vw, vspec, frames, mm_dtype=torch.float16)
+cpu = ref.visual_embed(vw, vspec, frames)
+eng = E.EmulEngine(spec, vit=vspec).load_weights({**w, **vw}, O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+out = eng.visual_embed(frames)
+scale = gold.abs().max().item()
+e = (out.float() - gold).abs().max().item()
+a = (amp.float() - gold).abs().max().item()
+r = (cpu.float() - gold).abs().max().item()
+print(f"[emul vit ping-pong] engine err {e:.4g} fp16-autocast err {a:.4g} cpu-ref err {r:.4g} scale {scale:.3g}")
+assert e <= 2.0 * max(a, r) + 2 * 2 ** -8 * scale, (e, a, r)
+if len(sys.argv) > 1:
+    torch.save(out, sys.argv[1])
+eng.close()
+print("OKPP")
+"""
+
+
+def _vitpp_child(env_extra, save=None):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, "-c", VITPP_CHILD % root] + ([save] if save else []), env=env, capture_output=True, text=True, timeout=1800)
+    print(r.stdout[-400:])
+    assert r.returncode == 0 and "OKPP" in r.stdout, r.stderr[-2000:]
+
+
+def test_vit_gemm_pingpong_kernel_in_emulation(E):
+    """vit_gemm_pp_kernel (256 x 256 tiles, two wave groups alternating read / MFMA segments, half-tiles restaged by direct-to-LDS
+    loads under COUNTED vmcnt waits; csrc/vit_gemm.inc) forced onto a small tower (hidden 256: N = 256 / 512 / 768, K = 256 / 512,
+    288 rows = a full tile + a partial one, 2 column groups in the XCD split where the width allows), with the emulated direct-to-LDS
+    loads landing as LATE as the hardware may land them (VLO_EMUL_GLDS=late: only at the vmcnt wait that retires them) — a fragment
+    read that is not covered by its wait + barriers reads stale shared memory and fails here — against the oracle."""
+    _vitpp_child(dict(VLO_VIT_PP_MIN_ROWS="1", VLO_VIT_PP_BM="256", VLO_VIT_PP_CB="2", VLO_EMUL_GLDS="late"))
+
+
+@pytest.mark.skipif(not FULL, reason="longer emulation cases: VLO_EMUL_FULL=1")
+def test_vit_gemm_pingpong_kernel_bit_identical_to_small_tile_kernels(E, tmp_path):
+    """Same MFMA, same k order: the ping-pong kernel's outputs equal the 64 x 64 / 128 x 128 kernels' bit for bit, for both tile
+    heights and both landing models of the emulated direct-to-LDS loads."""
+    base = str(tmp_path / "base.pt")
+    _vitpp_child(dict(VLO_VIT_PP="0"), base)
+    want = torch.load(base)
+    for bm, mode, cb in (("256", "late", "0"), ("128", "late", "2"), ("256", "sync", "2"), ("128", "sync", "0")):
+        f = str(tmp_path / f"pp_{bm}_{mode}.pt")
+        _vitpp_child(dict(VLO_VIT_PP_MIN_ROWS="1", VLO_VIT_PP_BM=bm, VLO_VIT_PP_CB=cb, VLO_EMUL_GLDS=mode), f)
+        assert torch.equal(torch.load(f), want), (bm, mode, cb)
+
+
 @pytest.mark.skipif(not FULL, reason="longer emulation cases: VLO_EMUL_FULL=1")
 @pytest.mark.parametrize("n", [17, 64, 65, 81])
 def test_step_chunking_boundaries(E, n):

@@ -22,329 +22,7 @@
 #include "common.cuh"
 #include "vit.h"
 
-enum { EP_F16 = 0, EP_F16_GELU = 1, EP_RESID = 2, EP_PATCH = 3, EP_QKV = 4, EP_F32 = 5 };
-
-struct GemmArgs {
-    const f16_t *X;            // [M][ldx] fp16   (EP_PATCH: unused)
-    const uint8_t *frames;     // EP_PATCH: uint8 [B][3][R][R]
-    const f16_t *W;            // [N][K] fp16
-    const float *bias;         // [N] fp32
-    f16_t *out16;              // EP_F16 / EP_F16_GELU / EP_QKV (q,k part): [M][ldo]
-    f16_t *outVT;              // EP_QKV: V^T [B][heads][hd][S]
-    float *out32;              // EP_RESID / EP_PATCH: residual stream [M][N];  EP_F32: [M][ldo]
-    const float *pos;          // EP_PATCH: [S][N]
-    int M, N, K, ldx, ldo;
-    int ksplit;                // EP_RESID only: K slices (grid.z), partial sums are atomically added into out32
-    int S, R, P, G;            // tokens per frame, resolution, patch size, grid (EP_PATCH / EP_QKV)
-    int D, hd;                 // EP_QKV: hidden size, head dim
-};
-
-VLO_DEV float gelu_tanh_f(float x) {
-    // 0.5 x (1 + tanh(u)) = x / (1 + exp(-2u)), u = k0 (x + k1 x^3): one v_exp_f32 + one v_rcp_f32 instead of libm's tanhf (the
-    // fc1 epilogue evaluates 32 of these per lane); relative error ~1e-6, three orders below the fp16 rounding of the result
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    const float u = k0 * (x + k1 * x * x * x);
-    return x * __frcp_rn(1.0f + __expf(-2.0f * u));
-}
-VLO_DEV float rh(float x) { return h2f(f2h(x)); }     // fp16 rounding point
-
-#define GEMM_BK 64
-
-// DEPTH == 0 selects the direct-to-LDS path: tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging,
-// no ds_write pass); the destination of a wave instruction is linear (base + lane*16 B), so the XOR swizzle of the
-// 16-byte chunks is applied to the per-lane SOURCE address — it permutes chunks inside one 128-B row segment, i.e.
-// coalescing is unchanged — and again on the fragment reads (cdna guide rule 21).  Two LDS buffers, one barrier per K tile.
-template <int BM, int BN, int WM, int WN, int EP, int DEPTH, int STAGES = 2>
-__global__ __launch_bounds__(WM * WN * 64) void vit_gemm_kernel(GemmArgs a) {
-    constexpr int NTHR = WM * WN * 64;
-    constexpr bool GLDS = (DEPTH == 0);
-    constexpr int RING = GLDS ? 1 : DEPTH;
-    constexpr int MI = BM / (WM * 16), NI = BN / (WN * 16);    // 16x16 MFMA tiles per wave along m / n (WM x WN waves)
-    // ONE shared object (a second one makes hipcc drain the direct-to-LDS queue before every k-step, cdna guide §5 trap 4a):
-    // NBUF stages of [X tile | W tile].  Direct-to-LDS path: STAGES - 1 K tiles in flight per block (2 stages = 64 KiB, two
-    // blocks per CU; 4 stages = 128 KiB, one block per CU with three tiles in flight).
-    constexpr int NBUF = GLDS ? STAGES : 2;
-    constexpr int STAGE = (BM + BN) * GEMM_BK;
-    __shared__ __attribute__((aligned(16))) f16_t smem[NBUF * STAGE];
-#define sX(buf) (smem + (buf) * STAGE)
-#define sW(buf) (smem + (buf) * STAGE + BM * GEMM_BK)
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wm = w / WN, wn = w % WN;
-    // XCD-aware tile order.  Workgroups are handed to the 8 XCDs round-robin in dispatch order (x fastest); each XCD has its own
-    // 4 MiB L2.  A grid whose width is a multiple of 8 therefore gives XCD i the column tiles i, i+8, ... of EVERY row: its slice of
-    // W stays in its L2 and the activations stream through all eight L2s (memory-side reads ~ 8 |X| + |W|).  Right for the wide
-    // GEMMs (qkv, fc1: |W| > L2), wrong for the narrow ones with long K (fc2 at 8 frames: 8 x 37.7 MB for 38.6 GFLOP; out-proj):
-    // there XCD i takes a CONTIGUOUS run of the row-major tile list instead (a band of rows x all columns, ~ |X| + 8 |W|).
-    // fc2: 92 -> 68 us.  Grids whose width is not a multiple of 8 (no clean column ownership) take the band order too.
-    int tile_x = blockIdx.x, tile_y = blockIdx.y;
-    if (gridDim.x <= 8 || (gridDim.x & 7)) {
-        const int ntx = gridDim.x, nt = gridDim.x * gridDim.y;
-        const int L = blockIdx.y * ntx + blockIdx.x, xcd = L & 7, j = L >> 3;
-        const int q = nt >> 3, r = nt & 7;                      // XCD x owns q + (x < r) tiles (bijective for any nt)
-        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-        tile_y = t / ntx;
-        tile_x = t - tile_y * ntx;
-    }
-    const int m0 = tile_y * BM, n0 = tile_x * BN;
-    const int r16 = lane & 15, qd = lane >> 4;
-    constexpr int XCH = BM * 8 / NTHR, WCH = BN * 8 / NTHR;   // 16-byte chunks per thread per tile
-    // DEPTH = K tiles in flight (register ring)
-    uint4 rx[RING][XCH], rw[RING][WCH];
-
-    // global -> registers for K tile starting at k0, into ring slot `slot` (compile-time after unrolling)
-#define LOAD_TILE(slot, k0_)                                                                                          \
-    do {                                                                                                              \
-        const int k0 = (k0_);                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < XCH; ++i) {                                                             \
-            const int id = tid + i * NTHR, row = id >> 3, c = id & 7;                                                  \
-            const int m = m0 + row;                                                                                   \
-            uint4 v = make_uint4(0, 0, 0, 0);                                                                         \
-            if (m < a.M) {                                                                                            \
-                if (EP == EP_PATCH) {                                                                                 \
-                    /* im2col on the fly: k = ch*P*P + py*P + px ; 8 consecutive px -> 8 consecutive bytes */        \
-                    const int k = k0 + c * 8;                                                                         \
-                    const int ch = k / (a.P * a.P), rem = k % (a.P * a.P), py = rem / a.P, px = rem % a.P;            \
-                    const int b = m / a.S, t = m % a.S, gy = t / a.G, gx = t % a.G;                                   \
-                    const uint8_t *src = a.frames + (((size_t)b * 3 + ch) * a.R + gy * a.P + py) * a.R + gx * a.P + px; \
-                    const uint2 raw = *reinterpret_cast<const uint2 *>(src);                                          \
-                    const uint8_t *e = reinterpret_cast<const uint8_t *>(&raw);                                       \
-                    f16_t o[8];                                                                                       \
-                    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                   \
-                        /* frames * rescale_factor, then (x - 0.5) / 0.5 in fp32, cast fp16 (vision_live.py:12) */    \
-                        const float x = (float)e[j] * 0.00392156862745098f;                                           \
-                        o[j] = f2h((x - 0.5f) / 0.5f);                                                                \
-                    }                                                                                                 \
-                    v = *reinterpret_cast<const uint4 *>(o);                                                          \
-                } else {                                                                                              \
-                    v = *reinterpret_cast<const uint4 *>(a.X + (size_t)m * a.ldx + k0 + c * 8);                       \
-                }                                                                                                     \
-            }                                                                                                         \
-            rx[slot][i] = v;                                                                                          \
-        }                                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < WCH; ++i) {                                                             \
-            const int id = tid + i * NTHR, row = id >> 3, c = id & 7;                                                  \
-            const int n = n0 + row;                                                                                   \
-            uint4 v = make_uint4(0, 0, 0, 0);                                                                         \
-            if (n < a.N) v = *reinterpret_cast<const uint4 *>(a.W + (size_t)n * a.K + k0 + c * 8);                    \
-            rw[slot][i] = v;                                                                                          \
-        }                                                                                                             \
-    } while (0)
-    // registers (ring slot) -> XOR-swizzled LDS buffer
-#define STORE_TILE(slot, buf)                                                                                         \
-    do {                                                                                                              \
-        _Pragma("unroll") for (int i = 0; i < XCH; ++i) {                                                             \
-            const int id = tid + i * NTHR, row = id >> 3, c = id & 7;                                                  \
-            *reinterpret_cast<uint4 *>(&sX(buf)[row * GEMM_BK + ((c ^ (row & 7)) << 3)]) = rx[slot][i];               \
-        }                                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < WCH; ++i) {                                                             \
-            const int id = tid + i * NTHR, row = id >> 3, c = id & 7;                                                  \
-            *reinterpret_cast<uint4 *>(&sW(buf)[row * GEMM_BK + ((c ^ (row & 7)) << 3)]) = rw[slot][i];               \
-        }                                                                                                             \
-    } while (0)
-
-    f32x4 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nk_all = a.K / GEMM_BK;
-    const int nk = (EP == EP_RESID && a.ksplit > 1) ? nk_all / a.ksplit : nk_all;
-    const int kbeg = (EP == EP_RESID && a.ksplit > 1) ? blockIdx.z * nk * GEMM_BK : 0;
-    if (GLDS) {
-        constexpr int XI = BM / 8 / (WM * WN), WI = BN / 8 / (WM * WN);     // 1-KiB (8-row) pieces per wave per tile
-        const int lrow = lane >> 3, lc = (lane & 7) ^ (lrow & 7);           // source chunk of this lane (swizzle on the source)
-        auto issue = [&](int buf, int k0) {
-#pragma unroll
-            for (int i = 0; i < XI; ++i) {
-                const int piece = w * XI + i;
-                const int m = min(m0 + piece * 8 + lrow, a.M - 1);          // clamp: rows past M are computed and dropped
-                const f16_t *g = a.X + (size_t)m * a.ldx + k0 + lc * 8;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                                 (__attribute__((address_space(3))) void *)&sX(buf)[piece * 8 * GEMM_BK], 16, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < WI; ++i) {
-                const int piece = w * WI + i;
-                const int n = min(n0 + piece * 8 + lrow, a.N - 1);
-                const f16_t *g = a.W + (size_t)n * a.K + k0 + lc * 8;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                                 (__attribute__((address_space(3))) void *)&sW(buf)[piece * 8 * GEMM_BK], 16, 0, 0);
-            }
-        };
-        // NBUF-stage pipeline, one raw barrier per K tile.  Iteration kt: wait until THIS wave's pieces of tile kt have landed
-        // (counted vmcnt: the younger tiles stay in flight), barrier (everybody's pieces have landed AND everybody is done
-        // reading tile kt-1), refill the stage tile kt-1 occupied with tile kt+NBUF-1, compute tile kt.
-        constexpr int PER_TILE = XI + WI;                   // direct-to-LDS instructions per wave per K tile
-#pragma unroll
-        for (int j = 0; j < NBUF - 1; ++j)
-            if (j < nk) issue(j, kbeg + j * GEMM_BK);
-        for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt % NBUF;
-            const int ahead = min(nk, kt + NBUF - 1) - kt - 1;        // younger tiles already issued: 0 .. NBUF-2
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_TILE) : "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (kt + NBUF - 1 < nk) issue((kt + NBUF - 1) % NBUF, kbeg + (kt + NBUF - 1) * GEMM_BK);
-#pragma unroll
-            for (int kk = 0; kk < GEMM_BK / 32; ++kk) {
-                frag_ab fx[MI], fw[NI];
-                const int c = kk * 4 + qd;
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const int row = wm * (BM / WM) + i * 16 + r16;
-                    fx[i] = *reinterpret_cast<const frag_ab *>(&sX(buf)[row * GEMM_BK + ((c ^ (row & 7)) << 3)]);
-                }
-#pragma unroll
-                for (int jn = 0; jn < NI; ++jn) {
-                    const int row = wn * (BN / WN) + jn * 16 + r16;
-                    fw[jn] = *reinterpret_cast<const frag_ab *>(&sW(buf)[row * GEMM_BK + ((c ^ (row & 7)) << 3)]);
-                }
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int jn = 0; jn < NI; ++jn) acc[i][jn] = mfma_f16(fw[jn], fx[i], acc[i][jn]);
-            }
-        }
-    } else {
-    // prologue: DEPTH tiles in flight; the first one lands in LDS buffer 0
-#pragma unroll
-    for (int j = 0; j < DEPTH; ++j)
-        if (j < nk) LOAD_TILE(j, kbeg + j * GEMM_BK);
-    STORE_TILE(0, 0);
-    __syncthreads();
-    // K loop: one global->LDS latency is hidden behind DEPTH-1 iterations of MFMA work.  Ring slot j holds
-    // tile kt (already copied to LDS) on entry of iteration kt = kt0 + j, so it is re-loaded with tile kt+DEPTH.
-    for (int kt0 = 0; kt0 < nk; kt0 += DEPTH) {
-#pragma unroll
-        for (int j = 0; j < DEPTH; ++j) {
-            const int kt = kt0 + j;
-            if (kt < nk) {
-                const int buf = kt & 1;
-                if (kt + DEPTH < nk) LOAD_TILE(j, kbeg + (kt + DEPTH) * GEMM_BK);
-#pragma unroll
-                for (int kk = 0; kk < GEMM_BK / 32; ++kk) {
-                    frag_ab fx[MI], fw[NI];
-                    const int c = kk * 4 + qd;
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) {
-                        const int row = wm * (BM / WM) + i * 16 + r16;
-                        fx[i] = *reinterpret_cast<const frag_ab *>(&sX(buf)[row * GEMM_BK + ((c ^ (row & 7)) << 3)]);
-                    }
-#pragma unroll
-                    for (int jn = 0; jn < NI; ++jn) {
-                        const int row = wn * (BN / WN) + jn * 16 + r16;
-                        fw[jn] = *reinterpret_cast<const frag_ab *>(&sW(buf)[row * GEMM_BK + ((c ^ (row & 7)) << 3)]);
-                    }
-#pragma unroll
-                    for (int i = 0; i < MI; ++i)
-#pragma unroll
-                        for (int jn = 0; jn < NI; ++jn) acc[i][jn] = mfma_f16(fw[jn], fx[i], acc[i][jn]);
-                }
-                if (kt + 1 < nk) STORE_TILE((j + 1) % DEPTH, buf ^ 1);
-                __syncthreads();
-            }
-        }
-    }
-    }
-#undef LOAD_TILE
-#undef STORE_TILE
-#undef sX
-#undef sW
-
-    // epilogue: lane holds out[m][n .. n+3], m = tile row (lane&15), n = tile col (lane>>4)*4
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wm * (BM / WM) + i * 16 + r16;
-        if (m >= a.M) continue;
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int n = n0 + wn * (BN / WN) + j * 16 + qd * 4;
-            if (n >= a.N) continue;
-            const float4 bv = *reinterpret_cast<const float4 *>(a.bias + n);
-            float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
-            if (EP == EP_F16 || EP == EP_F16_GELU) {
-                ushort4 o;
-                if (EP == EP_F16_GELU) {
-                    o.x = f2h(gelu_tanh_f(rh(v[0]))); o.y = f2h(gelu_tanh_f(rh(v[1])));
-                    o.z = f2h(gelu_tanh_f(rh(v[2]))); o.w = f2h(gelu_tanh_f(rh(v[3])));
-                } else {
-                    o.x = f2h(v[0]); o.y = f2h(v[1]); o.z = f2h(v[2]); o.w = f2h(v[3]);
-                }
-                *reinterpret_cast<ushort4 *>(a.out16 + (size_t)m * a.ldo + n) = o;
-            } else if (EP == EP_F32) {
-                *reinterpret_cast<float4 *>(a.out32 + (size_t)m * a.ldo + n) = make_float4(rh(v[0]), rh(v[1]), rh(v[2]), rh(v[3]));
-            } else if (EP == EP_RESID) {
-                float *hp = a.out32 + (size_t)m * a.N + n;
-                if (a.ksplit > 1) {
-                    // split-K: K-slice partial sums go straight into the fp32 residual stream (bias once);
-                    // skips the fp16 rounding of the Linear output, i.e. errs toward the fp32 reference
-                    const bool first = blockIdx.z == 0;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) atomicAdd(hp + r, first ? v[r] : acc[i][j][r]);
-                } else {
-                    float4 hv = *reinterpret_cast<float4 *>(hp);
-                    hv.x += rh(v[0]); hv.y += rh(v[1]); hv.z += rh(v[2]); hv.w += rh(v[3]);
-                    *reinterpret_cast<float4 *>(hp) = hv;
-                }
-            } else if (EP == EP_PATCH) {
-                const float4 pv = *reinterpret_cast<const float4 *>(a.pos + (size_t)(m % a.S) * a.N + n);
-                *reinterpret_cast<float4 *>(a.out32 + (size_t)m * a.N + n) =
-                    make_float4(rh(v[0]) + pv.x, rh(v[1]) + pv.y, rh(v[2]) + pv.z, rh(v[3]) + pv.w);
-            } else if (EP == EP_QKV) {
-                if (n < 2 * a.D) {
-                    ushort4 o;
-                    o.x = f2h(v[0]); o.y = f2h(v[1]); o.z = f2h(v[2]); o.w = f2h(v[3]);
-                    *reinterpret_cast<ushort4 *>(a.out16 + (size_t)m * a.ldo + n) = o;
-                } else {
-                    const int b = m / a.S, t = m % a.S;
-                    const int dcol = n - 2 * a.D, head = dcol / a.hd, d = dcol % a.hd;
-                    f16_t *vt = a.outVT + (((size_t)b * (a.D / a.hd) + head) * a.hd + d) * a.S + t;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) vt[(size_t)r * a.S] = f2h(v[r]);
-                }
-            }
-        }
-    }
-}
-
-template <int EP>
-static hipError_t gemm_launch(GemmArgs a, hipStream_t st) {
-    if (a.K % GEMM_BK || (a.N & 3)) return hipErrorInvalidValue;
-    // No split-K: slicing K with fp32 atomics into the residual stream measured no faster at one frame (3.50 vs
-    // 3.57 ms) and makes results depend on the atomic order.
-    a.ksplit = 1;
-    static const int big_min_tiles = getenv("VLO_VIT_BIG_TILES") ? atoi(getenv("VLO_VIT_BIG_TILES")) : 200;
-    const int big_tiles = ((a.M + 127) / 128) * (a.N / 128);
-    if (a.M <= 32) {
-        dim3 grid((a.N + 63) / 64, (a.M + 31) / 32, 1);
-        hipLaunchKernelGGL((vit_gemm_kernel<32, 64, 2, 2, EP, 4>), grid, dim3(256), 0, st, a);
-    } else if (a.N % 128 == 0 && big_min_tiles > 0 && big_tiles >= big_min_tiles) {
-        // batched frames (offline feature extraction, deep prefetch): 128x128 tiles on 8 waves (2 x 4, each 64x32):
-        // half the L2->LDS bytes per FLOP of the 64x64 kernel, which is L2-bandwidth-bound (~450 TFLOP/s ceiling)
-        dim3 grid(a.N / 128, (a.M + 127) / 128, 1);
-        static const bool use_glds = getenv("VLO_VIT_GLDS") ? atoi(getenv("VLO_VIT_GLDS")) != 0 : true;
-        // measured alternatives that lost at 8-14 frames: 3 / 4 direct-to-LDS stages (one block per CU), 4 waves of
-        // 64x64 per block
-        // from 16 frames in one launch (M >= 9216 rows): 256x256 tiles on SIXTEEN waves (4 x 4, each 64x64; 128 KiB of LDS, one block per
-        // CU).  The same waves per SIMD as two 128x128 blocks, half the L2 -> LDS bytes and a third less LDS read traffic per FLOP:
-        // 32 / 64 / 128 frames 646 / 621 / 611 -> 675 / 681 / 673 TFLOP/s, 16 frames in one branch 527 -> 564; below that the grid is too
-        // small for one block per CU (the same tile on 8 waves of 128x64 measured slower at every size)
-        static const int min256 = getenv("VLO_VIT_256_MIN_ROWS") ? atoi(getenv("VLO_VIT_256_MIN_ROWS")) : 9216;   // 0 = never
-        if (use_glds && EP != EP_PATCH && min256 > 0 && a.N % 256 == 0 && a.M >= min256) {
-            dim3 g2(a.N / 256, (a.M + 255) / 256, 1);
-            hipLaunchKernelGGL((vit_gemm_kernel<256, 256, 4, 4, EP, 0, 2>), g2, dim3(1024), 0, st, a);
-        } else if (use_glds && EP != EP_PATCH)
-            hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 4, EP, 0, 2>), grid, dim3(512), 0, st, a);
-        else
-            hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 4, EP, 2>), grid, dim3(512), 0, st, a);
-    } else {
-        dim3 grid((a.N + 63) / 64, (a.M + 63) / 64, 1);
-        hipLaunchKernelGGL((vit_gemm_kernel<64, 64, 2, 2, EP, 4>), grid, dim3(256), 0, st, a);
-    }
-    return hipGetLastError();
-}
+#include "vit_gemm.inc"
 
 // ------------------------------------------------------------------------------------
 // LayerNorm (fp32 in, fp32 stats) -> fp16 (matmul operand) and optionally fp32
