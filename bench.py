@@ -192,13 +192,53 @@ def run_tp_leg(args, rank, world, local, allreduce="rccl", port_offset=17):
     r = {k: d.get(k) for k in keep}
     r["rccl_comm"] = d["config"].get("rccl_comm")
     how = ("RCCL all-reduce x2 per layer + logits all-gather" if allreduce == "rccl" else
-           "one-shot peer-to-peer all-reduce over xGMI fused with residual add + RMSNorm, x2 per layer, + p2p logits gather; no RCCL")
+           "one-shot peer-to-peer all-reduce over xGMI fused with residual add + RMSNorm, x2 per layer, + p2p logits gather; no RCCL on the step path")
     r.update(parallelism=d["config"]["parallelism"], stream_hbm_roofline=d.get("stream_hbm_roofline"), wall_s=round(time.time() - t0, 1),
              exchange=d["config"].get("tp_exchange"),
              note=f"ONE stream, Llama tensor-parallel over the same GPUs ({how}), ViT "
-                  f"{'frame-parallel (one all-gather of the frame embeddings per batch)' if allreduce == 'rccl' and getattr(args, 'tp_vit', '') == 'frame-parallel' else 'replicated'}; measured by "
+                  f"{'frame-parallel (one RCCL all-gather of the frame embeddings per batch)' if getattr(args, 'tp_vit', '') == 'frame-parallel' else 'replicated'}; measured by "
                   f"`bench.py --tp --tp-allreduce {allreduce}` in child processes")
     return r
+
+
+def self_launch(n):
+    """Re-run this command line under torch.distributed.run with n ranks on this node (rendezvous on 127.0.0.1, a free port);
+    the ranks' output passes through (rank 0 prints the JSON line).  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd[1:])}")
+    return subprocess.call(cmd)
+
+
+def dry_run(args, rank, world, dist, backend):
+    """VLO_BENCH_DRY_RUN=1 (tests/test_multiproc_cpu.py): everything of an N-rank run EXCEPT the engine — launch, rendezvous, the
+    barrier + synchronize bracket, max-over-ranks timing, whole-job aggregation, rank 0's JSON line — with a host sleep standing in
+    for the frame.  Not a measurement: `value` is null and the line says so."""
+    K = args.steps
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        time.sleep(1e-3 * (rank + 1))              # the last rank is the slow replica
+    if dist is not None:
+        dist.barrier()
+    elapsed = reduce_elapsed_max(dist, time.perf_counter() - t0, device="cuda" if backend == "nccl" else "cpu")
+    out = None
+    if rank == 0:
+        out = {"metric": "launch-path rehearsal (no engine)", "value": None, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+               "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
+               "data": "none", "dry_run": True, "stand_in_frames_per_s": round(aggregate_fps(K, world, elapsed), 3),
+               "config": {"workload": "VLO_BENCH_DRY_RUN=1: a host sleep per step instead of the hot path", "parallelism": f"replicas{world}"}}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
 
 
 def main():
@@ -238,12 +278,20 @@ def main():
     ap.add_argument("--tp-leg-timeout", type=float, default=200.0, help="deadline of EACH tensor-parallel child leg (rccl, p2p)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU), so that an N-GPU line can
+        # never be a silent 1-GPU run
+        raise SystemExit(self_launch(args.gpus))
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or drop the launcher: bench.py starts its own ranks)")
+    if os.environ.get("VLO_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
     # VLO_BENCH_BACKEND=gloo lets the multi-process path be exercised on a box with fewer GPUs than ranks
     backend = os.environ.get("VLO_BENCH_BACKEND", "nccl")
     if backend != "nccl":
@@ -257,6 +305,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if os.environ.get("VLO_BENCH_DRY_RUN") == "1":
+        return dry_run(args, rank, world, dist, backend)
     from videollm_online_amd.engine import Engine, EngineConfig, TpGroup
     from videollm_online_amd.inference import LiveInfer
     from videollm_online_amd.modeling_live import LiveModel
@@ -280,7 +330,10 @@ def main():
                 out = [None] * world
                 dist.all_gather_object(out, mine)
                 return out
-            eng = TpGroup(cfg, world, device=local, rank=rank, allreduce="p2p", handle_allgather=gather_handles)
+            uid = [TpGroup.unique_id() if rank == 0 and args.tp_vit == "frame-parallel" else None]
+            dist.broadcast_object_list(uid, src=0)      # frame-parallel tower: RCCL carries ONLY the all-gather of the frame embeddings
+            eng = TpGroup(cfg, world, device=local, rank=rank, allreduce="p2p", handle_allgather=gather_handles, unique_id=uid[0],
+                          frame_parallel=args.tp_vit == "frame-parallel")
         else:
             uid = [TpGroup.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
@@ -419,7 +472,7 @@ def main():
                                       f"{kv_start} tokens when the clock starts, {final_len} when it stops), "
                                       if preroll else f"all {K} frames of a {minutes:g} min @ {args.fps:g} FPS 384x384 uint8 stream (KV 0 -> {final_len} tokens), ")
                                    + (f"ONE stream, Llama TP={world} ({'RCCL' if args.tp_allreduce == 'rccl' else 'one-shot p2p'} all-reduce x2/layer), ViT "
-                                      f"{'frame-parallel + all-gather of the frame embeddings' if (args.tp_allreduce == 'rccl' and args.tp_vit == 'frame-parallel') else 'replicated'}, "
+                                      f"{'frame-parallel + all-gather of the frame embeddings' if args.tp_vit == 'frame-parallel' else 'replicated'}, "
                                       if tp else f"TP=1, one stream per GPU ({world} replica(s)), ") + f"mode={args.mode} "
                                    f"(16-token response every 10th frame + t=0 query), random-init weights at true shapes",
                        "frames": K, "stream_frames": total, "preroll_frames": preroll, "kv_tokens_at_start": kv_start,
@@ -469,6 +522,14 @@ def main():
             out["tp"] = tp_leg
         if tp_p2p_leg is not None:
             out["tp_p2p"] = tp_p2p_leg
+        if world > 1:
+            # what a reader of a SCALE line needs first, at the top level: how many ranks RCCL itself saw, and the strong-scaling
+            # efficiency of ONE tensor-parallel stream (the better of the two exchange legs)
+            seen = [((leg or {}).get("rccl_comm") or {}).get("nranks") for leg in (tp_leg, tp_p2p_leg)]
+            out["rccl_ranks_seen"] = next((n for n in seen if n), int(out["config"].get("rccl_comm", {}).get("nranks", 0)) or None)
+            effs = {name: leg.get("scaling_efficiency") for name, leg in (("tp", tp_leg), ("tp_p2p", tp_p2p_leg)) if leg and leg.get("scaling_efficiency")}
+            out["tp_scaling_efficiency"] = max(effs.values()) if effs else None
+            out["tp_scaling_efficiency_by_leg"] = effs or None
         if world == 1 and not args.no_cpu_baseline:
             log("cpu_baseline: building CPU oracle")
             try:

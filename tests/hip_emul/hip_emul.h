@@ -326,6 +326,9 @@ static inline const char *hipGetErrorString(hipError_t e) { return e == hipSucce
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+typedef enum { hipDeviceAttributeMultiprocessorCount = 63 } hipDeviceAttribute_t;
+static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 4; return hipSuccess; }     // as hipGetDeviceProperties below
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 struct hipDeviceProp_t { int multiProcessorCount; };
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 4; return hipSuccess; }

@@ -177,3 +177,31 @@ def test_tp_data_path_two_processes_rccl_standin():
     assert res[0][2] >= 0.0 and res[1][2] >= 0.0
     # frame-parallel encode + all-gather == every rank encoding every frame (north_star's frame-embedding broadcast)
     assert all(v[0] for v in vit.values()), f"frame-parallel and replicated vision embeddings differ: {vit}"
+
+
+def _run_bench(argv, env_extra, timeout=300):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
+    """`python bench.py --gpus 2` with no launcher (how the driver starts N = 1) must not be a silent 1-GPU run: bench.py starts its
+    own two ranks (torch.distributed.run, 127.0.0.1), they rendezvous (gloo here), time under the barrier bracket and rank 0 prints
+    ONE line with n_gpus == 2.  VLO_BENCH_DRY_RUN=1 replaces the engine by a host sleep — this box has no GPU."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "5", "--warmup", "1"], dict(VLO_BENCH_BACKEND="gloo", VLO_BENCH_DRY_RUN="1"))
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["dry_run"] is True and d["value"] is None
+    # max over ranks: the slow rank sleeps 2 ms per step
+    assert d["ms_per_step"] >= 2.0
+
+
+def test_bench_world_size_mismatch_fails_loudly():
+    """A launcher that started a different number of ranks than --gpus (or one rank for --gpus 8) must exit non-zero, not print a line."""
+    r = _run_bench(["--gpus", "8", "--steps", "2"], dict(VLO_BENCH_BACKEND="gloo", VLO_BENCH_DRY_RUN="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

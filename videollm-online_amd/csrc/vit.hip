@@ -465,11 +465,14 @@ static int vit_reserve(vlo_engine *e, VitState *v, int B) {
     };
     A((void **)&v->h, M * D * 4);
     A((void **)&v->last, M * D * 4);
-    A((void **)&v->x16, M * D * 2);
+    // GEMM operands carry 256 extra rows: the ping-pong GEMM (vit_gemm.inc) reads whole 256-row tiles, the rows past M are computed
+    // and dropped
+    const size_t Mp = M + 256;
+    A((void **)&v->x16, Mp * D * 2);
     A((void **)&v->qk16, M * 2 * D * 2);
     A((void **)&v->vT, M * D * 2);
-    A((void **)&v->att16, M * D * 2);
-    A((void **)&v->mid16, M * I * 2);
+    A((void **)&v->att16, Mp * D * 2);
+    A((void **)&v->mid16, Mp * I * 2);
     A((void **)&v->kv16, M * 2 * D * 2);
     A((void **)&v->hatt16, (size_t)B * D * 2);
     A((void **)&v->ho16, (size_t)B * D * 2);

@@ -412,7 +412,8 @@ class TpGroup:
     * ``allreduce="p2p"`` (either mode): the exchanges are the one-shot peer-to-peer all-reduce over xGMI fused with the
       residual add + RMSNorm (include/vlo.h `vlo_tp_p2p_*`) instead of RCCL calls / sum kernels.  One process per GPU:
       pass ``handle_allgather`` — a callable taking this rank's 64-byte mailbox handle and returning every rank's, in
-      rank order (e.g. built on ``torch.distributed.all_gather_object``); no RCCL unique id is needed then.
+      rank order (e.g. built on ``torch.distributed.all_gather_object``); no RCCL unique id is needed then (give one anyway,
+      with ``frame_parallel=True``, to encode frame-parallel: RCCL then carries only the all-gather of the frame embeddings).
     Weights are given in FULL; every rank slices its shard.  ViT, connector and embeddings are replicated."""
 
     def __init__(self, cfg: EngineConfig, tp_size: int, device: int = 0, rank: int | None = None, unique_id: bytes | None = None,
@@ -530,24 +531,30 @@ class TpGroup:
         return self.engines[0].frame_ingest(frames, layout, resolution, cubic_a, out, stream)
 
     def visual_embed(self, frames_u8, stream=None, out=None):
-        """Replicated tower (every rank encodes every frame) unless this is a one-process-per-GPU group over RCCL with
+        """Replicated tower (every rank encodes every frame) unless this is a one-process-per-GPU group WITH an RCCL communicator
+        (``unique_id`` given — also next to ``allreduce="p2p"``, where RCCL then carries only this all-gather) and
         ``frame_parallel`` set: then rank r encodes frames r, r + T, ... and ONE all-gather hands every rank all the
-        [frame_num_tokens, H] embeddings (north_star's frame-embedding broadcast; 81 920 B per frame for Llama-3-8B)."""
-        if not (self.frame_parallel and self.allreduce == "rccl" and len(self.engines) == 1 and self.tp_size > 1):
+        [frame_num_tokens, H] embeddings (north_star's frame-embedding broadcast; 81 920 B per frame for Llama-3-8B).
+        Every rank must call it with the same number of frames."""
+        if not (self.frame_parallel and self._uid is not None and len(self.engines) == 1 and self.tp_size > 1):
             return self.engines[0].visual_embed(frames_u8, stream, out)
         e, T, r = self.engines[0], self.tp_size, self.engines[0].cfg.tp_rank
         B, rows, H = frames_u8.shape[0], self.cfg.frame_num_tokens, self.cfg.hidden_size
         k = (B + T - 1) // T                                   # frames per rank, the last ranks' shares padded
-        mine = frames_u8[r::T]
-        send = torch.zeros(k * rows, H, dtype=torch.bfloat16, device=self.device)
-        if mine.shape[0]:
-            e.visual_embed(mine, stream, out=send[:mine.shape[0] * rows])
-        recv = torch.empty(T, k * rows, H, dtype=torch.bfloat16, device=self.device)
-        _C.check(_C.lib().vlo_tp_allgather(self._g, _ptr(send), _ptr(recv), send.numel() * 2, _stream_handle(stream)))
-        if out is None:
-            out = torch.empty(B * rows, H, dtype=torch.bfloat16, device=self.device)
-        # frame i was encoded by rank i % T as its (i // T)-th frame
-        out.view(B, rows, H).copy_(recv.view(T, k, rows, H).transpose(0, 1).reshape(T * k, rows, H)[:B])
+        # the staging tensors below are filled / read by torch kernels: they must run on the stream the encode and the all-gather
+        # are enqueued on, whatever torch's current stream is
+        ts = stream if stream is not None else torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(ts):
+            mine = frames_u8[r::T].contiguous()
+            send = torch.zeros(k * rows, H, dtype=torch.bfloat16, device=self.device)
+            if mine.shape[0]:
+                e.visual_embed(mine, ts, out=send[:mine.shape[0] * rows])
+            recv = torch.empty(T, k * rows, H, dtype=torch.bfloat16, device=self.device)
+            _C.check(_C.lib().vlo_tp_allgather(self._g, _ptr(send), _ptr(recv), send.numel() * 2, _stream_handle(ts)))
+            if out is None:
+                out = torch.empty(B * rows, H, dtype=torch.bfloat16, device=self.device)
+            # frame i was encoded by rank i % T as its (i // T)-th frame
+            out.view(B, rows, H).copy_(recv.view(T, k, rows, H).transpose(0, 1).reshape(T * k, rows, H)[:B])
         return out
 
     def llm_step(self, session: TpSession, embeds: torch.Tensor, want_last=True, want_all=False, stream=None):
