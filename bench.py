@@ -296,7 +296,10 @@ def main():
     backend = os.environ.get("VLO_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local = local % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    elif os.environ.get("VLO_BENCH_DRY_RUN") != "1":
+        raise SystemExit("no GPU visible: the engine has no CPU path")
     dist = None
     if world > 1:
         import torch.distributed as dist

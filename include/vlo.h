@@ -124,7 +124,10 @@ int vlo_vision_tokens(vlo_engine *e, const uint8_t *frames_dev, int B, void *out
  *      2 —, -sws_flags bicubic, pad to R x R with black; demo/cli.py:13-22) followed by read_video(..., 'TCHW')
  *      (demo/inference.py:112).  src_dev: decoded uint8 RGB frames, layout 0 = [T,H,W,3] (decoder output), 1 = [T,3,H,W];
  *      resolution: R, or 0 for the vision tower's image size; cubic_a: Keys parameter of the antialiased bicubic (-0.6 =
- *      libswscale's default B=0,C=0.6; -0.5 = PIL / torch antialias); out_dev: uint8 [T,3,R,R]. */
+ *      libswscale's default B=0,C=0.6; -0.5 = PIL / torch antialias); out_dev: uint8 [T,3,R,R].
+ *      Thread-safe and stream-safe: the engine's one fp32 scratch is handed from call to call through an event (a call's kernels
+ *      start after the previous call's kernels, whichever streams and host threads the two calls came from); src_dev / out_dev
+ *      must stay valid until `stream` has run the call. */
 int vlo_frame_ingest(vlo_engine *e, const uint8_t *src_dev, int T, int H, int W, int layout, int resolution, float cubic_a,
                      uint8_t *out_dev, void *stream);
 /* host-only: scaled size (ow, oh) and pad offset (x0, y0) of the call above for W x H frames (any pointer may be NULL) */

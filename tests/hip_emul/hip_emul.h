@@ -167,6 +167,7 @@ static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); re
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 #define __expf(x) expf(x)                // glibc declares __expf but does not export it
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __frcp_rn(x) (1.0f / (x))
 static inline long long wall_clock64() {      // s_memrealtime: a 100 MHz counter
     return (long long)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10);
@@ -423,6 +424,8 @@ static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }   // emulated streams are synchronous
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new emul_event(); return hipSuccess; }
+#define hipEventDisableTiming 0x2
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new emul_event(); return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }

@@ -36,22 +36,30 @@ static int g_grid = 256;       // workgroups of the persistent ping-pong kernel 
 struct Variant { const char *name; int kind, bm, cb, prio; };     // kind 0 = old128, 1 = old256 (16 waves), 2 = ping-pong; prio 2 / 3 = ablations (no epilogue / no loads)
 
 template <int EP>
+static void launch_pp(const Variant &v, const GemmArgs &a, hipStream_t st) {
+    const int bm = v.bm, nt = std::min(((a.M + bm - 1) / bm) * (a.N / 256), g_grid);
+    if (bm == 128) hipLaunchKernelGGL((vit_gemm_pp_kernel<128, EP, 1>), dim3(nt), dim3(512), 0, st, a);
+    else if (v.prio == 2) hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP, 1, 1>), dim3(nt), dim3(512), 0, st, a);
+    else if (v.prio == 3) hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP, 1, 2>), dim3(nt), dim3(512), 0, st, a);
+    else if (v.prio) hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP, 1>), dim3(nt), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP, 0>), dim3(nt), dim3(512), 0, st, a);
+}
+template <int EP>
 static void launch(const Variant &v, GemmArgs a, hipStream_t st) {
-
     a.cb = v.cb;
+    a.xpad = 1;
     if (v.kind == 0) {
         hipLaunchKernelGGL((vit_gemm_kernel<128, 128, 2, 4, EP, 0, 2>), dim3(a.N / 128, (a.M + 127) / 128), dim3(512), 0, st, a);
     } else if (v.kind == 1) {
         hipLaunchKernelGGL((vit_gemm_kernel<256, 256, 4, 4, EP, 0, 2>), dim3(a.N / 256, (a.M + 255) / 256), dim3(1024), 0, st, a);
-    } else if (v.bm == 256) {
-        const int nt = std::min(((a.M + 255) / 256) * (a.N / 256), g_grid);
-        if (v.prio == 2) hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP, 1, 1>), dim3(nt), dim3(512), 0, st, a);
-        else if (v.prio == 3) hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP, 1, 2>), dim3(nt), dim3(512), 0, st, a);
-        else if (v.prio) hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP, 1>), dim3(nt), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP, 0>), dim3(nt), dim3(512), 0, st, a);
+    } else if constexpr (EP == EP_QKV) {       // as gemm_launch: q | k row-major, V transposed through the swapped-operand kernel
+        GemmArgs qk = a, vv = a;
+        qk.N = 2 * a.D;
+        vv.N = a.D; vv.W = a.W + (size_t)2 * a.D * a.K; vv.bias = a.bias + 2 * a.D;
+        launch_pp<EP_F16>(v, qk, st);
+        launch_pp<EP_VT>(v, vv, st);
     } else {
-        const int nt = std::min(((a.M + 127) / 128) * (a.N / 256), g_grid);
-        hipLaunchKernelGGL((vit_gemm_pp_kernel<128, EP, 1>), dim3(nt), dim3(512), 0, st, a);
+        launch_pp<EP>(v, a, st);
     }
 }
 static void launch_ep(int ep, const Variant &v, const GemmArgs &a, hipStream_t st) {

@@ -101,6 +101,7 @@ struct KvGeom;
 int ensure_pages(vlo_session *s, int64_t new_len, hipStream_t st);
 GemvArgs gemv_args(const PackedLinear &pl, const unsigned short *x, int ldx, int n_rows);
 KvGeom kv_geom(const vlo_session *s);
+void ingest_create(vlo_engine *e);
 void ingest_destroy(vlo_engine *e);
 int connector_run(vlo_engine *e, int slot, const void *feats_dev, int rows, void *out_dev, hipStream_t st);   // slot 0 / 1: scratch set
 int vlo_fail(int code, const std::string &msg);   // sets the thread-local error string, returns code

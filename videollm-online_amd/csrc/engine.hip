@@ -111,6 +111,7 @@ int vlo_engine_create(const vlo_config *cfg, int device, vlo_engine **out) {
     e->I_l = cfg->intermediate_size / T;
     e->V_l = cfg->vocab_size / T;
     if (e->cfg.kv_pool_tokens <= 0) e->cfg.kv_pool_tokens = 16384;
+    ingest_create(e);
     *out = e;
     return VLO_OK;
 }

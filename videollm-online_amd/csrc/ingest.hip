@@ -81,16 +81,20 @@ struct IngestPlan { Taps h, v; int ow, oh, x0, y0; };
 struct IngestState {
     std::mutex mu;
     std::map<std::tuple<int, int, int, int>, IngestPlan> plans;      // (H, W, R, a * 1e4)
-    float *tmp = nullptr;
+    float *tmp = nullptr;                 // ONE fp32 scratch per engine, shared by every caller: calls are ordered through `done`
     size_t tmp_bytes = 0;
+    hipEvent_t done = nullptr;            // recorded after the last launch that uses tmp; the next call's stream waits for it
     std::vector<void *> owned;
 };
+
+void ingest_create(vlo_engine *e) { e->ingest = new IngestState(); }     // with the engine (vlo_engine_create): push() may come from a feeder thread
 
 void ingest_destroy(vlo_engine *e) {
     IngestState *s = (IngestState *)e->ingest;
     if (!s) return;
     for (void *p : s->owned) hipFree(p);
     if (s->tmp) hipFree(s->tmp);
+    if (s->done) hipEventDestroy(s->done);
     delete s;
     e->ingest = nullptr;
 }
@@ -198,9 +202,16 @@ int vlo_frame_ingest(vlo_engine *e, const uint8_t *src_dev, int T, int H, int W,
     if ((size_t)W * 3 > 150 * 1024) return vlo_fail(VLO_E_UNSUPPORTED, "frame_ingest: rows wider than 51200 pixels");
     if (hipSetDevice(e->device) != hipSuccess) return vlo_fail(VLO_E_HIP, "hipSetDevice failed");
     hipStream_t st = (hipStream_t)stream;
-    if (!e->ingest) e->ingest = new IngestState();
     IngestState *s = (IngestState *)e->ingest;
+    if (!s) return vlo_fail(VLO_E_STATE, "frame_ingest: engine has no ingest state");
     std::lock_guard<std::mutex> g(s->mu);
+    // the scratch is shared: whatever stream the previous call ran on, its kernels finish before this call's kernels start (the host
+    // mutex only serialises the enqueueing — two FrameRings, or a ring's feeder thread next to load_video, use different streams)
+    if (!s->done) {
+        if (hipEventCreateWithFlags(&s->done, hipEventDisableTiming) != hipSuccess) return vlo_fail(VLO_E_HIP, "frame_ingest: hipEventCreate failed");
+    } else if (hipStreamWaitEvent(st, s->done, 0) != hipSuccess) {
+        return vlo_fail(VLO_E_HIP, "frame_ingest: hipStreamWaitEvent failed");
+    }
     const auto key = std::make_tuple(H, W, R, (int)lrintf(cubic_a * 10000.f));
     auto it = s->plans.find(key);
     if (it == s->plans.end()) {
@@ -240,5 +251,6 @@ int vlo_frame_ingest(vlo_engine *e, const uint8_t *src_dev, int T, int H, int W,
         const hipError_t he = hipGetLastError();
         if (he != hipSuccess) return vlo_fail(VLO_E_HIP, std::string("frame_ingest launch: ") + hipGetErrorString(he));
     }
+    if (hipEventRecord(s->done, st) != hipSuccess) return vlo_fail(VLO_E_HIP, "frame_ingest: hipEventRecord failed");
     return VLO_OK;
 }

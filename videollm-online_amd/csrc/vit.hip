@@ -516,27 +516,27 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
         hipLaunchKernelGGL(vit_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, w_h, Ly.ln1_w, Ly.ln1_b, w_x16, (float *)nullptr, M, D, v->eps);
         {
             GemmArgs a{};
-            a.X = w_x16; a.W = Ly.wqkv; a.bias = Ly.bqkv; a.out16 = w_qk16; a.outVT = w_vT;
+            a.xpad = 1; a.X = w_x16; a.W = Ly.wqkv; a.bias = Ly.bqkv; a.out16 = w_qk16; a.outVT = w_vT;
             a.M = M; a.N = 3 * D; a.K = D; a.ldx = D; a.ldo = 2 * D; a.S = S; a.D = D; a.hd = v->hd;
             VIT_TRY(gemm_launch<EP_QKV>(a, st));
         }
         hipLaunchKernelGGL((vit_attn_kernel<64>), dim3((S + 63) / 64, v->nh, B), dim3(256), kAttnLds, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
         {
             GemmArgs a{};
-            a.X = w_att16; a.W = Ly.wo; a.bias = Ly.bo; a.out32 = w_h;
+            a.xpad = 1; a.X = w_att16; a.W = Ly.wo; a.bias = Ly.bo; a.out32 = w_h;
             a.M = M; a.N = D; a.K = D; a.ldx = D;
             VIT_TRY(gemm_launch<EP_RESID>(a, st));
         }
         hipLaunchKernelGGL(vit_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, w_h, Ly.ln2_w, Ly.ln2_b, w_x16, (float *)nullptr, M, D, v->eps);
         {
             GemmArgs a{};
-            a.X = w_x16; a.W = Ly.w1; a.bias = Ly.b1; a.out16 = w_mid16;
+            a.xpad = 1; a.X = w_x16; a.W = Ly.w1; a.bias = Ly.b1; a.out16 = w_mid16;
             a.M = M; a.N = I; a.K = D; a.ldx = D; a.ldo = I;
             VIT_TRY(gemm_launch<EP_F16_GELU>(a, st));
         }
         {
             GemmArgs a{};
-            a.X = w_mid16; a.W = Ly.w2; a.bias = Ly.b2; a.out32 = w_h;
+            a.xpad = 1; a.X = w_mid16; a.W = Ly.w2; a.bias = Ly.b2; a.out32 = w_h;
             a.M = M; a.N = D; a.K = I; a.ldx = I;
             VIT_TRY(gemm_launch<EP_RESID>(a, st));
         }
@@ -545,7 +545,7 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
     hipLaunchKernelGGL(vit_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, w_h, v->post_w, v->post_b, w_x16, w_last, M, D, v->eps);
     {   // MAP head: K,V = last @ Wkv^T + bkv
         GemmArgs a{};
-        a.X = w_x16; a.W = v->in_proj_w + (size_t)D * D; a.bias = v->in_proj_b + D; a.out16 = w_kv16;
+        a.xpad = 1; a.X = w_x16; a.W = v->in_proj_w + (size_t)D * D; a.bias = v->in_proj_b + D; a.out16 = w_kv16;
         a.M = M; a.N = 2 * D; a.K = D; a.ldx = D; a.ldo = 2 * D;
         VIT_TRY(gemm_launch<EP_F16>(a, st));
     }
