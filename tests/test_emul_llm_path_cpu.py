@@ -369,9 +369,9 @@ sys.path.insert(0, %r)
 from oracle import vlo_oracle as O
 from tests.hip_emul import emul_engine as E
 spec = O.LlmSpec(128, 192, 1, 2, 2, 256, 10000.0, 1e-5, vision_hidden_size=256)
-vspec = O.VitSpec(hidden_size=256, intermediate_size=512, num_layers=1, num_heads=4, image_size=96, patch_size=16, pooled=(3, 3))
+vspec = O.VitSpec(hidden_size=256, intermediate_size=512, num_layers=1, num_heads=4, image_size=128, patch_size=16, pooled=(3, 3))
 w, vw = O.init_llm_weights(spec, seed=3), O.init_vit_weights(vspec, seed=1)
-frames = O.synthetic_frames(8, vspec.image_size, seed=7)          # 288 token rows: one full 256-row tile + a partial one
+frames = O.synthetic_frames(5, vspec.image_size, seed=7)          # 64 tokens per frame, 320 token rows: one full 256-row tile + a partial one
 gold = O.LlamaOracle(spec, w, torch.float32).visual_embed(vw, vspec, frames)
 ref = O.LlamaOracle(spec, w, torch.bfloat16)
 amp = ref.visual_embed(vw, vspec, frames, mm_dtype=torch.float16)
@@ -404,10 +404,12 @@ def _vitpp_child(env_extra, save=None):
 def test_vit_gemm_pingpong_kernel_in_emulation(E):
     """vit_gemm_pp_kernel (256 x 256 tiles, two wave groups alternating read / MFMA segments, half-tiles restaged by direct-to-LDS
     loads under COUNTED vmcnt waits; csrc/vit_gemm.inc) forced onto a small tower (hidden 256: N = 256 / 512 / 768, K = 256 / 512,
-    288 rows = a full tile + a partial one, 2 column groups in the XCD split where the width allows), with the emulated direct-to-LDS
-    loads landing as LATE as the hardware may land them (VLO_EMUL_GLDS=late: only at the vmcnt wait that retires them) — a fragment
-    read that is not covered by its wait + barriers reads stale shared memory and fails here — against the oracle."""
-    _vitpp_child(dict(VLO_VIT_PP_MIN_ROWS="1", VLO_VIT_PP_BM="256", VLO_VIT_PP_CB="2", VLO_EMUL_GLDS="late"))
+    320 rows = a full tile + a partial one, 2 column groups in the XCD split where the width allows; persistent: 4 emulated CUs walk
+    2 - 6 tiles), with the emulated direct-to-LDS loads landing as LATE as the hardware may land them (VLO_EMUL_GLDS=late: only at the
+    vmcnt wait that retires them) — a fragment read that is not covered by its wait + barriers reads stale shared memory and fails
+    here — against the oracle.  The same run forces vit_attn_head_kernel (whole head in LDS, 12 waves x 48 queries; 64 tokens: two
+    waves with work, a masked tail) instead of the 64-query-tile attention kernel."""
+    _vitpp_child(dict(VLO_VIT_PP_MIN_ROWS="1", VLO_VIT_PP_BM="256", VLO_VIT_PP_CB="2", VLO_EMUL_GLDS="late", VLO_VIT_ATTN_HEAD_MIN="1"))
 
 
 @pytest.mark.skipif(not FULL, reason="longer emulation cases: VLO_EMUL_FULL=1")
@@ -415,11 +417,11 @@ def test_vit_gemm_pingpong_kernel_bit_identical_to_small_tile_kernels(E, tmp_pat
     """Same MFMA, same k order: the ping-pong kernel's outputs equal the 64 x 64 / 128 x 128 kernels' bit for bit, for both tile
     heights and both landing models of the emulated direct-to-LDS loads."""
     base = str(tmp_path / "base.pt")
-    _vitpp_child(dict(VLO_VIT_PP="0"), base)
+    _vitpp_child(dict(VLO_VIT_PP="0", VLO_VIT_ATTN_HEAD_MIN="0"), base)
     want = torch.load(base)
     for bm, mode, cb in (("256", "late", "0"), ("128", "late", "2"), ("256", "sync", "2"), ("128", "sync", "0")):
         f = str(tmp_path / f"pp_{bm}_{mode}.pt")
-        _vitpp_child(dict(VLO_VIT_PP_MIN_ROWS="1", VLO_VIT_PP_BM=bm, VLO_VIT_PP_CB=cb, VLO_EMUL_GLDS=mode), f)
+        _vitpp_child(dict(VLO_VIT_PP_MIN_ROWS="1", VLO_VIT_PP_BM=bm, VLO_VIT_PP_CB=cb, VLO_EMUL_GLDS=mode, VLO_VIT_ATTN_HEAD_MIN="0"), f)
         assert torch.equal(torch.load(f), want), (bm, mode, cb)
 
 

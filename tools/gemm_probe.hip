@@ -41,6 +41,7 @@ static void launch_pp(const Variant &v, const GemmArgs &a, hipStream_t st) {
     if (bm == 128) hipLaunchKernelGGL((vit_gemm_pp_kernel<128, EP, 1>), dim3(nt), dim3(512), 0, st, a);
     else if (v.prio == 2) hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP, 1, 1>), dim3(nt), dim3(512), 0, st, a);
     else if (v.prio == 3) hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP, 1, 2>), dim3(nt), dim3(512), 0, st, a);
+    else if (v.prio == 4) hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP, 1, 3>), dim3(nt), dim3(512), 0, st, a);
     else if (v.prio) hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP, 1>), dim3(nt), dim3(512), 0, st, a);
     else hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP, 0>), dim3(nt), dim3(512), 0, st, a);
 }
@@ -108,13 +109,13 @@ int main(int argc, char **argv) {
     struct G { const char *name; int ep, N, K; } gemms[4] = {{"qkv", EP_QKV, 3 * D, D}, {"out", EP_RESID, D, D}, {"fc1", EP_F16_GELU, I, D}, {"fc2", EP_RESID, D, I}};
     std::vector<Variant> variants = {{"old128", 0, 128, 1, 0}, {"old256", 1, 256, 1, 0}, {"pp256", 2, 256, 0, 1}, {"pp256np", 2, 256, 0, 0},
                                      {"pp128", 2, 128, 0, 1},  {"pp256cb1", 2, 256, 1, 1}, {"pp256cb2", 2, 256, 2, 1}, {"pp256cb4", 2, 256, 4, 1},
-                                     {"pp256cb8", 2, 256, 8, 1}, {"pp256noepi", 2, 256, 0, 2}, {"pp256noload", 2, 256, 0, 3}};
+                                     {"pp256cb8", 2, 256, 8, 1}, {"pp256noepi", 2, 256, 0, 2}, {"pp256noload", 2, 256, 0, 3}, {"pp256atomic", 2, 256, 0, 4}};
     for (int B : frames) {
         const int M = B * S;
         for (const G &g : gemms) {
             if (only_gemm && strcmp(only_gemm, g.name)) continue;
             GemmArgs a{};
-            a.X = X; a.W = W; a.bias = bias; a.M = M; a.N = g.N; a.K = g.K; a.ldx = g.K; a.S = S; a.D = D; a.hd = HD;
+            a.X = X; a.W = W; a.bias = bias; a.M = M; a.N = g.N; a.K = g.K; a.ldx = g.K; a.S = S; a.Sp = S; a.D = D; a.hd = HD;
             a.ldo = g.ep == EP_QKV ? 2 * D : g.N;
             const int tx = g.N / 256;
             int auto_cb = 1;
@@ -138,7 +139,8 @@ int main(int argc, char **argv) {
                 CK(hipGetLastError());
                 const char *verdict = "ref";
                 if (v.kind == 0) have_ref = true;
-                else if (v.prio >= 2) verdict = "ablation";
+                else if (v.prio == 2 || v.prio == 3) verdict = "ablation";
+                else if (v.prio == 4 && g.ep != EP_RESID) continue;
                 else if (have_ref) {
                     std::vector<char> r0, r1;
                     auto cmp = [&](const void *p0, const void *p1, size_t n) {

@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const f16_t *__restrict__
     const size_t ld = (size_t)2 * D;
     const f16_t *qbase = qk + (size_t)b * S * ld + (size_t)head * HD;
     const f16_t *kbase = qbase + D;
-    const f16_t *vbase = vT + ((size_t)b * nheads + head) * HD * S;
+    const int Sp = (S + 31) & ~31;                                   // V^T rows: S rounded up to 32, tokens permuted inside 32-blocks (vt_pos)
+    const f16_t *vbase = vT + ((size_t)b * nheads + head) * HD * Sp;
 
     frag_ab qf[QS][NKK];
 #pragma unroll
@@ -131,13 +132,8 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const f16_t *__restrict__
         }
         frag_ab vf[NDT];
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            const f16_t *vr = vbase + (size_t)(dt * 16 + qrow) * S + kt0 + qd * 4;
-            uint2 lo = make_uint2(0, 0), hi = make_uint2(0, 0);
-            if (kt0 + qd * 4 < S) lo = *reinterpret_cast<const uint2 *>(vr);
-            if (kt0 + 16 + qd * 4 < S) hi = *reinterpret_cast<const uint2 *>(vr + 16);
-            vf[dt] = __builtin_bit_cast(frag_ab, make_uint4(lo.x, lo.y, hi.x, hi.y));
-        }
+        for (int dt = 0; dt < NDT; ++dt)          // keys kt0 + qd*4 .. +3 and kt0 + 16 + qd*4 .. +3: 16 contiguous bytes of the permuted row (pad columns are zero)
+            vf[dt] = *reinterpret_cast<const frag_ab *>(vbase + (size_t)(dt * 16 + qrow) * Sp + kt0 + qd * 8);
         const int kb = kt0 + qd * 4;
 #pragma unroll
         for (int qs = 0; qs < QS; ++qs) {
@@ -222,6 +218,165 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const f16_t *__restrict__
             ushort4 o16;
             o16.x = f2h(acc.x * inv); o16.y = f2h(acc.y * inv); o16.z = f2h(acc.z * inv); o16.w = f2h(acc.w * inv);
             *reinterpret_cast<ushort4 *>(orow + dt * 16 + qd * 4) = o16;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Batched frames: one workgroup per (frame, head) with the head's WHOLE K [Sp][64] and V^T [64][Sp] resident in LDS (Sp <= 608:
+// 148 KiB for SigLIP-L/16-384's 576 tokens), 12 waves, each owning 48 queries (three 16-query sub-tiles) against all keys —
+// K and V^T are fetched from L2 / HBM once per head instead of once per 64-query tile (nine times), every fragment read is one
+// conflict-free ds_read_b128 (K rows XOR-swizzled by 16-byte chunks, V^T rows padded to a stride of 10 chunks mod 16), there is no
+// cross-wave merge, and three waves per SIMD interleave the softmax (VALU) of one wave with the MFMAs of the others.
+// Scores live in the exp2 domain (scale * log2 e folded into one multiplier); the accumulator rescale is skipped on steps where no
+// lane of the wave raised its running maximum (bit-identical: the factor would be exactly 1).
+// grid = (ceil(S / 576), heads, frames), 768 threads; LDS = Sp * 128 + 64 * vrs bytes.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(768) void vit_attn_head_kernel(const f16_t *__restrict__ qk, const f16_t *__restrict__ vT, f16_t *__restrict__ out,
+                                                             int S, int D, int nheads, float scale_log2e, int vrs /* bytes per V^T row in LDS */) {
+    constexpr int HD = 64, NKK = 2, NDT = 4, QS = 3;
+    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+    char *const sK = reinterpret_cast<char *>(lds4);                        // [Sp][128 B], chunk c of row r at chunk c ^ (r & 7)
+    const int Sp = (S + 31) & ~31;
+    char *const sV = sK + (size_t)Sp * 128;                                 // [64][vrs]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r16 = lane & 15, qd = lane >> 4;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const size_t ld = (size_t)2 * D;
+    const f16_t *qbase = qk + (size_t)b * S * ld + (size_t)head * HD;
+    const f16_t *kbase = qbase + D;
+    const f16_t *vbase = vT + ((size_t)b * nheads + head) * HD * Sp;
+
+    // ---- fill: K rows (128 B each, 8 chunks) and V^T rows (Sp * 2 B each); every load is issued before the first LDS write
+    {
+        const int kchunks = Sp * 8, vcpr = Sp / 8, vchunks = HD * vcpr;     // 16-byte chunks
+        constexpr int MAXC = 7;                                              // (Sp * 8 + 64 * Sp / 8) / 768 <= 7 for Sp <= 608... 2 * 6.3
+        uint4 kreg[MAXC], vreg[MAXC];
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = tid + i * 768;
+            kreg[i] = make_uint4(0, 0, 0, 0);
+            if (c < kchunks) {
+                const int row = c >> 3;
+                if (row < S) kreg[i] = *reinterpret_cast<const uint4 *>(kbase + (size_t)row * ld + (c & 7) * 8);       // rows past S: zero
+            }
+            vreg[i] = make_uint4(0, 0, 0, 0);
+            if (c < vchunks) vreg[i] = *reinterpret_cast<const uint4 *>(vbase + (size_t)(c / vcpr) * Sp + (c % vcpr) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = tid + i * 768;
+            if (c < kchunks) {
+                const int row = c >> 3;
+                *reinterpret_cast<uint4 *>(sK + (size_t)row * 128 + (((c & 7) ^ (row & 7)) << 4)) = kreg[i];
+            }
+            if (c < vchunks) *reinterpret_cast<uint4 *>(sV + (size_t)(c / vcpr) * vrs + (c % vcpr) * 16) = vreg[i];
+        }
+    }
+    // ---- this wave's queries
+    const int q0 = blockIdx.x * (12 * QS * 16) + w * (QS * 16);
+    frag_ab qf[QS][NKK];
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs)
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            frag_ab z = {0, 0, 0, 0, 0, 0, 0, 0};
+            const int r = q0 + qs * 16 + r16;
+            if (r < S) z = *reinterpret_cast<const frag_ab *>(qbase + (size_t)r * ld + kk * 32 + qd * 8);
+            qf[qs][kk] = z;
+        }
+    __syncthreads();
+    if (q0 >= S) return;                 // no barrier below
+
+    f32x4 O[QS][NDT];
+    float mrun[QS], lrun[QS];
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs) {
+        mrun[qs] = -INFINITY;
+        lrun[qs] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) O[qs][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // fragment addresses: K frag (16 keys t, k chunk kk*4 + qd): row = k0 + t*16 + r16 -> (row & 7) = r16 & 7 (k0, t*16 multiples of 16)
+    const char *kaddr[NKK];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) kaddr[kk] = sK + (size_t)r16 * 128 + (((kk * 4 + qd) ^ (r16 & 7)) << 4);
+    const char *const vaddr = sV + (size_t)r16 * vrs + qd * 16;
+    const int nsteps = Sp >> 5;
+    for (int st = 0; st < nsteps; ++st) {
+        frag_ab kf[2][NKK], vf[NDT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) kf[t][kk] = *reinterpret_cast<const frag_ab *>(kaddr[kk] + (size_t)(st * 32 + t * 16) * 128);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) vf[dt] = *reinterpret_cast<const frag_ab *>(vaddr + (size_t)dt * 16 * vrs + st * 64);
+        const bool tail = (st == nsteps - 1) && (S & 31);                 // the only step with keys past S
+        const int kb = st * 32 + qd * 4;
+#pragma unroll
+        for (int qs = 0; qs < QS; ++qs) {
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                s0 = mfma_f16(kf[0][kk], qf[qs][kk], s0);
+                s1 = mfma_f16(kf[1][kk], qf[qs][kk], s1);
+            }
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = s0[r] * scale_log2e;
+                v[4 + r] = s1[r] * scale_log2e;
+            }
+            if (tail) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (kb + r >= S) v[r] = -INFINITY;
+                    if (kb + 16 + r >= S) v[4 + r] = -INFINITY;
+                }
+            }
+            float tmax = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const bool raise = __any(tmax > mrun[qs]) != 0;               // wave-uniform
+            if (raise) {
+                const float m_new = fmaxf(mrun[qs], tmax);                // finite: every 32-key block holds >= 1 valid key
+                const float alpha = __builtin_amdgcn_exp2f(mrun[qs] - m_new);
+                mrun[qs] = m_new;
+                lrun[qs] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    O[qs][dt][0] *= alpha; O[qs][dt][1] *= alpha; O[qs][dt][2] *= alpha; O[qs][dt][3] *= alpha;
+                }
+            }
+            const float mq = mrun[qs];
+            float psum = 0.f;
+            frag_ab pb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float p = __builtin_amdgcn_exp2f(v[j] - mq);
+                psum += p;
+                pb[j] = (short)f2h(p);
+            }
+            lrun[qs] += psum;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) O[qs][dt] = mfma_f16(vf[dt], pb, O[qs][dt]);
+        }
+    }
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs) {
+        float l = lrun[qs];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const int r = q0 + qs * 16 + r16;
+        if (r < S) {
+            const float inv = 1.0f / l;
+            f16_t *orow = out + ((size_t)b * S + r) * D + (size_t)head * HD;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                ushort4 o16;
+                o16.x = f2h(O[qs][dt][0] * inv); o16.y = f2h(O[qs][dt][1] * inv); o16.z = f2h(O[qs][dt][2] * inv); o16.w = f2h(O[qs][dt][3] * inv);
+                *reinterpret_cast<ushort4 *>(orow + dt * 16 + qd * 4) = o16;
+            }
         }
     }
 }
@@ -322,7 +477,7 @@ struct VitLayer {
 };
 
 struct VitState {
-    int D, I, L, nh, hd, R, P, G, S, ph, pw;
+    int D, I, L, nh, hd, R, P, G, S, Sp, ph, pw;             // Sp: S rounded up to 32 (row length of V^T)
     float eps;
     const f16_t *wpe;
     const float *bpe, *pos;
@@ -342,6 +497,8 @@ struct VitState {
     uint8_t *frames_in = nullptr;        // graph-stable staging of the input frames
     bf16_t *out_stage = nullptr;         // graph-stable staging of the output embeddings
     std::map<int, hipGraphExec_t> graphs;     // batch size -> captured encode
+    int attn_vrs = 0;                         // vit_attn_head_kernel: bytes per V^T row in LDS ((vrs / 16) % 16 == 10: conflict-free fragment reads)
+    size_t attn_head_lds = 0;                 // its LDS footprint, 0 = the head does not fit (Sp > 608)
     hipStream_t st2 = nullptr;                // second branch of the captured encode (two half-batches run concurrently)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<void *> ws;
@@ -371,7 +528,7 @@ int vit_finalize(vlo_engine *e) {
     const vlo_config &c = e->cfg;
     VitState *v = new VitState();
     v->D = c.vit_hidden_size; v->I = c.vit_intermediate_size; v->L = c.vit_num_layers; v->nh = c.vit_num_heads;
-    v->hd = v->D / v->nh; v->R = c.vit_image_size; v->P = c.vit_patch_size; v->G = v->R / v->P; v->S = v->G * v->G;
+    v->hd = v->D / v->nh; v->R = c.vit_image_size; v->P = c.vit_patch_size; v->G = v->R / v->P; v->S = v->G * v->G; v->Sp = (v->S + 31) & ~31;
     v->ph = c.pool_h; v->pw = c.pool_w; v->eps = c.vit_ln_eps;
     const int D = v->D, I = v->I;
     if (v->hd != 64 || (D % 64) || D > 2048 || (I % 64) || ((3 * v->P * v->P) % 64) || (v->P % 8) || c.vision_hidden_size != D ||
@@ -444,6 +601,15 @@ int vit_finalize(vlo_engine *e) {
     }
 #undef TK
     VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnLds));
+    {
+        const int cpr = v->Sp / 8;                                   // 16-byte chunks per V^T row
+        v->attn_vrs = (cpr + ((10 - cpr % 16) + 16) % 16) * 16;
+        const size_t lds = (size_t)v->Sp * 128 + (size_t)64 * v->attn_vrs;
+        if (lds <= 160 * 1024 && v->Sp <= 608) {
+            v->attn_head_lds = lds;
+            VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+    }
     e->vit = v;
     return VLO_OK;
 }
@@ -470,7 +636,7 @@ static int vit_reserve(vlo_engine *e, VitState *v, int B) {
     const size_t Mp = M + 256;
     A((void **)&v->x16, Mp * D * 2);
     A((void **)&v->qk16, M * 2 * D * 2);
-    A((void **)&v->vT, M * D * 2);
+    A((void **)&v->vT, (size_t)B * D * v->Sp * 2);          // V^T [B][heads][64][Sp]; the pad columns [S, Sp) are never written: zeroed below
     A((void **)&v->att16, Mp * D * 2);
     A((void **)&v->mid16, Mp * I * 2);
     A((void **)&v->kv16, M * 2 * D * 2);
@@ -484,6 +650,7 @@ static int vit_reserve(vlo_engine *e, VitState *v, int B) {
     A((void **)&v->frames_in, (size_t)B * 3 * v->R * v->R);
     A((void **)&v->out_stage, (size_t)B * (1 + v->ph * v->pw) * e->cfg.hidden_size * 2);
     if (rc) return rc;
+    if (hipMemset(v->vT, 0, (size_t)B * D * v->Sp * 2) != hipSuccess) return vlo_fail(VLO_E_HIP, "vit workspace memset failed");
     v->Bcap = B;
     (void)e;
     return VLO_OK;
@@ -500,7 +667,7 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
     // ranges can run concurrently as parallel branches of one captured graph
     const size_t r0 = (size_t)b0 * S;
     float *const w_h = v->h + r0 * D, *const w_last = v->last + r0 * D, *const w_tmp32 = v->tmp32 + (size_t)b0 * D;
-    f16_t *const w_x16 = v->x16 + r0 * D, *const w_qk16 = v->qk16 + r0 * 2 * D, *const w_vT = v->vT + r0 * D, *const w_att16 = v->att16 + r0 * D,
+    f16_t *const w_x16 = v->x16 + r0 * D, *const w_qk16 = v->qk16 + r0 * 2 * D, *const w_vT = v->vT + (size_t)b0 * D * v->Sp, *const w_att16 = v->att16 + r0 * D,
           *const w_mid16 = v->mid16 + r0 * I, *const w_kv16 = v->kv16 + r0 * 2 * D, *const w_hatt16 = v->hatt16 + (size_t)b0 * D,
           *const w_ho16 = v->ho16 + (size_t)b0 * D, *const w_hx16 = v->hx16 + (size_t)b0 * D, *const w_hmid16 = v->hmid16 + (size_t)b0 * I;
     bf16_t *const w_tokens = v->tokens + (size_t)b0 * (1 + v->ph * v->pw) * D;
@@ -517,10 +684,16 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
         {
             GemmArgs a{};
             a.xpad = 1; a.X = w_x16; a.W = Ly.wqkv; a.bias = Ly.bqkv; a.out16 = w_qk16; a.outVT = w_vT;
-            a.M = M; a.N = 3 * D; a.K = D; a.ldx = D; a.ldo = 2 * D; a.S = S; a.D = D; a.hd = v->hd;
+            a.M = M; a.N = 3 * D; a.K = D; a.ldx = D; a.ldo = 2 * D; a.S = S; a.Sp = v->Sp; a.D = D; a.hd = v->hd;
             VIT_TRY(gemm_launch<EP_QKV>(a, st));
         }
-        hipLaunchKernelGGL((vit_attn_kernel<64>), dim3((S + 63) / 64, v->nh, B), dim3(256), kAttnLds, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
+        // batched frames: one workgroup per (frame, head) with K and V^T resident in LDS; few frames: 64-query tiles, keys split over 4 waves
+        static const int head_min = getenv("VLO_VIT_ATTN_HEAD_MIN") ? atoi(getenv("VLO_VIT_ATTN_HEAD_MIN")) : 96;     // workgroups; 0 = never
+        if (head_min > 0 && B * v->nh >= head_min && v->attn_head_lds > 0)
+            hipLaunchKernelGGL(vit_attn_head_kernel, dim3((S + 575) / 576, v->nh, B), dim3(768), v->attn_head_lds, st, w_qk16, w_vT, w_att16, S, D, v->nh,
+                               scale * 1.4426950408889634f, v->attn_vrs);
+        else
+            hipLaunchKernelGGL((vit_attn_kernel<64>), dim3((S + 63) / 64, v->nh, B), dim3(256), kAttnLds, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
         {
             GemmArgs a{};
             a.xpad = 1; a.X = w_att16; a.W = Ly.wo; a.bias = Ly.bo; a.out32 = w_h;
