@@ -259,7 +259,9 @@ def main():
                     help="storage of the streamed Llama projections; fp8 = e4m3 + per-channel scales (BASELINE.json configs[4]); the headline "
                          "metric is quoted on bf16")
     ap.add_argument("--no-prefetch", action="store_true")
-    ap.add_argument("--prefetch-frames", type=int, default=16, help="frames encoded ahead per batched ViT call (16 = two parallel 8-frame branches of the captured encode graph)")
+    ap.add_argument("--prefetch-frames", type=int, default=28,
+                    help="frames encoded ahead per batched ViT call (28 frames = 16128 token rows = 63 row tiles of 256: the 1024-wide GEMMs are 252 "
+                         "tiles, one round of the 256 CUs, the wider ones 756 / 1008)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=20)
     ap.add_argument("--prof-stride", type=int, default=8)

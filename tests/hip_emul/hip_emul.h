@@ -68,7 +68,7 @@ static inline int max(int a, int b) { return a > b ? a : b; }
 
 struct emul_wave_ctx {
     pthread_barrier_t bar;
-    unsigned slot[64];                   // shuffles
+    unsigned slot[64], slot2[64];        // shuffles, row swaps
     float A[16 * 32], B[32 * 16];        // MFMA operands
 };
 struct emul_block_ctx {
@@ -125,6 +125,21 @@ template <class T> static inline T __shfl_up(T v, unsigned delta, int /*width*/ 
     return emul_shfl_from(v, lane >= (int)delta ? lane - (int)delta : lane);
 }
 template <class T> static inline T __shfl(T v, int src, int /*width*/ = 64) { return emul_shfl_from(v, src & 63); }
+// v_permlane16_swap / v_permlane32_swap (gfx950): the ODD rows (of 16 / 32 lanes) of the first operand trade places with the EVEN
+// rows of the second one; returns {first, second} after the swap
+typedef unsigned emul_u32x2 __attribute__((ext_vector_type(2)));
+static inline emul_u32x2 emul_permlane_swap(unsigned vdst, unsigned src, int row) {
+    emul_wave_ctx &W = emul_ctx->waves[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63, odd = (lane / row) & 1;
+    W.slot[lane] = vdst;
+    W.slot2[lane] = src;
+    pthread_barrier_wait(&W.bar);
+    emul_u32x2 r = {odd ? W.slot2[lane - row] : vdst, odd ? src : W.slot[lane + row]};
+    pthread_barrier_wait(&W.bar);
+    return r;
+}
+#define __builtin_amdgcn_permlane16_swap(a, b, fi, bc) emul_permlane_swap((a), (b), 16)
+#define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) emul_permlane_swap((a), (b), 32)
 // wave vote: every lane publishes its predicate, every lane ORs the 64 slots
 static inline int __any(int pred) {
     emul_wave_ctx &W = emul_ctx->waves[threadIdx.x >> 6];

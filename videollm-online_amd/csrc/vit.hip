@@ -76,310 +76,7 @@ __global__ __launch_bounds__(256) void vit_layernorm_kernel(const float *__restr
     }
 }
 
-// ------------------------------------------------------------------------------------
-// non-causal MHSA, hd = 64.  grid = (ceil(S/64) q-tiles, heads, B); 4 waves.
-// Every wave owns ALL 64 query rows of the block (4 sub-tiles of 16) and an interleaved quarter of
-// the key blocks (flash-decoding inside the block): K / V^T fragments fetched once per 32 keys feed
-// 32 MFMAs instead of 8, each wave runs ceil(S/128) iterations instead of S/32, and the four
-// partial (m, l, O) states are merged through LDS.  Operand scheme as in llm_ops.hip:
-//   S^T[key][q] = K[key][:].Q[q][:]   (K rows = MFMA A operand straight from global/L2)
-//   O^T[d][q]  += V^T[d][key].P^T[key][q]   (V^T rows = A operand; P^T stays in the producing lanes)
-// ------------------------------------------------------------------------------------
-template <int HD>
-__global__ __launch_bounds__(256) void vit_attn_kernel(const f16_t *__restrict__ qk, const f16_t *__restrict__ vT,
-                                                       f16_t *__restrict__ out, int S, int D, int nheads, float scale) {
-    constexpr int NKK = HD / 32, NDT = HD / 16, QS = 4;
-    extern __shared__ __attribute__((aligned(16))) float4 lds4[];     // [4 waves][QS][NDT][64] O partials, then m/l
-    float *lds_ml = reinterpret_cast<float *>(lds4 + 4 * QS * NDT * 64);   // [4][QS][16][2]
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int qrow = lane & 15, qd = lane >> 4;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 64;
-    const size_t ld = (size_t)2 * D;
-    const f16_t *qbase = qk + (size_t)b * S * ld + (size_t)head * HD;
-    const f16_t *kbase = qbase + D;
-    const int Sp = (S + 31) & ~31;                                   // V^T rows: S rounded up to 32, tokens permuted inside 32-blocks (vt_pos)
-    const f16_t *vbase = vT + ((size_t)b * nheads + head) * HD * Sp;
-
-    frag_ab qf[QS][NKK];
-#pragma unroll
-    for (int qs = 0; qs < QS; ++qs)
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) {
-            frag_ab z = {0, 0, 0, 0, 0, 0, 0, 0};
-            const int r = q0 + qs * 16 + qrow;
-            if (r < S) z = *reinterpret_cast<const frag_ab *>(qbase + (size_t)r * ld + kk * 32 + qd * 8);
-            qf[qs][kk] = z;
-        }
-    f32x4 O[QS][NDT];
-    float mrun[QS], lrun[QS];
-#pragma unroll
-    for (int qs = 0; qs < QS; ++qs) {
-        mrun[qs] = -INFINITY;
-        lrun[qs] = 0.f;
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) O[qs][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-
-    for (int kt0 = w * 32; kt0 < S; kt0 += 128) {
-        frag_ab kf[2][NKK];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int key = min(kt0 + t * 16 + qrow, S - 1);
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk)
-                kf[t][kk] = *reinterpret_cast<const frag_ab *>(kbase + (size_t)key * ld + kk * 32 + qd * 8);
-        }
-        frag_ab vf[NDT];
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)          // keys kt0 + qd*4 .. +3 and kt0 + 16 + qd*4 .. +3: 16 contiguous bytes of the permuted row (pad columns are zero)
-            vf[dt] = *reinterpret_cast<const frag_ab *>(vbase + (size_t)(dt * 16 + qrow) * Sp + kt0 + qd * 8);
-        const int kb = kt0 + qd * 4;
-#pragma unroll
-        for (int qs = 0; qs < QS; ++qs) {
-            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-                s0 = mfma_f16(kf[0][kk], qf[qs][kk], s0);
-                s1 = mfma_f16(kf[1][kk], qf[qs][kk], s1);
-            }
-            float v[8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = (kb + r < S) ? s0[r] * scale : -INFINITY;
-                v[4 + r] = (kb + 16 + r < S) ? s1[r] * scale : -INFINITY;
-            }
-            float tmax = v[0];
-#pragma unroll
-            for (int j = 1; j < 8; ++j) tmax = fmaxf(tmax, v[j]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(mrun[qs], tmax);          // finite: every 32-key block holds >= 1 valid key
-            const float alpha = __expf(mrun[qs] - m_new);
-            mrun[qs] = m_new;
-            float psum = 0.f;
-            frag_ab pb;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float p = __expf(v[j] - m_new);
-                psum += p;
-                pb[j] = (short)f2h(p);
-            }
-            lrun[qs] = lrun[qs] * alpha + psum;
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                f32x4 o = O[qs][dt];
-                o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
-                O[qs][dt] = mfma_f16(vf[dt], pb, o);
-            }
-        }
-    }
-    // publish this wave's partial state
-#pragma unroll
-    for (int qs = 0; qs < QS; ++qs) {
-        float l = lrun[qs];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        if (qd == 0) {
-            lds_ml[((w * QS + qs) * 16 + qrow) * 2] = mrun[qs];
-            lds_ml[((w * QS + qs) * 16 + qrow) * 2 + 1] = l;
-        }
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            const f32x4 o = O[qs][dt];
-            lds4[((w * QS + qs) * NDT + dt) * 64 + lane] = make_float4(o[0], o[1], o[2], o[3]);
-        }
-    }
-    __syncthreads();
-    // wave w finalises query sub-tile w
-    const int qs = w;
-    const int r = q0 + qs * 16 + qrow;
-    float M = -INFINITY;
-#pragma unroll
-    for (int ww = 0; ww < 4; ++ww) M = fmaxf(M, lds_ml[((ww * QS + qs) * 16 + qrow) * 2]);
-    float wgt[4], Lsum = 0.f;
-#pragma unroll
-    for (int ww = 0; ww < 4; ++ww) {
-        const float ms = lds_ml[((ww * QS + qs) * 16 + qrow) * 2];
-        wgt[ww] = (ms == -INFINITY) ? 0.f : __expf(ms - M);
-        Lsum += lds_ml[((ww * QS + qs) * 16 + qrow) * 2 + 1] * wgt[ww];
-    }
-    if (r < S) {
-        const float inv = 1.0f / Lsum;
-        f16_t *orow = out + ((size_t)b * S + r) * D + (size_t)head * HD;
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            float4 acc = make_float4(0, 0, 0, 0);
-#pragma unroll
-            for (int ww = 0; ww < 4; ++ww) {
-                const float4 o = lds4[((ww * QS + qs) * NDT + dt) * 64 + lane];
-                acc.x += o.x * wgt[ww]; acc.y += o.y * wgt[ww]; acc.z += o.z * wgt[ww]; acc.w += o.w * wgt[ww];
-            }
-            ushort4 o16;
-            o16.x = f2h(acc.x * inv); o16.y = f2h(acc.y * inv); o16.z = f2h(acc.z * inv); o16.w = f2h(acc.w * inv);
-            *reinterpret_cast<ushort4 *>(orow + dt * 16 + qd * 4) = o16;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// Batched frames: one workgroup per (frame, head) with the head's WHOLE K [Sp][64] and V^T [64][Sp] resident in LDS (Sp <= 608:
-// 148 KiB for SigLIP-L/16-384's 576 tokens), 12 waves, each owning 48 queries (three 16-query sub-tiles) against all keys —
-// K and V^T are fetched from L2 / HBM once per head instead of once per 64-query tile (nine times), every fragment read is one
-// conflict-free ds_read_b128 (K rows XOR-swizzled by 16-byte chunks, V^T rows padded to a stride of 10 chunks mod 16), there is no
-// cross-wave merge, and three waves per SIMD interleave the softmax (VALU) of one wave with the MFMAs of the others.
-// Scores live in the exp2 domain (scale * log2 e folded into one multiplier); the accumulator rescale is skipped on steps where no
-// lane of the wave raised its running maximum (bit-identical: the factor would be exactly 1).
-// grid = (ceil(S / 576), heads, frames), 768 threads; LDS = Sp * 128 + 64 * vrs bytes.
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(768) void vit_attn_head_kernel(const f16_t *__restrict__ qk, const f16_t *__restrict__ vT, f16_t *__restrict__ out,
-                                                             int S, int D, int nheads, float scale_log2e, int vrs /* bytes per V^T row in LDS */) {
-    constexpr int HD = 64, NKK = 2, NDT = 4, QS = 3;
-    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
-    char *const sK = reinterpret_cast<char *>(lds4);                        // [Sp][128 B], chunk c of row r at chunk c ^ (r & 7)
-    const int Sp = (S + 31) & ~31;
-    char *const sV = sK + (size_t)Sp * 128;                                 // [64][vrs]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int r16 = lane & 15, qd = lane >> 4;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const size_t ld = (size_t)2 * D;
-    const f16_t *qbase = qk + (size_t)b * S * ld + (size_t)head * HD;
-    const f16_t *kbase = qbase + D;
-    const f16_t *vbase = vT + ((size_t)b * nheads + head) * HD * Sp;
-
-    // ---- fill: K rows (128 B each, 8 chunks) and V^T rows (Sp * 2 B each); every load is issued before the first LDS write
-    {
-        const int kchunks = Sp * 8, vcpr = Sp / 8, vchunks = HD * vcpr;     // 16-byte chunks
-        constexpr int MAXC = 7;                                              // (Sp * 8 + 64 * Sp / 8) / 768 <= 7 for Sp <= 608... 2 * 6.3
-        uint4 kreg[MAXC], vreg[MAXC];
-#pragma unroll
-        for (int i = 0; i < MAXC; ++i) {
-            const int c = tid + i * 768;
-            kreg[i] = make_uint4(0, 0, 0, 0);
-            if (c < kchunks) {
-                const int row = c >> 3;
-                if (row < S) kreg[i] = *reinterpret_cast<const uint4 *>(kbase + (size_t)row * ld + (c & 7) * 8);       // rows past S: zero
-            }
-            vreg[i] = make_uint4(0, 0, 0, 0);
-            if (c < vchunks) vreg[i] = *reinterpret_cast<const uint4 *>(vbase + (size_t)(c / vcpr) * Sp + (c % vcpr) * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < MAXC; ++i) {
-            const int c = tid + i * 768;
-            if (c < kchunks) {
-                const int row = c >> 3;
-                *reinterpret_cast<uint4 *>(sK + (size_t)row * 128 + (((c & 7) ^ (row & 7)) << 4)) = kreg[i];
-            }
-            if (c < vchunks) *reinterpret_cast<uint4 *>(sV + (size_t)(c / vcpr) * vrs + (c % vcpr) * 16) = vreg[i];
-        }
-    }
-    // ---- this wave's queries
-    const int q0 = blockIdx.x * (12 * QS * 16) + w * (QS * 16);
-    frag_ab qf[QS][NKK];
-#pragma unroll
-    for (int qs = 0; qs < QS; ++qs)
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) {
-            frag_ab z = {0, 0, 0, 0, 0, 0, 0, 0};
-            const int r = q0 + qs * 16 + r16;
-            if (r < S) z = *reinterpret_cast<const frag_ab *>(qbase + (size_t)r * ld + kk * 32 + qd * 8);
-            qf[qs][kk] = z;
-        }
-    __syncthreads();
-    if (q0 >= S) return;                 // no barrier below
-
-    f32x4 O[QS][NDT];
-    float mrun[QS], lrun[QS];
-#pragma unroll
-    for (int qs = 0; qs < QS; ++qs) {
-        mrun[qs] = -INFINITY;
-        lrun[qs] = 0.f;
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) O[qs][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    // fragment addresses: K frag (16 keys t, k chunk kk*4 + qd): row = k0 + t*16 + r16 -> (row & 7) = r16 & 7 (k0, t*16 multiples of 16)
-    const char *kaddr[NKK];
-#pragma unroll
-    for (int kk = 0; kk < NKK; ++kk) kaddr[kk] = sK + (size_t)r16 * 128 + (((kk * 4 + qd) ^ (r16 & 7)) << 4);
-    const char *const vaddr = sV + (size_t)r16 * vrs + qd * 16;
-    const int nsteps = Sp >> 5;
-    for (int st = 0; st < nsteps; ++st) {
-        frag_ab kf[2][NKK], vf[NDT];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) kf[t][kk] = *reinterpret_cast<const frag_ab *>(kaddr[kk] + (size_t)(st * 32 + t * 16) * 128);
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) vf[dt] = *reinterpret_cast<const frag_ab *>(vaddr + (size_t)dt * 16 * vrs + st * 64);
-        const bool tail = (st == nsteps - 1) && (S & 31);                 // the only step with keys past S
-        const int kb = st * 32 + qd * 4;
-#pragma unroll
-        for (int qs = 0; qs < QS; ++qs) {
-            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-                s0 = mfma_f16(kf[0][kk], qf[qs][kk], s0);
-                s1 = mfma_f16(kf[1][kk], qf[qs][kk], s1);
-            }
-            float v[8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = s0[r] * scale_log2e;
-                v[4 + r] = s1[r] * scale_log2e;
-            }
-            if (tail) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (kb + r >= S) v[r] = -INFINITY;
-                    if (kb + 16 + r >= S) v[4 + r] = -INFINITY;
-                }
-            }
-            float tmax = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const bool raise = __any(tmax > mrun[qs]) != 0;               // wave-uniform
-            if (raise) {
-                const float m_new = fmaxf(mrun[qs], tmax);                // finite: every 32-key block holds >= 1 valid key
-                const float alpha = __builtin_amdgcn_exp2f(mrun[qs] - m_new);
-                mrun[qs] = m_new;
-                lrun[qs] *= alpha;
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-                    O[qs][dt][0] *= alpha; O[qs][dt][1] *= alpha; O[qs][dt][2] *= alpha; O[qs][dt][3] *= alpha;
-                }
-            }
-            const float mq = mrun[qs];
-            float psum = 0.f;
-            frag_ab pb;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float p = __builtin_amdgcn_exp2f(v[j] - mq);
-                psum += p;
-                pb[j] = (short)f2h(p);
-            }
-            lrun[qs] += psum;
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) O[qs][dt] = mfma_f16(vf[dt], pb, O[qs][dt]);
-        }
-    }
-#pragma unroll
-    for (int qs = 0; qs < QS; ++qs) {
-        float l = lrun[qs];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        const int r = q0 + qs * 16 + r16;
-        if (r < S) {
-            const float inv = 1.0f / l;
-            f16_t *orow = out + ((size_t)b * S + r) * D + (size_t)head * HD;
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                ushort4 o16;
-                o16.x = f2h(O[qs][dt][0] * inv); o16.y = f2h(O[qs][dt][1] * inv); o16.z = f2h(O[qs][dt][2] * inv); o16.w = f2h(O[qs][dt][3] * inv);
-                *reinterpret_cast<ushort4 *>(orow + dt * 16 + qd * 4) = o16;
-            }
-        }
-    }
-}
+#include "vit_attn.inc"
 
 // MAP head attention: one probe query per head over S keys.  grid = (heads, B), 256 threads.
 // kv: fp16 [B*S][2D] (K | V row-major), qp: fp16 [D] (probe @ Wq + bq, precomputed at load)
@@ -607,7 +304,7 @@ int vit_finalize(vlo_engine *e) {
         const size_t lds = (size_t)v->Sp * 128 + (size_t)64 * v->attn_vrs;
         if (lds <= 160 * 1024 && v->Sp <= 608) {
             v->attn_head_lds = lds;
-            VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_head_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
     }
     e->vit = v;
@@ -690,7 +387,7 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
         // batched frames: one workgroup per (frame, head) with K and V^T resident in LDS; few frames: 64-query tiles, keys split over 4 waves
         static const int head_min = getenv("VLO_VIT_ATTN_HEAD_MIN") ? atoi(getenv("VLO_VIT_ATTN_HEAD_MIN")) : 96;     // workgroups; 0 = never
         if (head_min > 0 && B * v->nh >= head_min && v->attn_head_lds > 0)
-            hipLaunchKernelGGL(vit_attn_head_kernel, dim3((S + 575) / 576, v->nh, B), dim3(768), v->attn_head_lds, st, w_qk16, w_vT, w_att16, S, D, v->nh,
+            hipLaunchKernelGGL((vit_attn_head_kernel<0>), dim3((S + 575) / 576, v->nh, B), dim3(768), v->attn_head_lds, st, w_qk16, w_vT, w_att16, S, D, v->nh,
                                scale * 1.4426950408889634f, v->attn_vrs);
         else
             hipLaunchKernelGGL((vit_attn_kernel<64>), dim3((S + 63) / 64, v->nh, B), dim3(256), kAttnLds, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
