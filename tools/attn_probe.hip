@@ -56,6 +56,7 @@ int main(int argc, char **argv) {
         const char *names[4] = {"tile64", "head", "head-nosoftmax", "head-nofill"};
         std::vector<f16_t> r0((size_t)B * S * D), r1((size_t)B * S * D);
         for (int which = 0; which < 4; ++which) {
+            if (getenv("ATTN_PROBE_ONLY") && strcmp(getenv("ATTN_PROBE_ONLY"), names[which])) continue;
             f16_t *out = which == 0 ? o0 : o1;
             run(which, out);
             CK(hipStreamSynchronize(st));
