@@ -1,0 +1,261 @@
+"""Long GPU parity runs (opt-in: VLO_LONG_TESTS=1 — minutes of CPU oracle time each; the numbers they print are kept in
+profiles/r3_parity_measurements.txt).
+
+* the TIMED PATH AS ONE TRACE: the package's LiveInfer with the bench's settings (batched prefetch of 28 frames on the encode
+  stream, staging buffer, fused sampler, speculative greedy loop) over all 1 200 frames of BASELINE.json configs[1]'s stream
+  (2 distinct Llama-3-8B-width layers + 2 SigLIP-L layers, KV to > 13 k tokens), scheduled AND free-running, followed decision by
+  decision by the oracle's restatement of demo/inference.py:40-123 teacher-forced with the engine's own tokens and frame
+  embeddings: every sampler decision and every greedy token must be the reference-bf16 path's, except at a near-tie of the
+  reference's own logits where the engine may pick the runner-up;
+* config 3's context: all-row logits 3-way at 66 000 cached tokens (narrow 3-layer model with the 8B head geometry);
+* tensor-parallel logical ranks T = 8 at 13 k cached tokens.
+"""
+import collections
+import os
+
+import pytest
+import torch
+
+from oracle import vlo_oracle as O
+from tests.parity_util import fmt, ulp_report
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("VLO_LONG_TESTS") != "1", reason="long parity runs: VLO_LONG_TESTS=1")]
+
+NEAR_TIE = 0.12     # logit units, as tests/test_gpu_liveinfer.py
+
+
+class Follower(O.LiveInferOracle):
+    """LiveInferOracle driven in lock-step with a finished engine run: frame embeddings and every token come from the engine's
+    trace; at each decision the oracle's own choice is compared with the engine's and the margin of the oracle's logits decides
+    whether a difference is a near-tie."""
+
+    def __init__(self, llm, tokens, frame_num_tokens, engine_trace, engine_embeds, schedule=None, max_new=100):
+        vs = O.VitSpec()
+        super().__init__(llm, None, vs, tokens, frame_fps=2, schedule=schedule, max_new=max_new)
+        self.frame_num_tokens = frame_num_tokens
+        self.ev = collections.deque(engine_trace)
+        self.emb = engine_embeds
+        self.stats = collections.Counter()
+
+    def input_video_stream(self, video_time):
+        frame_idx = int(video_time * self.frame_fps)
+        if frame_idx > self.last_frame_idx:
+            for r in range(self.last_frame_idx + 1, frame_idx + 1):
+                self.frame_embeds_queue.append((r / self.frame_fps, self.emb[r]))
+        self.last_frame_idx = frame_idx
+        self.video_time = video_time
+
+    def _judge(self, kind, mine, theirs, margin_runner):
+        self.stats[kind] += 1
+        if mine == theirs:
+            self.stats[kind + "_same"] += 1
+            return
+        margin, runner = margin_runner
+        assert margin < NEAR_TIE and theirs == runner, f"{kind} #{self.stats[kind]}: engine {theirs} vs reference {mine} (margin {margin:.4f}, runner-up {runner})"
+        self.stats[kind + "_near_tie"] += 1
+
+    def _call_for_streaming(self):                                     # demo/inference.py:54-82, decisions taken from the engine
+        while self.frame_embeds_queue:
+            if self.query_queue and self.frame_embeds_queue[0][0] > self.query_queue[0][0]:
+                return self.query_queue.popleft()
+            video_time, frame_embeds = self.frame_embeds_queue.popleft()
+            if not self.past_key_values:
+                self.last_ids = list(self.tok.start_ids)
+            elif self.last_ids == [self.tok.eos_token_id]:
+                self.last_ids = self.last_ids + list(self.tok.stream_prompt_ids)
+            H = self.llm.spec.hidden_size
+            inputs = torch.cat([self.llm.embed(torch.tensor(self.last_ids, dtype=torch.long)).view(-1, H), frame_embeds.view(-1, H)], dim=0)
+            logits, self.past_key_values = self.llm.forward(inputs, self.past_key_values)
+            self._frames_done += 1
+            if self.query_queue and video_time >= self.query_queue[0][0]:
+                return self.query_queue.popleft()
+            ev = self.ev.popleft()
+            assert ev[0] == "frame" and ev[1] == video_time and ev[3] == len(self.past_key_values), (ev, video_time, len(self.past_key_values))
+            zeroed = float(logits[-1].softmax(dim=-1)[self.tok.interval_id]) < self.threshold
+            tok, _ = O.stream_sample(logits[-1], self.tok.interval_id, self.threshold)
+            self._judge("sampler", tok, ev[4], O.top2_margin(logits[-1], self.tok.interval_id if zeroed else None, tok))
+            self.last_ids = [ev[2]]                                    # the token the engine went on with (scheduled or sampled)
+            if ev[2] != self.tok.interval_id:
+                return video_time, None
+        return None, None
+
+    def _call_for_response(self, video_time, query):                   # :40-52, teacher-forced with the engine's tokens
+        ev = self.ev.popleft()
+        assert ev[0] == "response" and ev[1] == video_time and ev[2] == query, (ev[:3], video_time, query)
+        self.last_ids = list(self.tok.query_ids[query]) if query is not None else list(self.tok.stream_generation_ids)
+        forced = self.schedule(self._frames_done - 1) if self.schedule is not None else None
+        x = self.llm.embed(torch.tensor(self.last_ids))
+        eos, V = self.tok.eos_token_id, self.llm.spec.vocab_size
+        for i, t in enumerate(ev[3]):
+            logits, self.past_key_values = self.llm.forward(x, self.past_key_values)
+            mine = int(logits[-1].argmax(dim=-1))
+            if forced is not None:                                     # forced_generate's rules
+                if i == len(ev[3]) - 1:
+                    mine = t if t == eos else mine
+                elif mine == eos:
+                    mine = (eos + 1) % V
+            if not (forced is not None and i == len(ev[3]) - 1):
+                self._judge("greedy", mine, t, O.top2_margin(logits[-1]))
+            if i < len(ev[3]) - 1:
+                x = self.llm.embed(torch.tensor([t]))
+        if forced is None:
+            assert ev[3][-1] == eos or len(ev[3]) == self.max_new
+        self.last_ids = list(ev[3][-1:])
+        return query, ev[3]
+
+
+@pytest.mark.parametrize("mode", ["scheduled", "free"])
+def test_liveinfer_1200_frame_stream_is_the_reference_trace(mode):
+    from videollm_online_amd.engine import Engine, EngineConfig
+    from videollm_online_amd.inference import LiveInfer, StreamTokens
+    from videollm_online_amd.modeling_live import LiveModel
+    from videollm_online_amd.synthetic import gpu_synthetic_frames
+    spec, vspec = O.LLM_SPECS["llama-3-8b-2l"], O.VIT_SPECS["siglip-l16-384-2l"]
+    T = int(os.environ.get("VLO_LONG_FRAMES", "1200"))
+    w, vw = O.init_llm_weights(spec, seed=31), O.init_vit_weights(vspec, seed=32)
+    toks = O.default_tokens(spec, seed=7, n_start=35)
+    cfg = EngineConfig(hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size, num_hidden_layers=spec.num_layers,
+                       num_attention_heads=spec.num_heads, num_key_value_heads=spec.num_kv_heads, vocab_size=spec.vocab_size,
+                       rope_theta=spec.rope_theta, rms_norm_eps=spec.rms_eps, vision_hidden_size=spec.vision_hidden_size,
+                       kv_pool_tokens=64 + 11 * T + (T // 10 + 2) * 24 + 4096 if mode == "scheduled" else 64 + 40 * T,
+                       frame_num_tokens=vspec.frame_num_tokens, frame_token_pooled=vspec.pooled,
+                       vit=dict(hidden_size=vspec.hidden_size, intermediate_size=vspec.intermediate_size, num_layers=vspec.num_layers,
+                                num_heads=vspec.num_heads, image_size=vspec.image_size, patch_size=vspec.patch_size, ln_eps=vspec.ln_eps))
+    eng = Engine(cfg)
+    eng.load_weights(w)
+    eng.load_weights(vw)
+    eng.load_weight("rope.inv_freq", O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+    eng.finalize()
+    model = LiveModel(eng, eos_token_id=toks.eos_token_id, frame_token_interval_id=toks.interval_id, frame_resolution=vspec.image_size)
+    st = StreamTokens(toks.start_ids, toks.stream_prompt_ids, toks.stream_generation_ids, toks.eos_token_id, toks.interval_id, dict(toks.query_ids))
+    sched = (lambda i: (i % 10 == 9, 16)) if mode == "scheduled" else None          # bench.py make_schedule("scheduled")
+    max_new = 100 if mode == "scheduled" else 8
+    li = LiveInfer(model, tokens=st, frame_fps=2, prefetch=True, prefetch_frames=28, schedule=sched, max_new_tokens=max_new, record=1 << 22)
+    frames = gpu_synthetic_frames(T, seed=1234)
+    # the embeddings LiveInfer consumes, as it batches them (first frame alone, then 28 at a time on the encode stream)
+    embeds = {}
+    inner = eng.visual_embed
+
+    def recording_embed(fr, stream=None, out=None):
+        e = inner(fr, stream, out)
+        lo = (fr.data_ptr() - frames.data_ptr()) // (3 * vspec.image_size * vspec.image_size)
+        for j in range(fr.shape[0]):
+            embeds[lo + j] = e[j * vspec.frame_num_tokens:(j + 1) * vspec.frame_num_tokens]
+        return e
+    eng.visual_embed = recording_embed
+    li.load_video(frames)
+    query = next(iter(toks.query_ids))
+    li.input_query_stream(query, video_time=0.0)
+    for i in range(T):
+        li.input_video_stream(i / 2)
+        li()
+    torch.cuda.synchronize()
+    trace = list(li.trace)
+    kv_end = len(li.past_key_values)
+    assert kv_end == sum(n for _, n in li.step_log)
+    emb_cpu = {k: v.cpu() for k, v in embeds.items()}
+    assert sorted(emb_cpu) == list(range(T))
+    f = Follower(O.LlamaOracle(spec, w, torch.bfloat16), toks, vspec.frame_num_tokens, trace, emb_cpu, schedule=sched, max_new=max_new)
+    f.load_video(torch.empty(T, 0))
+    f.input_query_stream(query, video_time=0.0)
+    for i in range(T):
+        f.input_video_stream(i / 2)
+        f()
+    assert not f.ev, f"{len(f.ev)} engine events were never reached by the reference flow"
+    assert len(f.past_key_values) == kv_end
+    s = f.stats
+    print(f"[liveinfer {mode} {T} frames] KV {kv_end} tokens, {len(trace)} events | sampler decisions {s['sampler']}: identical {s['sampler_same']}, "
+          f"near-tie runner-up {s['sampler_near_tie']} | greedy tokens {s['greedy']}: identical {s['greedy_same']}, near-tie runner-up {s['greedy_near_tie']}")
+    assert s["sampler"] >= T - 2 and s["sampler_same"] >= 0.97 * s["sampler"]
+    assert s["greedy"] == 0 or s["greedy_same"] >= 0.93 * s["greedy"]
+    li.reset()
+    eng.close()
+
+
+def test_config3_context_66k_logits_parity():
+    """BASELINE.json configs[2] ends at ~66 k cached tokens: the cache of a narrow 3-layer model with the 8B head geometry (4 query
+    heads of 128 on 2 kv heads) is filled to 66 000 tokens through the engine's block path and, in lock-step, through the oracle in
+    bf16 and fp32; a frame step (n = 11) and a decode step then compare all rows' LOGITS 3-way (258 KV pages, maximum split count)."""
+    from tests.test_gpu_llm import _engine, _three_way, MAX_ULPS_AT_SCALE
+    spec = O.LLM_SPECS["toy128"]
+    w = O.init_llm_weights(spec, seed=41)
+    toks = O.default_tokens(spec, seed=7, n_start=35)
+    ref, gold = O.LlamaOracle(spec, w, torch.bfloat16), O.LlamaOracle(spec, w, torch.float32)
+    target = int(os.environ.get("VLO_LONG_LC", "66000"))
+    eng = _engine(spec, w, kv_pool_tokens=target + 1024)
+    sess = eng.new_session()
+    g = torch.Generator().manual_seed(5)
+    H = spec.hidden_size
+    rc = gc = None
+    Lc = 0
+    while Lc < target:
+        m = min(2048, target - Lc)
+        x = (torch.randn(m, H, generator=g) * 0.7).bfloat16()
+        _, rc = ref.forward(x, rc, logits_from=m)
+        _, gc = gold.forward(x, gc, logits_from=m)
+        eng.llm_step(sess, x.cuda(), want_last=False)
+        Lc += m
+    frame = torch.cat([ref.embed(torch.tensor([toks.interval_id])), (torch.randn(10, H, generator=g) * 0.7).bfloat16()])
+    for kind, x in (("frame n=11", frame), ("decode n=1", ref.embed(torch.tensor([17])))):
+        rl, rc = ref.forward(x, rc)
+        gl, gc = gold.forward(x, gc)
+        _, allr = eng.llm_step(sess, x.cuda(), want_last=False, want_all=True)
+        torch.cuda.synchronize()
+        allr = allr.cpu()
+        e, r, scale = _three_way(allr, rl, gl)
+        rep = ulp_report(allr, rl)
+        print(f"[toy128 3 layers] Lc={Lc} {kind}: engine err {e:.4g} ref-bf16 err {r:.4g} scale {scale:.3g} | engine vs ref-bf16: {fmt(rep)}")
+        assert e <= 1.5 * r + 1e-3 * scale, f"Lc={Lc} {kind}: engine err {e} vs reference-bf16 err {r}"
+        assert rep["max_ulps_scale"] <= MAX_ULPS_AT_SCALE, fmt(rep)
+        Lc += x.shape[0]
+    assert len(sess) == len(rc) == Lc
+    sess.close()
+    eng.close()
+
+
+def test_tensor_parallel_8_logical_ranks_at_13k_context():
+    """TP = 8 logical ranks (sharding arithmetic + exchanges on one GPU) at configs[1]'s context: two distinct 8B-width layers, the
+    cache filled to 13 245 tokens through the TP step path, then a frame step and a decode step 3-way on the last row's logits."""
+    from videollm_online_amd.engine import EngineConfig, TpGroup
+    from tests.test_gpu_llm import _three_way
+    spec = O.LLM_SPECS["llama-3-8b-2l"]
+    w = O.init_llm_weights(spec, seed=11)
+    toks = O.default_tokens(spec, seed=7, n_start=35)
+    ref, gold = O.LlamaOracle(spec, w, torch.bfloat16), O.LlamaOracle(spec, w, torch.float32)
+    cfg = EngineConfig(hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size, num_hidden_layers=spec.num_layers,
+                       num_attention_heads=spec.num_heads, num_key_value_heads=spec.num_kv_heads, vocab_size=spec.vocab_size,
+                       rope_theta=spec.rope_theta, rms_norm_eps=spec.rms_eps, vision_hidden_size=spec.vision_hidden_size, kv_pool_tokens=16384)
+    for allreduce in ("default", "p2p"):
+        grp = TpGroup(cfg, 8, allreduce=allreduce)
+        grp.load_weights(w)
+        grp.load_weight("rope.inv_freq", O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+        grp.finalize()
+        sess = grp.new_session()
+        g = torch.Generator().manual_seed(12)
+        H = spec.hidden_size
+        rc = gc = None
+        Lc, target = 0, int(os.environ.get("VLO_LONG_TP_LC", "13245"))
+        while Lc < target:
+            m = min(1024, target - Lc)
+            x = (torch.randn(m, H, generator=g) * 0.7).bfloat16()
+            if allreduce == "default":
+                _, rc = ref.forward(x, rc, logits_from=m)
+                _, gc = gold.forward(x, gc, logits_from=m)
+            grp.llm_step(sess, x.cuda(), want_last=False)
+            Lc += m
+        if allreduce == "default":
+            saved = (rc, gc)
+        frame = torch.cat([ref.embed(torch.tensor([toks.interval_id])), (torch.randn(10, H, generator=g) * 0.7).bfloat16()])
+        rc, gc = saved
+        for kind, x in (("frame n=11", frame), ("decode n=1", ref.embed(torch.tensor([17])))):
+            rl, rc2 = ref.forward(x, rc)
+            gl, gc2 = gold.forward(x, gc)
+            last, _ = grp.llm_step(sess, x.cuda())
+            torch.cuda.synchronize()
+            e, r, scale = _three_way(last.cpu(), rl[-1], gl[-1])
+            print(f"[TP=8 logical, {allreduce}] Lc={Lc} {kind}: engine err {e:.4g} ref-bf16 err {r:.4g} scale {scale:.3g}")
+            assert e <= 1.5 * r + 1e-3 * scale, (allreduce, kind, e, r)
+            rc, gc = rc2, gc2
+            Lc += x.shape[0]
+        sess.close()
+        grp.close()

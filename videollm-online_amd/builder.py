@@ -64,6 +64,13 @@ def build_model_and_tokenizer(*, is_training: bool = False, llm_pretrained: str 
         raise FileNotFoundError(f"llm_pretrained must be a local checkpoint directory, got {llm_pretrained!r}")
     hf = json.load(open(os.path.join(llm_pretrained, "config.json")))
     rope = hf.get("rope_parameters") or {}
+    scaling = hf.get("rope_scaling") or ({} if rope.get("rope_type", "default") in ("default", None) else rope)
+    if scaling and scaling.get("rope_type", scaling.get("type", "default")) != "default":
+        raise NotImplementedError(f"rope scaling {scaling!r} is not implemented (the engine builds the plain rotary table of HF's "
+                                  f"LlamaRotaryEmbedding; Llama-3.1-style 'llama3' scaling would give wrong logits silently)")
+    for what, path in (("vision_pretrained", vision_pretrained if set_vision_inside else None), ("resume_from_checkpoint", resume_from_checkpoint or None)):
+        if path is not None and not os.path.isdir(path):
+            raise FileNotFoundError(f"{what} must be a local directory (hub ids are not resolved: there is no network path in the engine), got {path!r}")
     vit = _vit_config(vision_pretrained) if set_vision_inside else None
     cfg = EngineConfig(hidden_size=hf["hidden_size"], intermediate_size=hf["intermediate_size"],
                        num_hidden_layers=hf["num_hidden_layers"], num_attention_heads=hf["num_attention_heads"],

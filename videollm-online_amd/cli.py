@@ -82,6 +82,8 @@ def main(argv=None):
         if not query and not response:
             history["conversation"].append({"time": liveinfer.video_time, "fps": fps, "cost": timecosts[-1]})
     if feed is not None:
+        if feed.error is not None:
+            raise RuntimeError(f"the video decoder failed: {feed.error}") from feed.error
         feed.proc.kill()                                 # the loop may stop before the file ends
     json.dump(history, open(args.out, "w"), indent=4)
     print(f"Average Processing FPS: {fps:.1f}.  The conversation history has been saved to {args.out}.")

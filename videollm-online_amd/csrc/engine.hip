@@ -853,19 +853,27 @@ int vlo_greedy_generate(vlo_session *s, const void *embeds_dev, int m, int eos_t
         volatile int64_t *slot = s->host_tok + (i & 1);
         HIP_TRY(hipMemcpyAsync((void *)slot, out_ids_dev + i, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord(s->tok_ev[i & 1], st));
-        if (!last) {
+        // speculate only when the step needs nothing it could fail to get: a position inside the pages the session already owns.
+        // (An EOS on the last KV slot, or one page short of an exhausted pool, must end the response as the reference's loop
+        // does, not fail on a step that would be thrown away.)
+        const bool spec = !last && s->len + 1 <= (int64_t)s->pages.size() * VLO_PAGE_TOKENS && s->len + 1 <= e->max_positions;
+        if (spec) {
             HIP_TRY(embed_gather_launch((const unsigned short *)e->embed, out_ids_dev + i, 1, e->cfg.hidden_size, V, s->emb1, st));
             if ((rc = vlo_llm_step(s, s->emb1, 1, nullptr, nullptr, stream))) return rc;
         }
         HIP_TRY(hipEventSynchronize(s->tok_ev[i & 1]));
         if (*slot == eos_token_id) {
-            if (!last) {
+            if (spec) {
                 s->len -= 1;                 // the EOS token is never fed to the model (:179-181)
                 s->has_logits = false;
             }
             break;
         }
         if (last) break;
+        if (!spec) {                         // the blocking order of the reference: token known, then the step (which may need a page)
+            HIP_TRY(embed_gather_launch((const unsigned short *)e->embed, out_ids_dev + i, 1, e->cfg.hidden_size, V, s->emb1, st));
+            if ((rc = vlo_llm_step(s, s->emb1, 1, nullptr, nullptr, stream))) { if (n_written) *n_written = i + 1; return rc; }
+        }
     }
     HIP_TRY(hipStreamSynchronize(st));        // the ids are read by the caller right away
     if (n_written) *n_written = i + 1;

@@ -117,8 +117,11 @@ class LiveInfer:
             self.step_log.append((Lc, n))
 
     def drop_prefetched(self):
-        """Forget frames encoded ahead and not yet queued (they are simply encoded again when their time comes)."""
-        self._encoded.clear()
+        """Forget frames encoded ahead and not yet queued: with a resident video they are simply encoded again when their time
+        comes.  A FrameRing has already been told it may overwrite them (their encode has read them), so there the embeddings are
+        kept — dropping them would leave frames that can no longer be encoded."""
+        if self._ring is None:
+            self._encoded.clear()
 
     def load_video(self, video):                                       # :111-115
         """``video``: uint8 tensor [T,3,R,R] (what read_video(..., output_format='TCHW') yields for the ffmpeg-prepared file),
@@ -183,7 +186,13 @@ class LiveInfer:
         if frame_idx > self.last_frame_idx:
             ranger = range(self.last_frame_idx + 1, frame_idx + 1)
             if self._ring is not None and not self._ring.closed:
+                if ranger.stop - self._ring.tail > self._ring.capacity:
+                    raise RuntimeError(f"input_video_stream({video_time}) needs frames [{ranger.start}, {ranger.stop}) at once but the FrameRing holds "
+                                       f"{self._ring.capacity}: advance the stream in smaller steps (or build a larger ring)")
                 self._ring.wait_for(ranger.stop, self.frame_wait_s)   # a live feed: the frames of this instant may still be on their way
+            feed_error = getattr(getattr(self._ring, "feed", None), "error", None)
+            if feed_error is not None:
+                raise RuntimeError(f"the video decoder feeding the FrameRing failed: {feed_error}") from feed_error
             self._encode_async(ranger.start, ranger.stop)
             for r in ranger:
                 if r not in self._encoded:
@@ -261,13 +270,14 @@ class LiveInfer:
                               tok_out=self._tok_dev, p_out=self._p_dev)
             self._tok_host.copy_(self._tok_dev, non_blocking=True)
             self._main.synchronize()
-            tok = int(self._tok_host[0])
+            tok = sampled = int(self._tok_host[0])
             forced = self.schedule(self._frames_done - 1) if self.schedule is not None else None
             if forced is not None:
                 tok = self._added_stream_generation_ids[0] if forced[0] else self.frame_token_interval_id
             self.last_ids = [tok]
             if self._record:
-                self.trace.append(("frame", video_time, tok, len(self.past_key_values)))
+                # (kind, time, token used, KV length, token the sampler chose — differs from the one used only under a schedule)
+                self.trace.append(("frame", video_time, tok, len(self.past_key_values), sampled))
             if tok != self.frame_token_interval_id:
                 return video_time, None
         return None, None

@@ -43,6 +43,7 @@ class FrameRing:
         self._ready = {}                                 # absolute frame index -> event (prepared frame is in the ring)
         self._released = None                            # event after which released positions are no longer read
         self.closed = False                              # no more frames will come
+        self.feed = None                                 # the DecoderFeed filling this ring, if any
         self._cv = threading.Condition()                 # push() may run on a feeder thread, window() / release() on the consumer's
 
     def __len__(self):
@@ -179,6 +180,7 @@ class DecoderFeed(threading.Thread):
         self.argv, self.ring, self.full_timeout = list(argv), ring, full_timeout
         self.error = None
         self.frames = 0
+        ring.feed = self                               # LiveInfer.input_video_stream reports a decoder failure instead of "frame N is not available"
         self.proc = subprocess.Popen(self.argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, bufsize=0)
         self.start()
 
