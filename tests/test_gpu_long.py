@@ -11,6 +11,7 @@ profiles/r3_parity_measurements.txt).
 * tensor-parallel logical ranks T = 8 at 13 k cached tokens.
 """
 import collections
+import math
 import os
 
 import pytest
@@ -45,14 +46,20 @@ class Follower(O.LiveInferOracle):
         self.last_frame_idx = frame_idx
         self.video_time = video_time
 
-    def _judge(self, kind, mine, theirs, margin_runner):
+    def _judge(self, kind, mine, theirs, margin_runner, logits_row):
         self.stats[kind] += 1
         if mine == theirs:
             self.stats[kind + "_same"] += 1
             return
         margin, runner = margin_runner
-        assert margin < NEAR_TIE and theirs == runner, f"{kind} #{self.stats[kind]}: engine {theirs} vs reference {mine} (margin {margin:.4f}, runner-up {runner})"
+        # a near-tie of the reference's own bf16 logits: the top two within NEAR_TIE, or within two bf16 ulps of the top logit
+        # (one ulp is 0.0625 at |logit| 8-16 and 0.125 at 16-32, the range the 8B-width logits live in)
+        top = float(logits_row.float().abs().max())
+        tie = max(NEAR_TIE, 2.0 * 2.0 ** (math.floor(math.log2(max(top, 1e-6))) - 7))
+        assert margin <= tie and theirs == runner, (f"{kind} #{self.stats[kind]}: engine {theirs} vs reference {mine} (margin {margin:.4f}, "
+                                                     f"near-tie bound {tie:.4f}, runner-up {runner})")
         self.stats[kind + "_near_tie"] += 1
+        self.worst_tie = max(getattr(self, "worst_tie", 0.0), margin)
 
     def _call_for_streaming(self):                                     # demo/inference.py:54-82, decisions taken from the engine
         while self.frame_embeds_queue:
@@ -73,7 +80,7 @@ class Follower(O.LiveInferOracle):
             assert ev[0] == "frame" and ev[1] == video_time and ev[3] == len(self.past_key_values), (ev, video_time, len(self.past_key_values))
             zeroed = float(logits[-1].softmax(dim=-1)[self.tok.interval_id]) < self.threshold
             tok, _ = O.stream_sample(logits[-1], self.tok.interval_id, self.threshold)
-            self._judge("sampler", tok, ev[4], O.top2_margin(logits[-1], self.tok.interval_id if zeroed else None, tok))
+            self._judge("sampler", tok, ev[4], O.top2_margin(logits[-1], self.tok.interval_id if zeroed else None, tok), logits[-1])
             self.last_ids = [ev[2]]                                    # the token the engine went on with (scheduled or sampled)
             if ev[2] != self.tok.interval_id:
                 return video_time, None
@@ -95,7 +102,7 @@ class Follower(O.LiveInferOracle):
                 elif mine == eos:
                     mine = (eos + 1) % V
             if not (forced is not None and i == len(ev[3]) - 1):
-                self._judge("greedy", mine, t, O.top2_margin(logits[-1]))
+                self._judge("greedy", mine, t, O.top2_margin(logits[-1]), logits[-1])
             if i < len(ev[3]) - 1:
                 x = self.llm.embed(torch.tensor([t]))
         if forced is None:
@@ -165,7 +172,7 @@ def test_liveinfer_1200_frame_stream_is_the_reference_trace(mode):
     assert len(f.past_key_values) == kv_end
     s = f.stats
     print(f"[liveinfer {mode} {T} frames] KV {kv_end} tokens, {len(trace)} events | sampler decisions {s['sampler']}: identical {s['sampler_same']}, "
-          f"near-tie runner-up {s['sampler_near_tie']} | greedy tokens {s['greedy']}: identical {s['greedy_same']}, near-tie runner-up {s['greedy_near_tie']}")
+          f"near-tie runner-up {s['sampler_near_tie']} | greedy tokens {s['greedy']}: identical {s['greedy_same']}, near-tie runner-up {s['greedy_near_tie']} | largest margin at a flip {getattr(f, 'worst_tie', 0.0):.4f}")
     assert s["sampler"] >= T - 2 and s["sampler_same"] >= 0.97 * s["sampler"]
     assert s["greedy"] == 0 or s["greedy_same"] >= 0.93 * s["greedy"]
     li.reset()
