@@ -46,18 +46,21 @@ class Follower(O.LiveInferOracle):
         self.last_frame_idx = frame_idx
         self.video_time = video_time
 
-    def _judge(self, kind, mine, theirs, margin_runner, logits_row):
+    def _judge(self, kind, mine, theirs, logits_row, excluded=None):
         self.stats[kind] += 1
         if mine == theirs:
             self.stats[kind + "_same"] += 1
             return
-        margin, runner = margin_runner
-        # a near-tie of the reference's own bf16 logits: the top two within NEAR_TIE, or within two bf16 ulps of the top logit
-        # (one ulp is 0.0625 at |logit| 8-16 and 0.125 at 16-32, the range the 8B-width logits live in)
-        top = float(logits_row.float().abs().max())
-        tie = max(NEAR_TIE, 2.0 * 2.0 ** (math.floor(math.log2(max(top, 1e-6))) - 7))
-        assert margin <= tie and theirs == runner, (f"{kind} #{self.stats[kind]}: engine {theirs} vs reference {mine} (margin {margin:.4f}, "
-                                                     f"near-tie bound {tie:.4f}, runner-up {runner})")
+        # a near-tie of the reference's own bf16 logits: the engine's token must be one of the reference's top candidates, i.e. its
+        # reference logit lies within NEAR_TIE, or within two bf16 ulps of the top logit, of the reference's maximum (one ulp is 0.0625
+        # at |logit| 8-16 and 0.125 at 16-32, where the 8B-width logits live; random weights tie three and more tokens at times)
+        row = logits_row.float().clone()
+        if excluded is not None:
+            row[excluded] = -float("inf")
+        top = float(row.max())
+        tie = max(NEAR_TIE, 2.0 * 2.0 ** (math.floor(math.log2(max(abs(top), 1e-6))) - 7))
+        margin = top - float(row[theirs])
+        assert margin <= tie, f"{kind} #{self.stats[kind]}: engine {theirs} vs reference {mine}: the engine's token is {margin:.4f} below the reference's top logit (near-tie bound {tie:.4f})"
         self.stats[kind + "_near_tie"] += 1
         self.worst_tie = max(getattr(self, "worst_tie", 0.0), margin)
 
@@ -80,7 +83,7 @@ class Follower(O.LiveInferOracle):
             assert ev[0] == "frame" and ev[1] == video_time and ev[3] == len(self.past_key_values), (ev, video_time, len(self.past_key_values))
             zeroed = float(logits[-1].softmax(dim=-1)[self.tok.interval_id]) < self.threshold
             tok, _ = O.stream_sample(logits[-1], self.tok.interval_id, self.threshold)
-            self._judge("sampler", tok, ev[4], O.top2_margin(logits[-1], self.tok.interval_id if zeroed else None, tok), logits[-1])
+            self._judge("sampler", tok, ev[4], logits[-1], self.tok.interval_id if zeroed else None)
             self.last_ids = [ev[2]]                                    # the token the engine went on with (scheduled or sampled)
             if ev[2] != self.tok.interval_id:
                 return video_time, None
@@ -102,7 +105,7 @@ class Follower(O.LiveInferOracle):
                 elif mine == eos:
                     mine = (eos + 1) % V
             if not (forced is not None and i == len(ev[3]) - 1):
-                self._judge("greedy", mine, t, O.top2_margin(logits[-1]), logits[-1])
+                self._judge("greedy", mine, t, logits[-1])
             if i < len(ev[3]) - 1:
                 x = self.llm.embed(torch.tensor([t]))
         if forced is None:
