@@ -329,7 +329,7 @@ def rope_inv_freq(hd: int, theta: float):
 
 def rope_cos_sin(positions: torch.Tensor, hd: int, theta: float, dtype):
     """LlamaRotaryEmbedding.forward :113-127 (fp32 angles, cast to model dtype)."""
-    inv = rope_inv_freq(hd, theta)
+    inv = rope_inv_freq(hd, theta).to(positions.device)
     freqs = (inv[None, :, None] @ positions[None, None, :].float()).transpose(1, 2)[0]
     emb = torch.cat((freqs, freqs), dim=-1)
     return emb.cos().to(dtype), emb.sin().to(dtype)
@@ -421,13 +421,14 @@ class LlamaOracle:
             cache = self.new_cache()
         n, Lc = inputs_embeds.shape[0], len(cache)
         nh, nkv, hd = s.num_heads, s.num_kv_heads, s.head_dim
-        pos = torch.arange(Lc, Lc + n)                                   # :386-389
+        dev = inputs_embeds.device              # CPU everywhere except the long-context fills of tests/test_gpu_long.py (same code, torch on the GPU)
+        pos = torch.arange(Lc, Lc + n, device=dev)                       # :386-389
         cos, sin = rope_cos_sin(pos, hd, s.rope_theta, self.dtype)
         h = inputs_embeds.to(self.dtype)
         # mask (HF:masking_utils.py): none for n==1; is_causal for empty cache; bool mask otherwise
         mask = None
         if n > 1 and Lc > 0:
-            mask = (torch.arange(Lc + n)[None, :] <= (Lc + torch.arange(n))[:, None])
+            mask = (torch.arange(Lc + n, device=dev)[None, :] <= (Lc + torch.arange(n, device=dev))[:, None])
         for i in range(s.num_layers):
             p = f"model.layers.{i}."
             x = rmsnorm(h, W[p + "input_layernorm.weight"], s.rms_eps)

@@ -14,10 +14,12 @@ from parity_util import fmt, ulp_report
 
 pytestmark = pytest.mark.gpu
 
-# Direct engine-vs-reference-path gates (VERDICT r1 weak #2a), set from the first hardware measurement of these quantities
-# (gpurun_out r2; DESIGN.md section 2 records the numbers): fraction of logits whose bf16 bit pattern equals the reference
-# bf16 CPU path's, and the largest difference in bf16 ulps of the largest logit.
-# measured (MI355X, round 2): bit-equal 21-34 %, within one local ulp 51-69 %, worst difference 0.75-2.0 ulps of the largest logit
+# Direct engine-vs-reference-path quantities (VERDICT r1 weak #2a): fraction of logits whose bf16 bit pattern equals the reference
+# bf16 CPU path's, and the largest difference in bf16 ulps of the largest logit.  The bit-equal / within-one-ulp numbers below are
+# REGRESSION FLOORS, not tolerances: they sit just under what the hardware measured (MI355X, round 2: bit-equal 21-34 %, within one
+# local ulp 51-69 %, worst difference 0.75-2.0 ulps of the largest logit; DESIGN.md section 2 explains why two correct bf16 paths
+# with different fp32 summation orders agree on only a third of the bit patterns).  The TOLERANCE is the 3-way band against the fp32
+# gold (engine error <= 1.5 x the reference bf16 path's own error + 1e-3 of the logit scale) and MAX_ULPS_AT_SCALE.
 MIN_BIT_EQUAL = {"toy": 0.18, "toy128": 0.15, "tinyllama-2l": 0.2, "llama-3-8b-2l": 0.2}
 MIN_WITHIN_1ULP = 0.45
 MAX_ULPS_AT_SCALE = 2.5
@@ -453,18 +455,21 @@ def test_attention_at_stream_length_vs_torch_fp32(Lc):
 
 def test_full_depth_8b_shape_aliased_layers():
     """All 32 layers at the true Llama-3-8B shapes (H 4096, I 14336, 32/8 heads of 128, V 128256): rounding noise has to
-    stay bounded through the full depth, not only through the 2-layer slices above.  One random layer's weights are
-    aliased across the 32 layers on both sides (a 15 GB random checkpoint would take minutes to draw on the host); first
-    step of a stream (45 tokens: block path), two frame steps, two decode steps, 3-way against fp32 gold."""
+    stay bounded through the full depth, not only through the 2-layer slices above.  FOUR distinct random layers are cycled
+    through the 32 positions on both sides (layer i carries the weights of layer i % 4: error growth through different
+    weights, where one layer repeated 32 times could resonate or cancel; a 15 GB random checkpoint would take minutes to draw on
+    the host); first step of a stream (45 tokens: block path), two frame steps, two decode steps, 3-way against fp32 gold."""
     from dataclasses import replace
     spec2 = O.LLM_SPECS["llama-3-8b-2l"]
     spec = replace(spec2, num_layers=32)
-    w2 = O.init_llm_weights(spec2, seed=11)
-    w = {k: v for k, v in w2.items() if not k.startswith("model.layers.")}
+    distinct = 4
+    w4 = O.init_llm_weights(replace(spec2, num_layers=distinct), seed=11)
+    w = {k: v for k, v in w4.items() if not k.startswith("model.layers.")}
     for i in range(spec.num_layers):
-        for k, v in w2.items():
-            if k.startswith("model.layers.0."):
-                w[k.replace("model.layers.0.", f"model.layers.{i}.")] = v
+        src = f"model.layers.{i % distinct}."
+        for k, v in w4.items():
+            if k.startswith(src):
+                w[k.replace(src, f"model.layers.{i}.")] = v
     ref, gold = O.LlamaOracle(spec, w, torch.bfloat16), O.LlamaOracle(spec, w, torch.float32)
     eng = _engine(spec, w)
     sess = eng.new_session()

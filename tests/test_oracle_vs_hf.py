@@ -26,9 +26,15 @@ def _hf_llama(spec, w, dtype):
     return m
 
 
+# one decoder layer at the Llama-3-8B width and head geometry (H 4096, I 14336, 32 query heads on 8 kv heads of 128, theta 5e5) with a
+# reduced vocabulary: the width the oracle is used at as the checker of the GPU suite, not only the toy one
+WIDE_1L = O.LlmSpec(4096, 14336, 1, 32, 8, 4096, 500000.0, 1e-5)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_llama_step_sequence_matches_hf(dtype):
-    spec = O.LLM_SPECS["toy128"]
+@pytest.mark.parametrize("which", ["toy128", "llama-3-8b-width-1l"])
+def test_llama_step_sequence_matches_hf(dtype, which):
+    spec = O.LLM_SPECS["toy128"] if which == "toy128" else WIDE_1L
     w = O.init_llm_weights(spec, seed=3)
     hf = _hf_llama(spec, w, dtype)
     me = O.LlamaOracle(spec, w, dtype)
@@ -43,7 +49,7 @@ def test_llama_step_sequence_matches_hf(dtype):
         if dtype == torch.bfloat16:
             assert torch.equal(o.logits[0], lg)          # same ops, same order, same rounding points
         else:
-            assert (o.logits[0] - lg).abs().max().item() < 2e-4
+            assert (o.logits[0] - lg).abs().max().item() < 2e-4 * max(1.0, float(lg.abs().max()) / 8)
         assert past.get_seq_length() == len(cache)
 
 
