@@ -12,7 +12,7 @@
 //   EPI_ROPE    q/k/v split, apply_rotary_pos_emb (:138-160), KV append (replaces DynamicLayer.update's
 //               torch.cat of the whole cache, HF:cache_utils.py:127-151)
 //   EPI_SWIGLU  act_fn(gate) * up (:176);  EPI_BF16_GELU_ERF  the connector's python-GELU
-// so a decoder layer is 6 launches (qkv, attention, combine, o, gate_up, down) instead of 9+.
+// so a decoder layer is 7 launches (add_rmsnorm, qkv, attention, combine, o, gate_up, down; engine.hip::run_chunk) instead of ~14.
 //
 // HBM-bound (arithmetic intensity ~ n FLOP per weight byte): every weight byte is streamed exactly
 // once with 1-KiB-per-wave coalesced global_load_dwordx4; the tiny activation operand lives in VGPRs.
