@@ -88,7 +88,7 @@ def make_schedule(mode):
     return None
 
 
-def cpu_baseline(model_name, frames_u8_cpu, toks, mode, sample_frames, budget_s=25.0):
+def cpu_baseline(model_name, frames_u8_cpu, toks, mode, sample_frames, budget_s=25.0, windows=()):
     """The CPU oracle (a port of the reference's CPU/sdpa path: bf16 Llama, fp32 SigLIP) on the first
     ``sample_frames`` frames of the same stream.  Timing-equivalent weights: one random layer aliased
     across all layers (values do not affect CPU time, and 15 GB of distinct random numbers would take
@@ -132,6 +132,25 @@ def cpu_baseline(model_name, frames_u8_cpu, toks, mode, sample_frames, budget_s=
     otoks = O.StreamTokens(toks.start_ids, toks.stream_prompt_ids, toks.stream_generation_ids, toks.eos_token_id,
                            toks.interval_id, dict(toks.query_ids))
     sched = make_schedule(mode)                 # the GPU line's schedule: 16-token responses
+    win = []
+    for Lc in windows:
+        # 10-frame windows deep in the stream, the KV cache pre-filled with random keys / values (their values
+        # do not affect CPU time); the window's last frame is answered as the schedule says.  Reported as windows, never extrapolated.
+        lw = O.LiveInferOracle(llm, vw, vspec, otoks, frame_fps=2, schedule=sched, max_new=16)
+        lw.load_video(frames_u8_cpu[:10])
+        cache = llm.new_cache()
+        for i in range(spec.num_layers):
+            cache.k[i] = torch.randn(spec.num_kv_heads, Lc, hd, generator=g).to(bf)
+            cache.v[i] = torch.randn(spec.num_kv_heads, Lc, hd, generator=g).to(bf)
+        lw.past_key_values, lw.last_ids = cache, [toks.interval_id]
+        t0 = time.time()
+        for i in range(10):
+            lw.input_video_stream(i / 2)
+            lw()
+        dt = time.time() - t0
+        win.append({"kv_tokens_at_start": Lc, "kv_tokens_at_end": len(lw.past_key_values), "frames": 10, "frames_per_s": round(10 / dt, 4)})
+        log(f"cpu_baseline window at Lc={Lc}: {10 / dt:.3f} frames/s")
+        del lw, cache
     li = O.LiveInferOracle(llm, vw, vspec, otoks, frame_fps=2, schedule=sched, max_new=16)
     li.load_video(frames_u8_cpu)
     li.input_query_stream("Please narrate the video in real time.", video_time=0.0)
@@ -147,6 +166,10 @@ def cpu_baseline(model_name, frames_u8_cpu, toks, mode, sample_frames, budget_s=
     dt = time.time() - t0
     sample_frames = done
     return {"value": round(sample_frames / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            **({"windows": win, "windows_note": "10-frame windows of the same stream with the KV cache pre-filled (random) to the given length; "
+                                                "each window's last frame is answered with a 16-token response"} if win else {}),
+            "port_vs_reference": "profiles/r3_port_vs_reference_cpu.txt: the port runs at 0.85-1.07x the time of the reference's own classes "
+                                 "(LiveLlamaForCausalLM, _siglip_vision_encode) on identical inputs in the build container",
             "sample": f"first {sample_frames} frames of the same stream with the same schedule (t=0 query and every 10th frame answered with a "
                       f"16-token response), i.e. at cache lengths Lc <= {len(li.past_key_values)} — NOT at the ~13-15.7 k-token context the GPU "
                       f"line is timed at (the CPU path only gets slower there: HF re-concatenates the whole KV every step); "
@@ -264,6 +287,9 @@ def main():
                          "tiles, one round of the 256 CUs, the wider ones 756 / 1008)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=20)
+    ap.add_argument("--cpu-windows", default="", help="comma-separated cache lengths (e.g. 1024,4096,13312): the CPU baseline additionally times "
+                                                      "10-frame windows with the KV cache pre-filled to these lengths (BASELINE.md section 4); "
+                                                      "~15-40 s of CPU time each at the 8B size, off by default")
     ap.add_argument("--prof-stride", type=int, default=8)
     ap.add_argument("--tp", action="store_true",
                     help="N > 1: ONE stream, Llama tensor-parallel over the N GPUs (RCCL all-reduce), strong scaling; "
@@ -318,7 +344,7 @@ def main():
 
     K, Wm = args.steps, args.warmup
     shape = LLM_SHAPES[args.model]
-    total = args.stream_frames or int(round((600 if args.model == "llama-3-8b" else 30) * args.fps))
+    total = args.stream_frames or int(round((30 if args.model == "tinyllama-1.1b" else 600) * args.fps))
     total = max(total, K)
     preroll = total - K                       # frames streamed un-timed before the K timed ones (0 when --steps covers the stream)
     n_frames = max(total, Wm) + 2
@@ -538,8 +564,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             log("cpu_baseline: building CPU oracle")
             try:
-                out["cpu_baseline"] = cpu_baseline(args.model, frames[:args.cpu_sample_frames].cpu(), toks, args.mode,
-                                                   args.cpu_sample_frames)
+                out["cpu_baseline"] = cpu_baseline(args.model, frames[:max(args.cpu_sample_frames, 10)].cpu(), toks, args.mode,
+                                                   args.cpu_sample_frames, windows=[int(v) for v in args.cpu_windows.split(",") if v])
             except Exception as ex:     # never lose the GPU line to a host-side problem
                 out["cpu_baseline"] = {"value": None, "error": repr(ex)}
         print(json.dumps(out), flush=True)

@@ -6,6 +6,9 @@ import torch
 LLM_SHAPES = {
     "llama-3-8b": dict(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32,
                        num_key_value_heads=8, vocab_size=128256, rope_theta=500000.0, rms_norm_eps=1e-5),
+    # BASELINE.json configs[4]'s language model (fp8 weights: 69.5 GB, one MI355X holds it at TP = 1)
+    "llama-3-70b": dict(hidden_size=8192, intermediate_size=28672, num_hidden_layers=80, num_attention_heads=64,
+                        num_key_value_heads=8, vocab_size=128256, rope_theta=500000.0, rms_norm_eps=1e-5),
     "tinyllama-1.1b": dict(hidden_size=2048, intermediate_size=5632, num_hidden_layers=22, num_attention_heads=32,
                            num_key_value_heads=4, vocab_size=32000, rope_theta=10000.0, rms_norm_eps=1e-5),
 }
