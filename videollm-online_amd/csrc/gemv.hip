@@ -214,14 +214,12 @@ int gemv_grid_x(const GemvArgs &a, const GemvPlan &p, int epi) {
 template <int KF, int NW>
 static hipError_t launch_variant(const GemvArgs &a, int xsrc, int epi, dim3 grid, size_t lds, hipStream_t st) {
     dim3 block(NW * 64);
-    static const bool fp8_pipe = env_int("VLO_FP8_PIPE", 0) != 0;       // fp8 image: expansion software-pipelined one register ahead (WQ = 2)
 #define VLO_GO(XS, EP)                                                                            \
     do {                                                                                          \
         if (a.wq) {                                                                               \
-            if constexpr ((KF & 1) == 0 && NW == 8) {                                             \
-                if (fp8_pipe) hipLaunchKernelGGL((gemv16_kernel<KF, NW, XS, EP, 2>), grid, block, lds, st, a);  \
-                else hipLaunchKernelGGL((gemv16_kernel<KF, NW, XS, EP, 1>), grid, block, lds, st, a);  \
-            } else                                                                                \
+            if constexpr ((KF & 1) == 0 && NW == 8)                                               \
+                hipLaunchKernelGGL((gemv16_kernel<KF, NW, XS, EP, 1>), grid, block, lds, st, a);  \
+            else                                                                                  \
                 return hipErrorInvalidValue;      /* fp8 image: two fragments per 16-byte load */ \
         } else {                                                                                  \
             hipLaunchKernelGGL((gemv16_kernel<KF, NW, XS, EP, 0>), grid, block, lds, st, a);      \
