@@ -42,6 +42,7 @@ static void launch_pp(const Variant &v, const GemmArgs &a, hipStream_t st) {
     else if (v.prio == 2) hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP, 1, 1>), dim3(nt), dim3(512), 0, st, a);
     else if (v.prio == 3) hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP, 1, 2>), dim3(nt), dim3(512), 0, st, a);
     else if (v.prio == 4) hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP, 1, 3>), dim3(nt), dim3(512), 0, st, a);
+    else if (v.prio == 5) hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP, 1, 4>), dim3(nt), dim3(512), 0, st, a);
     else if (v.prio) hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP, 1>), dim3(nt), dim3(512), 0, st, a);
     else hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP, 0>), dim3(nt), dim3(512), 0, st, a);
 }
@@ -66,6 +67,7 @@ static void launch(const Variant &v, GemmArgs a, hipStream_t st) {
 static void launch_ep(int ep, const Variant &v, const GemmArgs &a, hipStream_t st) {
     if (ep == EP_QKV) launch<EP_QKV>(v, a, st);
     else if (ep == EP_RESID) launch<EP_RESID>(v, a, st);
+    else if (ep == EP_F16) launch<EP_F16>(v, a, st);
     else launch<EP_F16_GELU>(v, a, st);
 }
 
@@ -106,10 +108,11 @@ int main(int argc, char **argv) {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
 
-    struct G { const char *name; int ep, N, K; } gemms[4] = {{"qkv", EP_QKV, 3 * D, D}, {"out", EP_RESID, D, D}, {"fc1", EP_F16_GELU, I, D}, {"fc2", EP_RESID, D, I}};
+    struct G { const char *name; int ep, N, K; } gemms[5] = {{"qkv", EP_QKV, 3 * D, D}, {"out", EP_RESID, D, D}, {"fc1", EP_F16_GELU, I, D}, {"fc2", EP_RESID, D, I},
+                                                             {"fc1-nogelu", EP_F16, I, D}};
     std::vector<Variant> variants = {{"old128", 0, 128, 1, 0}, {"old256", 1, 256, 1, 0}, {"pp256", 2, 256, 0, 1}, {"pp256np", 2, 256, 0, 0},
                                      {"pp128", 2, 128, 0, 1},  {"pp256cb1", 2, 256, 1, 1}, {"pp256cb2", 2, 256, 2, 1}, {"pp256cb4", 2, 256, 4, 1},
-                                     {"pp256cb8", 2, 256, 8, 1}, {"pp256noepi", 2, 256, 0, 2}, {"pp256noload", 2, 256, 0, 3}, {"pp256atomic", 2, 256, 0, 4}};
+                                     {"pp256cb8", 2, 256, 8, 1}, {"pp256noepi", 2, 256, 0, 2}, {"pp256noload", 2, 256, 0, 3}, {"pp256atomic", 2, 256, 0, 4}, {"pp256nostore", 2, 256, 0, 5}};
     for (int B : frames) {
         const int M = B * S;
         for (const G &g : gemms) {
@@ -139,7 +142,7 @@ int main(int argc, char **argv) {
                 CK(hipGetLastError());
                 const char *verdict = "ref";
                 if (v.kind == 0) have_ref = true;
-                else if (v.prio == 2 || v.prio == 3) verdict = "ablation";
+                else if (v.prio == 2 || v.prio == 3 || v.prio == 5) verdict = "ablation";
                 else if (v.prio == 4 && g.ep != EP_RESID) continue;
                 else if (have_ref) {
                     std::vector<char> r0, r1;
