@@ -282,9 +282,10 @@ def main():
                     help="storage of the streamed Llama projections; fp8 = e4m3 + per-channel scales (BASELINE.json configs[4]); the headline "
                          "metric is quoted on bf16")
     ap.add_argument("--no-prefetch", action="store_true")
-    ap.add_argument("--prefetch-frames", type=int, default=28,
-                    help="frames encoded ahead per batched ViT call (28 frames = 16128 token rows = 63 row tiles of 256: the 1024-wide GEMMs are 252 "
-                         "tiles, one round of the 256 CUs, the wider ones 756 / 1008)")
+    ap.add_argument("--prefetch-frames", type=int, default=56,
+                    help="frames encoded ahead per batched ViT call while the Llama steps run (the reference batches pending frames the same way, "
+                         "demo/inference.py:105-106).  56 frames = 32256 token rows = 126 row tiles of 256: every GEMM of the tower is a whole "
+                         "number of 256-CU rounds within 2 % (504 / 1512 / 2016 tiles); 28 frames give 252 / 756 / 1008")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=20)
     ap.add_argument("--cpu-windows", default="", help="comma-separated cache lengths (e.g. 1024,4096,13312): the CPU baseline additionally times "

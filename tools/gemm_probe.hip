@@ -150,7 +150,15 @@ int main(int argc, char **argv) {
                         r0.resize(n); r1.resize(n);
                         CK(hipMemcpy(r0.data(), p0, n, hipMemcpyDeviceToHost));
                         CK(hipMemcpy(r1.data(), p1, n, hipMemcpyDeviceToHost));
-                        return memcmp(r0.data(), r1.data(), n) == 0;
+                        if (memcmp(r0.data(), r1.data(), n) == 0) return true;
+                        if (g.ep != EP_RESID) {      // fp16 outputs: how many differ, and by how many fp16 ulps at most
+                            const unsigned short *a16 = (const unsigned short *)r0.data(), *b16 = (const unsigned short *)r1.data();
+                            size_t cnt = 0; int worst = 0;
+                            for (size_t i = 0; i < n / 2; ++i)
+                                if (a16[i] != b16[i]) { ++cnt; const int d = abs((int)(a16[i] & 0x7fff) - (int)(b16[i] & 0x7fff)); if (d > worst) worst = d; }
+                            printf("    (%zu of %zu fp16 outputs differ, by at most %d in the last place)\n", cnt, n / 2, worst);
+                        }
+                        return false;
                     };
                     bool ok = true;
                     if (g.ep == EP_RESID) ok = cmp(out32[0], out32[1], out_bytes32);
