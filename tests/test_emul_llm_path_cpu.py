@@ -412,6 +412,20 @@ def test_vit_gemm_pingpong_kernel_in_emulation(E):
     _vitpp_child(dict(VLO_VIT_PP_MIN_ROWS="1", VLO_VIT_PP_BM="256", VLO_VIT_PP_CB="2", VLO_EMUL_GLDS="late", VLO_VIT_ATTN_HEAD_MIN="1"))
 
 
+def test_vit_small_tile_direct_to_lds_kernels_in_emulation(E, tmp_path):
+    """Few frames: the 64 x 64 / 32 x 64 tiles as direct-to-LDS kernels with 4 or 6 stages (csrc/vit_gemm.inc::gemm_launch,
+    VLO_VIT_SMALL_STAGES) — K = 256 / 512 here is 4 / 8 K tiles, i.e. a prologue SHORTER than the 6-stage pipeline, the steady state and
+    the drain, each with its counted vmcnt — with the emulated loads landing only at the wait that retires them: inside the oracle's
+    band and bit-identical to the register-ring form of the same kernels (same MFMA, same k order)."""
+    base = str(tmp_path / "ring.pt")
+    _vitpp_child(dict(VLO_VIT_PP="0", VLO_VIT_ATTN_HEAD_MIN="0", VLO_VIT_SMALL_STAGES="0"), base)
+    want = torch.load(base)
+    for stages in ("4", "6"):
+        f = str(tmp_path / f"glds_{stages}.pt")
+        _vitpp_child(dict(VLO_VIT_PP="0", VLO_VIT_ATTN_HEAD_MIN="0", VLO_VIT_SMALL_STAGES=stages, VLO_EMUL_GLDS="late"), f)
+        assert torch.equal(torch.load(f), want), stages
+
+
 @pytest.mark.skipif(not FULL, reason="longer emulation cases: VLO_EMUL_FULL=1")
 def test_vit_gemm_pingpong_kernel_bit_identical_to_small_tile_kernels(E, tmp_path):
     """Same MFMA, same k order: the ping-pong kernel's outputs equal the 64 x 64 / 128 x 128 kernels' bit for bit, for both tile
