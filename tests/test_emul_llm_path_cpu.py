@@ -357,7 +357,7 @@ def test_vit_gemm_256_tile_kernel_in_emulation(E):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, VLO_VIT_BIG_TILES="1", VLO_VIT_256_MIN_ROWS="1")
+    env = dict(os.environ, VLO_VIT_BIG_TILES="1", VLO_VIT_256_MIN_ROWS="1", VLO_VIT_SPLIT_MIN="0")
     r = subprocess.run([sys.executable, "-c", VIT256_CHILD % root], env=env, capture_output=True, text=True, timeout=900)
     print(r.stdout[-600:])
     assert r.returncode == 0 and "OK256" in r.stdout, r.stderr[-2000:]
@@ -395,7 +395,7 @@ def _vitpp_child(env_extra, save=None):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, **env_extra)
+    env = dict(os.environ, VLO_VIT_SPLIT_MIN="0", **env_extra)     # one branch: the row counts above are chosen for full + partial tiles
     r = subprocess.run([sys.executable, "-c", VITPP_CHILD % root] + ([save] if save else []), env=env, capture_output=True, text=True, timeout=1800)
     print(r.stdout[-400:])
     assert r.returncode == 0 and "OKPP" in r.stdout, r.stderr[-2000:]
@@ -424,6 +424,14 @@ def test_vit_small_tile_direct_to_lds_kernels_in_emulation(E, tmp_path):
         f = str(tmp_path / f"glds_{stages}.pt")
         _vitpp_child(dict(VLO_VIT_PP="0", VLO_VIT_ATTN_HEAD_MIN="0", VLO_VIT_SMALL_STAGES=stages, VLO_EMUL_GLDS="late"), f)
         assert torch.equal(torch.load(f), want), stages
+    # the two residual GEMMs (out-proj K = 256, fc2 K = 512) as split-K slices (2 and 4) reduced by the LayerNorm that follows them:
+    # another summation order, so inside the oracle's band (checked by the child) and within a few bf16 ulps of the un-split result
+    f = str(tmp_path / "splitk.pt")
+    _vitpp_child(dict(VLO_VIT_PP="0", VLO_VIT_ATTN_HEAD_MIN="0", VLO_EMUL_GLDS="late", VLO_VIT_SPLITK="4", VLO_VIT_SPLITK_MIN_TILES="2",
+                      VLO_VIT_PP_GRID="64"), f)
+    got = torch.load(f)
+    assert not torch.equal(got, want), "split-K did not run"
+    assert (got.float() - want.float()).abs().max().item() <= 4 * 2 ** -8 * want.float().abs().max().item()
 
 
 @pytest.mark.skipif(not FULL, reason="longer emulation cases: VLO_EMUL_FULL=1")

@@ -174,7 +174,7 @@ def test_full_depth_siglip_l_vs_cpu_fp32_reference():
 
 
 def test_two_branch_batched_encode_matches_single_branch():
-    """From 12 frames up (VLO_VIT_SPLIT_MIN) the captured encode runs as two parallel half-batch branches on two streams, each on its own slice of the
+    """From 4 frames up (VLO_VIT_SPLIT_MIN) the captured encode runs as two parallel half-batch branches on two streams, each on its own slice of the
     workspace and its own connector scratch (csrc/vit.hip::vit_visual_embed).  Same frames through the eager single-branch path
     (default stream) must give the same embeddings — the rows are independent, only which GEMM tile variant computes them differs."""
     spec, vspec = O.LLM_SPECS["tinyllama-2l"], O.VIT_SPECS["siglip-l16-384-2l"]
@@ -182,7 +182,7 @@ def test_two_branch_batched_encode_matches_single_branch():
     eng = _engine(spec, vspec, w, vw)
     frames = O.synthetic_frames(13, vspec.image_size, seed=21).cuda()
     side = torch.cuda.Stream()
-    for B in (13, 12, 9):
+    for B in (13, 12, 9, 5, 4):
         eager = eng.visual_embed(frames[:B]).clone()                 # default stream: no graph, one branch
         torch.cuda.synchronize()             # the engine's encode workspace is shared: calls on different streams are ordered by the caller
         for _ in range(2):                                            # capture, then replay

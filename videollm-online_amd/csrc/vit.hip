@@ -30,12 +30,17 @@
 // one WAVE per token row (4 rows per block): the row lives in registers (D / 64 floats per lane, coalesced float4 loads), mean and
 // variance are two wave reductions — no LDS, no block barrier; D <= 2048, D % 4 == 0
 #define LN_MAXC 8
-__global__ __launch_bounds__(256) void vit_layernorm_kernel(const float *__restrict__ x, const float *__restrict__ w,
+// RED: the residual GEMM before this LayerNorm ran split-K (vit_gemm.inc::gemm_launch_slab): the row first becomes
+// x + fp16(slab[0] + ... + slab[ks-1] + bias) — the epilogue the un-split GEMM applies itself (EP_RESID) — and is written back.
+template <bool RED>
+__global__ __launch_bounds__(256) void vit_layernorm_kernel(float *__restrict__ x, const float *__restrict__ w,
                                                             const float *__restrict__ b, f16_t *__restrict__ out16,
-                                                            float *__restrict__ out32, int M, int D, float eps) {
+                                                            float *__restrict__ out32, int M, int D, float eps,
+                                                            const float *__restrict__ slab, int ks, size_t slab_stride,
+                                                            const float *__restrict__ gbias) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const float *xr = x + (size_t)row * D;
+    float *xr = x + (size_t)row * D;
     float4 v[LN_MAXC];
     float s = 0.f;
 #pragma unroll
@@ -44,6 +49,19 @@ __global__ __launch_bounds__(256) void vit_layernorm_kernel(const float *__restr
         v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < D) {
             v[c] = *reinterpret_cast<const float4 *>(xr + i);
+            if (RED) {
+                float4 t = *reinterpret_cast<const float4 *>(slab + (size_t)row * D + i);
+#pragma unroll
+                for (int z = 1; z < 4; ++z) {                 // ks <= 4; unrolled so that the slab loads go out together
+                    if (z < ks) {
+                        const float4 u = *reinterpret_cast<const float4 *>(slab + (size_t)z * slab_stride + (size_t)row * D + i);
+                        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+                    }
+                }
+                const float4 gb = *reinterpret_cast<const float4 *>(gbias + i);
+                v[c].x += rh(t.x + gb.x); v[c].y += rh(t.y + gb.y); v[c].z += rh(t.z + gb.z); v[c].w += rh(t.w + gb.w);
+                *reinterpret_cast<float4 *>(xr + i) = v[c];
+            }
             s += v[c].x + v[c].y + v[c].z + v[c].w;
         }
     }
@@ -188,6 +206,8 @@ struct VitState {
     // workspace for up to Bcap frames
     int Bcap = 0;
     float *h = nullptr, *last = nullptr, *cls32 = nullptr, *tmp32 = nullptr;
+    float *slab = nullptr;               // split-K partial sums of the residual GEMMs at few frames: [4][slab_rows][D] fp32
+    int slab_rows = 0;
     f16_t *x16 = nullptr, *qk16 = nullptr, *vT = nullptr, *att16 = nullptr, *mid16 = nullptr, *kv16 = nullptr;
     f16_t *hx16 = nullptr, *hmid16 = nullptr, *hatt16 = nullptr, *ho16 = nullptr;
     bf16_t *tokens = nullptr;
@@ -328,6 +348,8 @@ static int vit_reserve(vlo_engine *e, VitState *v, int B) {
     };
     A((void **)&v->h, M * D * 4);
     A((void **)&v->last, M * D * 4);
+    v->slab_rows = (int)std::min<size_t>(M, 2048);               // split-K only ever runs on fewer rows than that (vit_resid_ksplit)
+    A((void **)&v->slab, (size_t)4 * v->slab_rows * D * 4);
     // GEMM operands carry 256 extra rows: the ping-pong GEMM (vit_gemm.inc) reads whole 256-row tiles, the rows past M are computed
     // and dropped
     const size_t Mp = M + 256;
@@ -369,6 +391,33 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
           *const w_ho16 = v->ho16 + (size_t)b0 * D, *const w_hx16 = v->hx16 + (size_t)b0 * D, *const w_hmid16 = v->hmid16 + (size_t)b0 * I;
     bf16_t *const w_tokens = v->tokens + (size_t)b0 * (1 + v->ph * v->pw) * D;
     const float scale = 1.0f / sqrtf((float)v->hd);
+    // few frames: out-proj / fc2 as split-K slices into v->slab, reduced (+ bias + residual) by the LayerNorm that follows either of them
+    float *const w_slab = v->slab + r0 * D;
+    const size_t slab_stride = (size_t)v->slab_rows * D;
+    const bool slab_ok = r0 + (size_t)M <= (size_t)v->slab_rows;
+    const int ks_out = slab_ok ? vit_resid_ksplit(M, D, D) : 1, ks_fc2 = slab_ok ? vit_resid_ksplit(M, D, I) : 1;
+    int pend_ks = 0;                          // K slices waiting in the slab for the next LayerNorm (0 = none)
+    const float *pend_bias = nullptr;
+    auto layernorm = [&](const float *g, const float *b, f16_t *o16, float *o32) {
+        if (pend_ks > 0)
+            hipLaunchKernelGGL((vit_layernorm_kernel<true>), dim3((M + 3) / 4), dim3(256), 0, st, w_h, g, b, o16, o32, M, D, v->eps,
+                               (const float *)w_slab, pend_ks, slab_stride, pend_bias);
+        else
+            hipLaunchKernelGGL((vit_layernorm_kernel<false>), dim3((M + 3) / 4), dim3(256), 0, st, w_h, g, b, o16, o32, M, D, v->eps,
+                               (const float *)nullptr, 0, (size_t)0, (const float *)nullptr);
+        pend_ks = 0;
+    };
+    auto resid_gemm = [&](const f16_t *X, const f16_t *W, const float *bias, int K, int ks) -> hipError_t {
+        GemmArgs a{};
+        a.xpad = 1; a.X = X; a.W = W; a.bias = bias; a.M = M; a.N = D; a.K = K; a.ldx = K;
+        if (ks > 1) {
+            a.out32 = w_slab; a.ldo = v->slab_rows;
+            pend_ks = ks; pend_bias = bias;
+            return gemm_launch_slab(a, ks, st);
+        }
+        a.out32 = w_h;
+        return gemm_launch<EP_RESID>(a, st);
+    };
     {   // patch embed + pos  -> residual stream h (fp32)
         GemmArgs a{};
         a.frames = frames_dev; a.W = v->wpe; a.bias = v->bpe; a.out32 = w_h; a.pos = v->pos;
@@ -377,7 +426,7 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
     }
     for (int l = 0; l < v->L; ++l) {
         const VitLayer &Ly = v->layers[l];
-        hipLaunchKernelGGL(vit_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, w_h, Ly.ln1_w, Ly.ln1_b, w_x16, (float *)nullptr, M, D, v->eps);
+        layernorm(Ly.ln1_w, Ly.ln1_b, w_x16, nullptr);
         {
             GemmArgs a{};
             a.xpad = 1; a.X = w_x16; a.W = Ly.wqkv; a.bias = Ly.bqkv; a.out16 = w_qk16; a.outVT = w_vT;
@@ -391,28 +440,18 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
                                scale * 1.4426950408889634f, v->attn_vrs);
         else
             hipLaunchKernelGGL((vit_attn_kernel<64>), dim3((S + 63) / 64, v->nh, B), dim3(256), kAttnLds, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
-        {
-            GemmArgs a{};
-            a.xpad = 1; a.X = w_att16; a.W = Ly.wo; a.bias = Ly.bo; a.out32 = w_h;
-            a.M = M; a.N = D; a.K = D; a.ldx = D;
-            VIT_TRY(gemm_launch<EP_RESID>(a, st));
-        }
-        hipLaunchKernelGGL(vit_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, w_h, Ly.ln2_w, Ly.ln2_b, w_x16, (float *)nullptr, M, D, v->eps);
+        VIT_TRY(resid_gemm(w_att16, Ly.wo, Ly.bo, D, ks_out));
+        layernorm(Ly.ln2_w, Ly.ln2_b, w_x16, nullptr);
         {
             GemmArgs a{};
             a.xpad = 1; a.X = w_x16; a.W = Ly.w1; a.bias = Ly.b1; a.out16 = w_mid16;
             a.M = M; a.N = I; a.K = D; a.ldx = D; a.ldo = I;
             VIT_TRY(gemm_launch<EP_F16_GELU>(a, st));
         }
-        {
-            GemmArgs a{};
-            a.xpad = 1; a.X = w_mid16; a.W = Ly.w2; a.bias = Ly.b2; a.out32 = w_h;
-            a.M = M; a.N = D; a.K = I; a.ldx = I;
-            VIT_TRY(gemm_launch<EP_RESID>(a, st));
-        }
+        VIT_TRY(resid_gemm(w_mid16, Ly.w2, Ly.b2, I, ks_fc2));
     }
     // post layernorm: fp32 (pooling input) + fp16 (head K/V operand)
-    hipLaunchKernelGGL(vit_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, w_h, v->post_w, v->post_b, w_x16, w_last, M, D, v->eps);
+    layernorm(v->post_w, v->post_b, w_x16, w_last);
     {   // MAP head: K,V = last @ Wkv^T + bkv
         GemmArgs a{};
         a.xpad = 1; a.X = w_x16; a.W = v->in_proj_w + (size_t)D * D; a.bias = v->in_proj_b + D; a.out16 = w_kv16;
@@ -427,7 +466,8 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
         VIT_TRY(gemm_launch<EP_F16>(a, st));
     }
     hipLaunchKernelGGL(f16_to_f32_kernel, dim3((B * D + 255) / 256), dim3(256), 0, st, w_ho16, w_tmp32, B * D);
-    hipLaunchKernelGGL(vit_layernorm_kernel, dim3((B + 3) / 4), dim3(256), 0, st, w_tmp32, v->hln_w, v->hln_b, w_hx16, (float *)nullptr, B, D, v->eps);
+    hipLaunchKernelGGL((vit_layernorm_kernel<false>), dim3((B + 3) / 4), dim3(256), 0, st, w_tmp32, v->hln_w, v->hln_b, w_hx16, (float *)nullptr, B, D, v->eps,
+                       (const float *)nullptr, 0, (size_t)0, (const float *)nullptr);
     {
         GemmArgs a{};
         a.X = w_hx16; a.W = v->hfc1_w; a.bias = v->hfc1_b; a.out16 = w_hmid16;
@@ -450,14 +490,15 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
     return connector_run(e, conn_slot, w_tokens, B * (1 + v->ph * v->pw), out_dev, st);
 }
 
-// B frames as ONE branch, or — from VLO_VIT_SPLIT_MIN frames up (default 12) — as TWO parallel half-batch branches: first half on the
+// B frames as ONE branch, or — from VLO_VIT_SPLIT_MIN frames up (default 4) — as TWO parallel half-batch branches: first half on the
 // caller's stream, second half on an internal one, each on its own slice of the workspace and its own connector scratch, forked and
 // joined with events (inside a stream capture they become parallel branches of the graph).  One half's tails, ramps and
-// under-filled kernels overlap the other's: measured 588 vs 572 TFLOP/s at 14 frames, 599 vs 520 at 16, 625 vs 578 at 32 (448 vs
-// 465 at 8: halves of 4 frames fall back to the 64x64 tiles); results are bit-identical.
+// under-filled kernels overlap the other's.  Measured per call, one branch -> two: 4 frames 3.91 -> 3.57 ms, 6: 5.12 -> 4.45, 8: 5.90 ->
+// 5.45, 12: 6.96 -> 6.56, 16: 9.41 -> 8.0, 28: 13.1 -> 12.4 (profiles/r3_vit_small_and_mid_batches.txt).  Every row is computed from its own frame only and all GEMM tiles
+// accumulate K in the same order, so the split changes results only where a half-batch selects the other attention kernel (1 fp16 ulp).
 static int vit_run_branches(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_dev, hipStream_t st, bool with_connector) {
     VitState *v = e->vit;
-    static const int split_min = getenv("VLO_VIT_SPLIT_MIN") ? atoi(getenv("VLO_VIT_SPLIT_MIN")) : 12;
+    static const int split_min = getenv("VLO_VIT_SPLIT_MIN") ? atoi(getenv("VLO_VIT_SPLIT_MIN")) : 4;
     if (split_min <= 0 || B < split_min || st == nullptr) return vit_run(e, frames_dev, B, out_dev, st, with_connector);
     if (!v->st2) {
         VIT_TRY(hipStreamCreateWithFlags(&v->st2, hipStreamNonBlocking));
