@@ -59,9 +59,10 @@ def gemv_plan(K, allow_ksplit):
 
 
 class EmulEngine:
-    def __init__(self, spec, kv_pool_tokens=1024, tp_rank=0, tp_size=1, vit=None):
+    def __init__(self, spec, kv_pool_tokens=1024, tp_rank=0, tp_size=1, vit=None, weight_dtype=0):
         self.spec, self.vit = spec, vit
         c = _C.VloConfig()
+        c.weight_dtype = weight_dtype                    # 1: fp8 e4m3 image of the streamed projections (+ "<name>_scale")
         if vit is not None:
             c.has_vit = 1
             c.vit_hidden_size, c.vit_intermediate_size = vit.hidden_size, vit.intermediate_size
@@ -85,8 +86,11 @@ class EmulEngine:
             if name.startswith("vision.") and self.vit is None:
                 continue
             t = t.detach().contiguous()
+            dt = _C.DT_FP8_E4M3 if t.dtype == torch.float8_e4m3fn else _DT[t.dtype]
+            if t.dtype == torch.float8_e4m3fn:
+                t = t.view(torch.uint8)
             shape = (C.c_int64 * t.dim())(*t.shape)
-            check(lib().vlo_engine_load_weight(self._h, name.encode(), _ptr(t), _DT[t.dtype], shape, t.dim()))
+            check(lib().vlo_engine_load_weight(self._h, name.encode(), _ptr(t), dt, shape, t.dim()))
         if inv_freq is not None:
             t = inv_freq.float().contiguous()
             check(lib().vlo_engine_load_weight(self._h, b"rope.inv_freq", _ptr(t), _C.DT_F32, (C.c_int64 * 1)(t.numel()), 1))

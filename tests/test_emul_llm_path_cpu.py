@@ -521,3 +521,38 @@ def test_fp8_weight_image_gemv(E, n, N, K):
     assert (y.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()) * (K / 256) ** 0.5 + 1e-5
     W2 = O.fp8_dequantized_weights({"lm_head.weight": W})["lm_head.weight"]
     assert torch.equal(W2.double(), Wd.float().double())
+
+
+FP8_TINY = O.LlmSpec(512, 1024, 1, 4, 2, 256, 10000.0, 1e-5, vision_hidden_size=128)    # K = 512 / 1024: the smallest shapes the fp8 image takes
+
+
+def test_fp8_engine_block_path_and_chunks(E):
+    """An fp8 engine (weight_dtype = 1) end to end in emulation: a 45-token first step through the 64-token block path
+    (csrc/prefill.hip::gemm64_kernel<KF, EPI, WQ = 1>: one e4m3 -> bf16 expansion per fragment pair feeds four token tiles, scales on
+    the reduced sums), then 11- and 1-row steps through the 16-row GEMV path of the same image, against the reference arithmetic on
+    the dequantised weights (the band of tests/test_gpu_fp8.py); with VLO_BLOCK_PATH=0 semantics covered by the chunk steps."""
+    from videollm_online_amd.checkpoint import quantize_fp8_per_channel
+    spec = FP8_TINY
+    w = O.init_llm_weights(spec, seed=11)
+    eng_w, ora_w, keep = {}, {}, set()
+    for k, v in w.items():
+        if k.endswith(O.FP8_STREAMED):
+            q, sc = quantize_fp8_per_channel(v)
+            eng_w[k], eng_w[k + "_scale"] = q, sc
+            ora_w[k] = q.float() * sc[:, None]
+            keep.add(k)
+        else:
+            eng_w[k] = ora_w[k] = v
+    ref, gold = O.LlamaOracle(spec, ora_w, torch.bfloat16, keep_fp32=keep), O.LlamaOracle(spec, ora_w, torch.float32)
+    toks = O.default_tokens(spec, n_start=35)
+    eng = E.EmulEngine(spec, weight_dtype=1).load_weights(eng_w, O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+    s = eng.new_session()
+    rc = gc = None
+    for i, x in enumerate(_steps(spec, ref, toks, 12, [45, 11, 1])):
+        rl, rc = ref.forward(x, rc)
+        gl, gc = gold.forward(x, gc)
+        last, allr = eng.llm_step(s, x)
+        assert eng.session_len(s) == len(rc) and torch.equal(last, allr[-1])
+        _three_way("fp8 tiny", i, allr, rl, gl)
+    eng.close()
+

@@ -87,7 +87,7 @@ def _steps(spec, ref, toks, seed):
     g = torch.Generator().manual_seed(seed + 100)
     H = spec.hidden_size
     frame = lambda: torch.randn(10, H, generator=g).bfloat16()
-    return [torch.cat([ref.embed(torch.tensor(toks.start_ids)), frame()]),         # 45 tokens: 16-row chunks (no block path for fp8)
+    return [torch.cat([ref.embed(torch.tensor(toks.start_ids)), frame()]),         # 45 tokens: the 64-token block path on the fp8 image
             torch.cat([ref.embed(torch.tensor([toks.interval_id])), frame()]),      # n = 11
             ref.embed(torch.tensor(toks.stream_generation_ids)),                    # n = 4
             ref.embed(torch.tensor([17])),                                         # n = 1
@@ -155,6 +155,65 @@ def test_fp8_70b_width_tp8_logical_ranks():
         _check("fp8 70b-1l tp8", i, allr.cpu(), rl, gl)
     sess.close()
     grp.close()
+
+
+def test_fp8_block_path_teacher_forced_rows():
+    """A 150-token teacher-forced input on an fp8 engine: blocks of 64 + 64 + 22 tokens through gemm64_kernel<KF, EPI, WQ = 1>
+    (csrc/prefill.hip: the fp8 image streamed once per 64 tokens), every row's logits against the reference arithmetic on the
+    dequantised weights — then the stream continues on the 16-row path over the KV those blocks appended."""
+    from videollm_online_amd.engine import Engine
+    spec = O.LLM_SPECS["llama-3-8b-2l"]
+    w = O.init_llm_weights(spec, seed=9)
+    eng_w, ora_w, keep = _quantized(w)
+    ref, gold = _oracles(spec, ora_w, keep)
+    eng = Engine(_cfg(spec))
+    eng.load_weights(eng_w)
+    eng.load_weight("rope.inv_freq", O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+    eng.finalize()
+    sess = eng.new_session()
+    g = torch.Generator().manual_seed(31)
+    ids = torch.randint(0, spec.vocab_size, (150,), generator=g)
+    rc = gc = None
+    for i, x in enumerate([ref.embed(ids), torch.randn(11, spec.hidden_size, generator=g).bfloat16(), ref.embed(torch.tensor([5]))]):
+        rl, rc = ref.forward(x, rc)
+        gl, gc = gold.forward(x, gc)
+        last, allr = eng.llm_step(sess, x.cuda(), want_last=True, want_all=True)
+        torch.cuda.synchronize()
+        assert sess.get_seq_length() == len(rc) and torch.equal(last, allr[-1])
+        _check("fp8 8b-2l block path", i, allr.cpu(), rl, gl)
+    sess.close()
+    eng.close()
+
+
+def test_fp8_70b_width_two_layer_stream_on_one_gpu():
+    """configs[4]'s LLM half as ONE rank holds it at TP = 1 (the bench's `--model llama-3-70b --weight-dtype fp8` line): H 8192, I 28672,
+    64 q / 8 kv heads, two distinct layers, fp8 weights — the streaming step sequence (block-path prompt, frame steps, decode steps)
+    and a greedy response, against the reference arithmetic on the dequantised weights."""
+    import dataclasses
+    from videollm_online_amd.engine import Engine
+    spec = dataclasses.replace(O.LLM_SPECS["llama-3-70b-1l"], num_layers=2)
+    w = O.init_llm_weights(spec, seed=10)
+    toks = O.default_tokens(spec, seed=7, n_start=35)
+    eng_w, ora_w, keep = _quantized(w)
+    ref, gold = _oracles(spec, ora_w, keep)
+    eng = Engine(_cfg(spec))
+    eng.load_weights(eng_w)
+    eng.load_weight("rope.inv_freq", O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+    eng.finalize()
+    sess = eng.new_session()
+    rc = gc = None
+    for i, x in enumerate(_steps(spec, ref, toks, 10)):
+        rl, rc = ref.forward(x, rc)
+        gl, gc = gold.forward(x, gc)
+        last, allr = eng.llm_step(sess, x.cuda(), want_last=True, want_all=True)
+        torch.cuda.synchronize()
+        assert sess.get_seq_length() == len(rc) and torch.equal(last, allr[-1])
+        _check("fp8 70b-2l tp1", i, allr.cpu(), rl, gl)
+    ids = torch.zeros(6, dtype=torch.long, device="cuda")
+    n = eng.greedy_generate(sess, eng.embed(torch.tensor(toks.stream_generation_ids)), toks.eos_token_id, ids, force_len=5)
+    assert n == 5 and ids[4].item() == toks.eos_token_id
+    sess.close()
+    eng.close()
 
 
 def test_fp8_rejected_where_the_image_cannot_be_built():

@@ -15,8 +15,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="llama-3-8b")
     ap.add_argument("--tokens", type=int, default=2048)
+    ap.add_argument("--weight-dtype", default="bf16", choices=["bf16", "fp8"])
     args = ap.parse_args()
-    cfg = EngineConfig(**SHAPES[args.model], kv_pool_tokens=max(16384, 2 * args.tokens))
+    cfg = EngineConfig(**SHAPES[args.model], kv_pool_tokens=max(16384, 2 * args.tokens), weight_dtype=args.weight_dtype)
     eng = Engine(cfg)
     random_llm_weights_to_engine(eng, cfg)
     eng.finalize()
@@ -38,7 +39,7 @@ def main():
             eng.llm_step(sess, x)
         torch.cuda.synchronize()
         dt = time.time() - t0
-        print(f"[{mode}] {args.tokens} tokens, all-row logits+stats={want_all}: {dt*1e3:.1f} ms = {args.tokens/dt:.0f} tok/s "
+        print(f"[{mode}, {args.weight_dtype} weights] {args.tokens} tokens, all-row logits+stats={want_all}: {dt*1e3:.1f} ms = {args.tokens/dt:.0f} tok/s "
               f"({dt*1e3/args.tokens*64:.2f} ms per 64 tokens)")
         sess.close()
 

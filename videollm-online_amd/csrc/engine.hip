@@ -220,8 +220,8 @@ static int make_linear(vlo_engine *e, PackedLinear *pl, int N, int K, bool allow
     if (gemv_plan(K, allow_ksplit, &pl->plan)) return fail(VLO_E_UNSUPPORTED, "no GEMV plan for K=" + std::to_string(K));
     if (fp8 && ((pl->plan.KF & 1) || pl->plan.NW != 8 || (K & 63)))
         return fail(VLO_E_UNSUPPORTED, "fp8 weight image needs an even fragment count per wave (K=" + std::to_string(K) + ")");
-    // fp8 engines run every input through 16-row chunks (the 64-token block path streams the bf16 image only)
-    if (!fp8 && gemm64_plan(K, &pl->plan64)) return fail(VLO_E_UNSUPPORTED, "no block-GEMM plan for K=" + std::to_string(K));
+    if (gemm64_plan(K, &pl->plan64, fp8))
+        return fail(VLO_E_UNSUPPORTED, "no block-GEMM plan for K=" + std::to_string(K));
     const size_t bytes = (size_t)pl->NT * 16 * K * (fp8 ? 1 : 2);
     int rc = dev_alloc(&pl->Wp, bytes);
     if (rc) return rc;
@@ -767,7 +767,7 @@ int vlo_llm_step(vlo_session *s, const void *embeds_dev, int n, void *last_logit
         const int left = n - c0;
         const unsigned short *src = (const unsigned short *)embeds_dev + (size_t)c0 * H;
         unsigned short *all = all_logits_dev ? (unsigned short *)all_logits_dev + (size_t)c0 * V : nullptr;
-        if (block_path && left > 16 && e->cfg.weight_dtype != 1) {
+        if (block_path && left > 16) {
             const int m = std::min(VLO_BLOCK_TOKENS, left);
             if ((rc = run_block(s, src, m, c0 + m == n, all, st))) return rc;
             c0 += m;

@@ -123,22 +123,6 @@ VLO_DEV float gelu_python_bf16(float x) {    // HF GELUActivation(use_gelu_pytho
 VLO_DEV float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 VLO_DEV float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 
-// fp8 e4m3 (OCP, gfx950's native format) -> bf16, exact: every e4m3 value is a bf16 value, so the f32 the converter
-// returns is truncated, not rounded.  One 16-byte register = the 8 + 8 weights of two consecutive MFMA fragments.
-typedef __attribute__((ext_vector_type(2))) float f32x2_cv;
-template <bool HI>
-VLO_DEV unsigned fp8x2_to_bf16x2(unsigned src) {          // bytes 0,1 (HI = false) or 2,3 of src
-    const f32x2_cv v = __builtin_amdgcn_cvt_pk_f32_fp8((int)src, HI);
-    return (__float_as_uint(v[0]) >> 16) | (__float_as_uint(v[1]) & 0xffff0000u);
-}
-VLO_DEV void fp8x16_to_bf16(frag_ab raw, frag_ab &f0, frag_ab &f1) {
-    const uint4 u = __builtin_bit_cast(uint4, raw);
-    f0 = __builtin_bit_cast(frag_ab, make_uint4(fp8x2_to_bf16x2<false>(u.x), fp8x2_to_bf16x2<true>(u.x),
-                                                  fp8x2_to_bf16x2<false>(u.y), fp8x2_to_bf16x2<true>(u.y)));
-    f1 = __builtin_bit_cast(frag_ab, make_uint4(fp8x2_to_bf16x2<false>(u.z), fp8x2_to_bf16x2<true>(u.z),
-                                                  fp8x2_to_bf16x2<false>(u.w), fp8x2_to_bf16x2<true>(u.w)));
-}
-
 template <int KF, int NW, int XSRC, int EPI, int WQ>
 __global__ __launch_bounds__(NW * 64) void gemv16_kernel(GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 red[];      // [2][NW][CTG][64] float4, then scratch

@@ -16,6 +16,9 @@
 // shared by every block) and therefore live in a fragment-packed layout ("packed-64", llm_ops.h) written by their
 // producers — row-major rows cost 16 half-used cache lines per fragment and made the kernel L2-line-bound; no norm-on-load / split-K partial variants (the block path runs the row-parallel
 // add_rmsnorm kernel instead, its cost is amortised over 64 tokens).
+//
+// WQ = 1 streams the fp8 e4m3 image (gemv.hip: one 16-byte register = two consecutive fragments, expanded to bf16 exactly in
+// registers; per-output-channel scales on the reduced fp32 sums): one expansion feeds the four token tiles.
 #include <stdlib.h>
 
 #include "common.cuh"
@@ -24,9 +27,11 @@
 VLO_DEV float silu_bf16_p(float g) { return rbf(g / (1.0f + __expf(-g))); }     // F.silu on a bf16 tensor
 VLO_DEV float4 f4add_p(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-template <int KF, int EPI>
+template <int KF, int EPI, int WQ>
 __global__ __launch_bounds__(512) void gemm64_kernel(GemvArgs a) {
     constexpr int MT = VLO_BLOCK_TOKENS / 16, CTG = 2;
+    constexpr int WRN = WQ ? KF / 2 : KF;                                  // weight registers per tile and K chunk (fp8: two fragments each)
+    static_assert(!WQ || (KF % 2) == 0, "fp8 image: fragments come in pairs");
     extern __shared__ __attribute__((aligned(16))) float4 red[];          // [NW][CTG][MT][64] float4
     const int NW = blockDim.x >> 6;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -42,14 +47,14 @@ __global__ __launch_bounds__(512) void gemm64_kernel(GemvArgs a) {
     auto tile_a = [&](int g) { return (EPI == EPI_ROPE) ? (g / hp) * tph + (g % hp) : (single ? g : 2 * g); };
     auto tile_b = [&](int g) { return (EPI == EPI_ROPE) ? (g / hp) * tph + (g % hp) + hp : (single ? a.NT : 2 * g + 1); };
 
-    const frag_ab *wbase = reinterpret_cast<const frag_ab *>(a.Wp) + (size_t)kfw0 * 64 + lane;
-    const size_t tile_stride = (size_t)KFtot * 64;
-    auto item_ptr = [&](int tile, int c) { return wbase + (size_t)tile * tile_stride + (size_t)c * KF * 64; };
+    const frag_ab *wbase = reinterpret_cast<const frag_ab *>(a.Wp) + (size_t)(WQ ? kfw0 / 2 : kfw0) * 64 + lane;
+    const size_t tile_stride = (size_t)(WQ ? KFtot / 2 : KFtot) * 64;
+    auto item_ptr = [&](int tile, int c) { return wbase + (size_t)tile * tile_stride + (size_t)c * WRN * 64; };
 
     // Weight fragments of BOTH tiles of the current K chunk sit in registers (2 x KF KiB per wave in flight) and each is
     // refilled for the next chunk right after the MFMAs that consumed it; the four activation fragments of step kf+1
     // are fetched (L2) while step kf computes.
-    frag_ab wrA[KF], wrB[KF];
+    frag_ab wrA[WRN], wrB[WRN];
     frag_ab xc[MT], xn[MT];
     const frag_ab *xbase = reinterpret_cast<const frag_ab *>(a.x) + (size_t)kfw0 * MT * 64 + lane;   // packed-64 (llm_ops.h)
     auto load_x = [&](int step, frag_ab (&dst)[MT]) {                      // step = c * KF + kf inside this wave's K range
@@ -62,11 +67,11 @@ __global__ __launch_bounds__(512) void gemm64_kernel(GemvArgs a) {
         const frag_ab *pa = item_ptr(tile_a(g), 0);
         const int tb = tile_b(g);
 #pragma unroll
-        for (int kf = 0; kf < KF; ++kf) wrA[kf] = __builtin_nontemporal_load(pa + kf * 64);
+        for (int i = 0; i < WRN; ++i) wrA[i] = __builtin_nontemporal_load(pa + i * 64);
         if (tb < a.NT) {
             const frag_ab *pb = item_ptr(tb, 0);
 #pragma unroll
-            for (int kf = 0; kf < KF; ++kf) wrB[kf] = __builtin_nontemporal_load(pb + kf * 64);
+            for (int i = 0; i < WRN; ++i) wrB[i] = __builtin_nontemporal_load(pb + i * 64);
         }
         load_x(0, xc);
     }
@@ -86,21 +91,30 @@ __global__ __launch_bounds__(512) void gemm64_kernel(GemvArgs a) {
             const frag_ab *na = !last_c ? item_ptr(tA, c + 1) : (gn < ngroups ? item_ptr(tile_a(gn), 0) : nullptr);
             const int tBn = !last_c ? tB : (gn < ngroups ? tile_b(gn) : a.NT);
             const frag_ab *nb = tBn < a.NT ? item_ptr(tBn, last_c ? 0 : c + 1) : nullptr;
+            frag_ab eA[2], eB[2];                                          // fp8: the expanded fragment pair of the current register
 #pragma unroll
             for (int kf = 0; kf < KF; ++kf) {
                 // x of the next step (wraps to step 0 — same K range — when the next group starts)
                 const int nstep = (last_c && kf == KF - 1) ? 0 : c * KF + kf + 1;
                 load_x(nstep, xn);
+                if (WQ && !(kf & 1)) {                                     // expand, then the register is free for its refill
+                    fp8x16_to_bf16(wrA[kf >> 1], eA[0], eA[1]);
+                    if (na) wrA[kf >> 1] = __builtin_nontemporal_load(na + (kf >> 1) * 64);
+                    if (hasB) fp8x16_to_bf16(wrB[kf >> 1], eB[0], eB[1]);
+                    if (nb) wrB[kf >> 1] = __builtin_nontemporal_load(nb + (kf >> 1) * 64);
+                }
+                const frag_ab fa = WQ ? eA[kf & 1] : wrA[kf];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    if (mt < mt_live) acc[0][mt] = mfma_bf16(wrA[kf], xc[mt], acc[0][mt]);
-                if (na) wrA[kf] = __builtin_nontemporal_load(na + kf * 64);
+                    if (mt < mt_live) acc[0][mt] = mfma_bf16(fa, xc[mt], acc[0][mt]);
+                if (!WQ && na) wrA[kf] = __builtin_nontemporal_load(na + kf * 64);
                 if (hasB) {
+                    const frag_ab fb = WQ ? eB[kf & 1] : wrB[kf];
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        if (mt < mt_live) acc[1][mt] = mfma_bf16(wrB[kf], xc[mt], acc[1][mt]);
+                        if (mt < mt_live) acc[1][mt] = mfma_bf16(fb, xc[mt], acc[1][mt]);
                 }
-                if (nb) wrB[kf] = __builtin_nontemporal_load(nb + kf * 64);
+                if (!WQ && nb) wrB[kf] = __builtin_nontemporal_load(nb + kf * 64);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) xc[mt] = xn[mt];
             }
@@ -115,6 +129,10 @@ __global__ __launch_bounds__(512) void gemm64_kernel(GemvArgs a) {
         auto reduced = [&](int ct, int mt, int l) {
             float4 s = make_float4(0, 0, 0, 0);
             for (int ww = 0; ww < NW; ++ww) s = f4add_p(s, red[((size_t)(ww * CTG + ct) * MT + mt) * 64 + l]);
+            if (WQ) {                                                      // per-output-channel weight scales, packed row order (gemv.h)
+                const float4 sc = *reinterpret_cast<const float4 *>(a.wscale + (ct ? tB : tA) * 16 + (l >> 4) * 4);
+                s = make_float4(s.x * sc.x, s.y * sc.y, s.z * sc.z, s.w * sc.w);
+            }
             return s;
         };
         if (EPI == EPI_ROPE) {
@@ -201,7 +219,7 @@ __global__ __launch_bounds__(512) void gemm64_kernel(GemvArgs a) {
 // ------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------
-int gemm64_plan(int K, Gemm64Plan *p) {
+int gemm64_plan(int K, Gemm64Plan *p, bool even_kf) {
     if (K <= 0 || (K & 31)) return -1;
     const int KFtot = K >> 5;
     // 8-wave blocks, one per CU, each wave keeping 2 x KF KiB of weight loads in flight (KF = 8: 128 KiB per CU, what the
@@ -209,23 +227,23 @@ int gemm64_plan(int K, Gemm64Plan *p) {
     static const int nws[] = {8, 4, 2, 1}, kfs[] = {8, 4, 2, 1};
     for (int nw : nws)
         for (int kf : kfs)
-            if (KFtot % (nw * kf) == 0) {
+            if (KFtot % (nw * kf) == 0 && !(even_kf && (kf & 1))) {      // fp8 image: fragments are stored in pairs
                 p->NW = nw; p->KF = kf; p->KC = KFtot / (nw * kf);
                 return 0;
             }
     return -1;
 }
 
-template <int KF>
+template <int KF, int WQ>
 static hipError_t launch64(const GemvArgs &a, int epi, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
 #define VLO_GO64(EP)                                                                      \
     do {                                                                                  \
         static bool attr = false;                                                         \
         if (!attr) {                                                                      \
-            hipFuncSetAttribute((const void *)gemm64_kernel<KF, EP>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+            hipFuncSetAttribute((const void *)gemm64_kernel<KF, EP, WQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
             attr = true;                                                                  \
         }                                                                                 \
-        hipLaunchKernelGGL((gemm64_kernel<KF, EP>), grid, block, lds, st, a);             \
+        hipLaunchKernelGGL((gemm64_kernel<KF, EP, WQ>), grid, block, lds, st, a);             \
         return hipGetLastError();                                                         \
     } while (0)
     if (epi == EPI_ROPE) VLO_GO64(EPI_ROPE);
@@ -248,11 +266,20 @@ hipError_t gemm64_launch(GemvArgs a, const Gemm64Plan &p, int epi, hipStream_t s
     gx = (ngroups + per - 1) / per;
     const size_t lds = (size_t)p.NW * 2 * (VLO_BLOCK_TOKENS / 16) * 64 * sizeof(float4);
     dim3 grid(gx), block(p.NW * 64);
+    if (a.wq) {                                  // fp8 image: fragment pairs
+        if (!a.wscale || (a.K & 63)) return hipErrorInvalidValue;
+        switch (p.KF) {
+            case 8: return launch64<8, 1>(a, epi, grid, block, lds, st);
+            case 4: return launch64<4, 1>(a, epi, grid, block, lds, st);
+            case 2: return launch64<2, 1>(a, epi, grid, block, lds, st);
+        }
+        return hipErrorInvalidValue;
+    }
     switch (p.KF) {
-        case 8: return launch64<8>(a, epi, grid, block, lds, st);
-        case 4: return launch64<4>(a, epi, grid, block, lds, st);
-        case 2: return launch64<2>(a, epi, grid, block, lds, st);
-        case 1: return launch64<1>(a, epi, grid, block, lds, st);
+        case 8: return launch64<8, 0>(a, epi, grid, block, lds, st);
+        case 4: return launch64<4, 0>(a, epi, grid, block, lds, st);
+        case 2: return launch64<2, 0>(a, epi, grid, block, lds, st);
+        case 1: return launch64<1, 0>(a, epi, grid, block, lds, st);
     }
     return hipErrorInvalidValue;
 }
