@@ -113,6 +113,14 @@ VIT_SPECS = {
     "siglip-l16-384-2l": VitSpec(num_layers=2),
     "toy": VitSpec(hidden_size=128, intermediate_size=512, num_layers=2, num_heads=2,
                    image_size=96, patch_size=16, pooled=(3, 3)),
+    # BASELINE.json configs[4]'s tower (SURVEY.md §8 dimension table; HF google/siglip-so400m-patch14-384): head dim 72, MLP 4304,
+    # 27 x 27 patches of 14 pixels (the 384-pixel image is cropped to 378 by the strided conv).  The reference's build_live_vision
+    # accepts SigLIP-L only; the oracle's tower code is shape-generic and pinned to HF's SiglipVisionModel by tests/test_oracle_vs_hf.py
+    "siglip-so400m14-384": VitSpec(hidden_size=1152, intermediate_size=4304, num_layers=27, num_heads=16, image_size=384, patch_size=14),
+    "siglip-so400m14-384-2l": VitSpec(hidden_size=1152, intermediate_size=4304, num_layers=2, num_heads=16, image_size=384, patch_size=14),
+    # the same irregularities at toy size: head dim 72 (16 heads: the connector's GEMV has no plan for K = 576), MLP width 336 (not a
+    # multiple of 64), 3 x 3 patches of 14 pixels (K = 588)
+    "toy-hd72": VitSpec(hidden_size=1152, intermediate_size=336, num_layers=1, num_heads=16, image_size=42, patch_size=14, pooled=(3, 3)),
 }
 
 

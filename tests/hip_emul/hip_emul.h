@@ -414,6 +414,10 @@ static inline hipError_t hipMemcpy2DAsync(void *d, size_t dpitch, const void *s,
     else op();
     return hipSuccess;
 }
+static inline hipError_t hipMemcpy2D(void *d, size_t dpitch, const void *s, size_t spitch, size_t width, size_t height, hipMemcpyKind) {
+    for (size_t r = 0; r < height; ++r) memmove((char *)d + r * dpitch, (const char *)s + r * spitch, width);
+    return hipSuccess;
+}
 typedef enum { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamCaptureModeRelaxed = 2 } hipStreamCaptureMode;
 static inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) {
     if (emul_capturing) return hipErrorInvalidValue;

@@ -556,3 +556,30 @@ def test_fp8_engine_block_path_and_chunks(E):
         _three_way("fp8 tiny", i, allr, rl, gl)
     eng.close()
 
+
+def test_vision_tower_with_padded_head_dim_mlp_width_and_patch_k(E):
+    """The shapes of SigLIP-so400m/14 (BASELINE.json configs[4]) at toy size — head dim 72 (stored as 96 columns per head in q | k and 80
+    rows per head in V^T, vit_attn_kernel<96, 80>), MLP width 336 (zero-padded to 512 at load), 14-pixel patches (K = 588 padded to
+    640, element-wise im2col), 9 tokens per frame (not a multiple of 4) — against the oracle with the tolerance of the ViT tests."""
+    vspec = O.VIT_SPECS["toy-hd72"]
+    spec = O.LlmSpec(128, 192, 1, 2, 2, 256, 10000.0, 1e-5, vision_hidden_size=vspec.hidden_size)
+    w, vw = O.init_llm_weights(spec, seed=3), O.init_vit_weights(vspec, seed=2)
+    frames = O.synthetic_frames(2, vspec.image_size, seed=5)
+    gold = O.LlamaOracle(spec, w, torch.float32).visual_embed(vw, vspec, frames)
+    ref = O.LlamaOracle(spec, w, torch.bfloat16)
+    amp = ref.visual_embed(vw, vspec, frames, mm_dtype=torch.float16)
+    cpu = ref.visual_embed(vw, vspec, frames)
+    eng = E.EmulEngine(spec, vit=vspec).load_weights({**w, **vw}, O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+    out = eng.visual_embed(frames)
+    scale = gold.abs().max().item()
+    e = (out.float() - gold).abs().max().item()
+    a = (amp.float() - gold).abs().max().item()
+    r = (cpu.float() - gold).abs().max().item()
+    print(f"[emul vit hd72] engine err {e:.4g} fp16-autocast err {a:.4g} cpu-ref err {r:.4g} scale {scale:.3g}")
+    assert e <= 2.0 * max(a, r) + 2 * 2 ** -8 * scale, (e, a, r)
+    tok = eng.vision_tokens(frames)
+    want = O.siglip_vision_encode(vw, vspec, frames)
+    assert (tok.float() - want.float()).abs().max().item() <= 2.0 * (O.siglip_vision_encode(vw, vspec, frames, mm_dtype=torch.float16).float()
+                                                                    - want.float()).abs().max().item() + 2 * 2 ** -8 * want.abs().max().item()
+    eng.close()
+

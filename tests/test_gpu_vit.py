@@ -32,9 +32,15 @@ def _engine(spec, vspec, w, vw):
 
 
 @pytest.mark.parametrize("llm,vit,B", [("toy128", "toy", 3), ("toy128", "toy", 1), ("tinyllama-2l", "siglip-l16-384-2l", 2),
-                                       ("tinyllama-2l", "siglip-l16-384-2l", 4)])     # B=4 takes the 128x128-tile GEMM path
+                                       ("tinyllama-2l", "siglip-l16-384-2l", 4),      # B=4 takes the 128x128-tile GEMM path
+                                       # BASELINE.json configs[4]'s tower: head dim 72, MLP 4304, 729 patches of 14 pixels — padded
+                                       # heads / MLP width / patch K (csrc/vit.hip::vit_finalize); 1 frame: 64x64 tiles; 9 frames:
+                                       # two branches on 128x128 tiles
+                                       ("tinyllama-2l", "siglip-so400m14-384-2l", 1), ("tinyllama-2l", "siglip-so400m14-384-2l", 9)])
 def test_visual_embed_parity(llm, vit, B):
+    import dataclasses
     spec, vspec = O.LLM_SPECS[llm], O.VIT_SPECS[vit]
+    spec = dataclasses.replace(spec, vision_hidden_size=vspec.hidden_size)
     w = O.init_llm_weights(spec, seed=3)
     vw = O.init_vit_weights(vspec, seed=1)
     frames = O.synthetic_frames(B, vspec.image_size, seed=1234)

@@ -181,7 +181,8 @@ __global__ void f16_to_f32_kernel(const f16_t *__restrict__ a, float *__restrict
 // ------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------
-static const size_t kAttnLds = (size_t)4 * 4 * 4 * 64 * 16 + 4 * 4 * 16 * 2 * 4;     // O partials + (m, l)
+static size_t attn_lds(int hdv) { return (size_t)4 * 4 * (hdv / 16) * 64 * 16 + 4 * 4 * 16 * 2 * 4; }     // O partials + (m, l) of vit_attn_kernel
+static const size_t kAttnLds = attn_lds(64);
 
 struct VitLayer {
     const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
@@ -192,7 +193,9 @@ struct VitLayer {
 };
 
 struct VitState {
-    int D, I, L, nh, hd, R, P, G, S, Sp, ph, pw;             // Sp: S rounded up to 32 (row length of V^T)
+    int D, I, L, nh, hd, R, P, G, S, Sp, ph, pw;             // Sp: S rounded up to 32 (row length of V^T); I: the MLP width the kernels see (padded)
+    int hdk = 64, hdv = 64;                                  // columns per head in the q | k buffer (hd up to 32) / rows per head in V^T (hd up to 16)
+    int Kpe = 0, Kpe_real = 0;                               // patch-embed K: 3 P P, and rounded up to 64 (zero columns in the padded weight)
     float eps;
     const f16_t *wpe;
     const float *bpe, *pos;
@@ -247,13 +250,49 @@ int vit_finalize(vlo_engine *e) {
     v->D = c.vit_hidden_size; v->I = c.vit_intermediate_size; v->L = c.vit_num_layers; v->nh = c.vit_num_heads;
     v->hd = v->D / v->nh; v->R = c.vit_image_size; v->P = c.vit_patch_size; v->G = v->R / v->P; v->S = v->G * v->G; v->Sp = (v->S + 31) & ~31;
     v->ph = c.pool_h; v->pw = c.pool_w; v->eps = c.vit_ln_eps;
-    const int D = v->D, I = v->I;
-    if (v->hd != 64 || (D % 64) || D > 2048 || (I % 64) || ((3 * v->P * v->P) % 64) || (v->P % 8) || c.vision_hidden_size != D ||
-        c.frame_num_tokens != 1 + v->ph * v->pw || (v->S % 4))
-        { delete v; return vlo_fail(VLO_E_UNSUPPORTED, "vision tower shape not covered by the kernels (need head_dim 64, dims % 64 == 0)"); }
+    // Shapes the kernels take as they are: head dim 64, MLP width % 256 == 0, 3 P P % 64 == 0 (SigLIP-L/16: 64 / 4096 / 768).  Others are PADDED
+    // with zeros where the padding is arithmetically inert (SigLIP-so400m/14: head dim 72, MLP 4304, 3 P P = 588):
+    //   * MLP width I -> Ip = I up to 256: fc1 gets zero rows + zero bias (GELU(0) = 0), fc2 zero columns;
+    //   * patch-embed K = 3 P P -> up to 64: zero weight columns, zero A-tile elements;
+    //   * head dim hd -> hdk = hd up to 32 columns per head in the q | k buffer (zeros add 0 to q.k) and hdv = hd up to 16 rows per head in V^T
+    //     (zero rows: outputs never stored).  The hidden size itself (LayerNorm width, residual stream) is never padded.
+    const int D = v->D, I = c.vit_intermediate_size, Ip = (I + 255) / 256 * 256;
+    v->I = Ip;
+    v->Kpe_real = 3 * v->P * v->P; v->Kpe = (v->Kpe_real + 63) / 64 * 64;
+    v->hdk = (v->hd + 31) / 32 * 32; v->hdv = (v->hd + 15) / 16 * 16;
+    const bool heads_ok = (v->hdk == 64 && v->hdv == 64) || (v->hdk == 96 && v->hdv == 80);
+    if (v->nh <= 0 || v->hd * v->nh != D || (v->hd & 3) || !heads_ok || (D % 64) || D > 2048 || (I & 3) || c.vision_hidden_size != D ||
+        c.frame_num_tokens != 1 + v->ph * v->pw || v->G <= 0)          // G = R / P rounded down: a strided 'valid' conv ignores the remainder (384 / 14)
+        { delete v; return vlo_fail(VLO_E_UNSUPPORTED, "vision tower shape not covered by the kernels (head dim 64 or 68..80 in steps of 4, hidden % 64 == 0 and <= 2048)"); }
     int rc;
+    // [rows][cols] fp16 (or a float vector) -> zero-padded [rows_p][cols_p] copy owned by the engine
+    auto padded16 = [&](const f16_t *&w, int rows, int cols, int rows_p, int cols_p) -> int {
+        if (rows == rows_p && cols == cols_p) return VLO_OK;
+        f16_t *d;
+        int r2 = dev_alloc((void **)&d, (size_t)rows_p * cols_p * 2);
+        if (r2) return r2;
+        e->owned.push_back(d);
+        if (hipMemset(d, 0, (size_t)rows_p * cols_p * 2) != hipSuccess ||
+            hipMemcpy2D(d, (size_t)cols_p * 2, w, (size_t)cols * 2, (size_t)cols * 2, rows, hipMemcpyDeviceToDevice) != hipSuccess)
+            return vlo_fail(VLO_E_HIP, "padding a vision weight failed");
+        w = d;
+        return VLO_OK;
+    };
+    auto padded32 = [&](const float *&b, int n, int n_p) -> int {
+        if (n == n_p) return VLO_OK;
+        float *d;
+        int r2 = dev_alloc((void **)&d, (size_t)n_p * 4);
+        if (r2) return r2;
+        e->owned.push_back(d);
+        if (hipMemset(d, 0, (size_t)n_p * 4) != hipSuccess || hipMemcpy(d, b, (size_t)n * 4, hipMemcpyDeviceToDevice) != hipSuccess)
+            return vlo_fail(VLO_E_HIP, "padding a vision bias failed");
+        b = d;
+        return VLO_OK;
+    };
+#define PAD(call) if ((rc = (call))) { delete v; return rc; }
 #define TK(name, shape, dt, field) if ((rc = vtake(e, name, shape, dt, (const void **)&field))) { delete v; return rc; }
     TK("vision.embeddings.patch_embedding.weight", (std::vector<int64_t>{D, 3, v->P, v->P}), VLO_DT_F16, v->wpe);
+    PAD(padded16(v->wpe, D, v->Kpe_real, D, v->Kpe));
     TK("vision.embeddings.patch_embedding.bias", (std::vector<int64_t>{D}), VLO_DT_F32, v->bpe);
     TK("vision.embeddings.position_embedding.weight", (std::vector<int64_t>{v->S, D}), VLO_DT_F32, v->pos);
     v->layers.resize(v->L);
@@ -284,6 +323,9 @@ int vit_finalize(vlo_engine *e) {
         TK(p + "mlp.fc1.bias", (std::vector<int64_t>{I}), VLO_DT_F32, Ly.b1);
         TK(p + "mlp.fc2.weight", (std::vector<int64_t>{D, I}), VLO_DT_F16, Ly.w2);
         TK(p + "mlp.fc2.bias", (std::vector<int64_t>{D}), VLO_DT_F32, Ly.b2);
+        PAD(padded16(Ly.w1, I, D, Ip, D));
+        PAD(padded32(Ly.b1, I, Ip));
+        PAD(padded16(Ly.w2, D, I, D, Ip));
     }
     TK("vision.post_layernorm.weight", (std::vector<int64_t>{D}), VLO_DT_F32, v->post_w);
     TK("vision.post_layernorm.bias", (std::vector<int64_t>{D}), VLO_DT_F32, v->post_b);
@@ -297,6 +339,9 @@ int vit_finalize(vlo_engine *e) {
     TK("vision.head.mlp.fc1.bias", (std::vector<int64_t>{I}), VLO_DT_F32, v->hfc1_b);
     TK("vision.head.mlp.fc2.weight", (std::vector<int64_t>{D, I}), VLO_DT_F16, v->hfc2_w);
     TK("vision.head.mlp.fc2.bias", (std::vector<int64_t>{D}), VLO_DT_F32, v->hfc2_b);
+    PAD(padded16(v->hfc1_w, I, D, Ip, D));
+    PAD(padded32(v->hfc1_b, I, Ip));
+    PAD(padded16(v->hfc2_w, D, I, D, Ip));
     // probe query is input-independent: q = probe @ Wq^T + bq, once (fp16 like the autocast Linear)
     {
         const float *probe32;
@@ -317,12 +362,14 @@ int vit_finalize(vlo_engine *e) {
         VIT_TRY(hipDeviceSynchronize());
     }
 #undef TK
+#undef PAD
     VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnLds));
+    VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_kernel<96, 80>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds(80)));
     {
         const int cpr = v->Sp / 8;                                   // 16-byte chunks per V^T row
         v->attn_vrs = (cpr + ((10 - cpr % 16) + 16) % 16) * 16;
         const size_t lds = (size_t)v->Sp * 128 + (size_t)64 * v->attn_vrs;
-        if (lds <= 160 * 1024 && v->Sp <= 608) {
+        if (lds <= 160 * 1024 && v->Sp <= 608 && v->hd == 64) {
             v->attn_head_lds = lds;
             VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_head_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
@@ -354,8 +401,9 @@ static int vit_reserve(vlo_engine *e, VitState *v, int B) {
     // and dropped
     const size_t Mp = M + 256;
     A((void **)&v->x16, Mp * D * 2);
-    A((void **)&v->qk16, M * 2 * D * 2);
-    A((void **)&v->vT, (size_t)B * D * v->Sp * 2);          // V^T [B][heads][64][Sp]; the pad columns [S, Sp) are never written: zeroed below
+    const size_t Dk = (size_t)v->nh * v->hdk, Dv = (size_t)v->nh * v->hdv;     // padded head layouts (== D for head dim 64)
+    A((void **)&v->qk16, M * 2 * Dk * 2);                   // q | k, [M][2][heads][hdk]; pad columns never written: zeroed below
+    A((void **)&v->vT, (size_t)B * Dv * v->Sp * 2);         // V^T [B][heads][hdv][Sp]; the pad columns [S, Sp) and pad rows are never written: zeroed below
     A((void **)&v->att16, Mp * D * 2);
     A((void **)&v->mid16, Mp * I * 2);
     A((void **)&v->kv16, M * 2 * D * 2);
@@ -369,7 +417,8 @@ static int vit_reserve(vlo_engine *e, VitState *v, int B) {
     A((void **)&v->frames_in, (size_t)B * 3 * v->R * v->R);
     A((void **)&v->out_stage, (size_t)B * (1 + v->ph * v->pw) * e->cfg.hidden_size * 2);
     if (rc) return rc;
-    if (hipMemset(v->vT, 0, (size_t)B * D * v->Sp * 2) != hipSuccess) return vlo_fail(VLO_E_HIP, "vit workspace memset failed");
+    if (hipMemset(v->vT, 0, (size_t)B * Dv * v->Sp * 2) != hipSuccess || (Dk != D && hipMemset(v->qk16, 0, M * 2 * Dk * 2) != hipSuccess))
+        return vlo_fail(VLO_E_HIP, "vit workspace memset failed");
     v->Bcap = B;
     (void)e;
     return VLO_OK;
@@ -386,7 +435,7 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
     // ranges can run concurrently as parallel branches of one captured graph
     const size_t r0 = (size_t)b0 * S;
     float *const w_h = v->h + r0 * D, *const w_last = v->last + r0 * D, *const w_tmp32 = v->tmp32 + (size_t)b0 * D;
-    f16_t *const w_x16 = v->x16 + r0 * D, *const w_qk16 = v->qk16 + r0 * 2 * D, *const w_vT = v->vT + (size_t)b0 * D * v->Sp, *const w_att16 = v->att16 + r0 * D,
+    f16_t *const w_x16 = v->x16 + r0 * D, *const w_qk16 = v->qk16 + r0 * 2 * v->nh * v->hdk, *const w_vT = v->vT + (size_t)b0 * v->nh * v->hdv * v->Sp, *const w_att16 = v->att16 + r0 * D,
           *const w_mid16 = v->mid16 + r0 * I, *const w_kv16 = v->kv16 + r0 * 2 * D, *const w_hatt16 = v->hatt16 + (size_t)b0 * D,
           *const w_ho16 = v->ho16 + (size_t)b0 * D, *const w_hx16 = v->hx16 + (size_t)b0 * D, *const w_hmid16 = v->hmid16 + (size_t)b0 * I;
     bf16_t *const w_tokens = v->tokens + (size_t)b0 * (1 + v->ph * v->pw) * D;
@@ -421,7 +470,7 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
     {   // patch embed + pos  -> residual stream h (fp32)
         GemmArgs a{};
         a.frames = frames_dev; a.W = v->wpe; a.bias = v->bpe; a.out32 = w_h; a.pos = v->pos;
-        a.M = M; a.N = D; a.K = 3 * v->P * v->P; a.S = S; a.R = v->R; a.P = v->P; a.G = v->G;
+        a.M = M; a.N = D; a.K = v->Kpe; a.Kreal = v->Kpe_real; a.S = S; a.R = v->R; a.P = v->P; a.G = v->G;
         VIT_TRY(gemm_launch<EP_PATCH>(a, st));
     }
     for (int l = 0; l < v->L; ++l) {
@@ -430,7 +479,7 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
         {
             GemmArgs a{};
             a.xpad = 1; a.X = w_x16; a.W = Ly.wqkv; a.bias = Ly.bqkv; a.out16 = w_qk16; a.outVT = w_vT;
-            a.M = M; a.N = 3 * D; a.K = D; a.ldx = D; a.ldo = 2 * D; a.S = S; a.Sp = v->Sp; a.D = D; a.hd = v->hd;
+            a.M = M; a.N = 3 * D; a.K = D; a.ldx = D; a.ldo = 2 * v->nh * v->hdk; a.S = S; a.Sp = v->Sp; a.D = D; a.hd = v->hd; a.hdk = v->hdk; a.hdv = v->hdv;
             VIT_TRY(gemm_launch<EP_QKV>(a, st));
         }
         // batched frames: one workgroup per (frame, head) with K and V^T resident in LDS; few frames: 64-query tiles, keys split over 4 waves
@@ -438,8 +487,10 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
         if (head_min > 0 && B * v->nh >= head_min && v->attn_head_lds > 0)
             hipLaunchKernelGGL((vit_attn_head_kernel<0>), dim3((S + 575) / 576, v->nh, B), dim3(768), v->attn_head_lds, st, w_qk16, w_vT, w_att16, S, D, v->nh,
                                scale * 1.4426950408889634f, v->attn_vrs);
-        else
+        else if (v->hdk == 64)
             hipLaunchKernelGGL((vit_attn_kernel<64>), dim3((S + 63) / 64, v->nh, B), dim3(256), kAttnLds, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
+        else
+            hipLaunchKernelGGL((vit_attn_kernel<96, 80>), dim3((S + 63) / 64, v->nh, B), dim3(256), attn_lds(80), st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
         VIT_TRY(resid_gemm(w_att16, Ly.wo, Ly.bo, D, ks_out));
         layernorm(Ly.ln2_w, Ly.ln2_b, w_x16, nullptr);
         {
