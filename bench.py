@@ -37,7 +37,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from videollm_online_amd.synthetic import (LLM_SHAPES, VIT_SHAPE, gpu_random_weights, gpu_synthetic_frames,  # noqa: E402
+from videollm_online_amd.synthetic import (LLM_SHAPES, VIT_SHAPE, VIT_SHAPES, vit_gflop_per_frame, gpu_random_weights, gpu_synthetic_frames,  # noqa: E402
                                            stream_tokens)
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -298,6 +298,8 @@ def main():
     ap.add_argument("--tp-allreduce", default="rccl", choices=["rccl", "p2p"],
                     help="--tp exchanges: RCCL all-reduce / all-gather, or the one-shot peer-to-peer all-reduce over xGMI fused "
                          "with the residual add + RMSNorm (csrc/tp.hip, no RCCL)")
+    ap.add_argument("--vit", default="siglip-l16-384", choices=sorted(VIT_SHAPES),
+                    help="vision tower (BASELINE.json's metric is quoted on siglip-l16-384; configs[4] names siglip-so400m14-384)")
     ap.add_argument("--tp-vit", default="frame-parallel", choices=["frame-parallel", "replicated"],
                     help="--tp over RCCL: rank r encodes frames r, r + N, ... of a pending batch and one all-gather distributes the "
                          "[10, H] frame embeddings (north_star), or every rank encodes every frame")
@@ -351,8 +353,10 @@ def main():
     n_frames = max(total, Wm) + 2
     # KV: start prompt + 11 tokens per frame + responses (query + "]\nAssistant:" + 16 tokens, every 10th frame)
     kv_tokens = 64 + 11 * n_frames + (n_frames // 10 + 2) * 24 + 4096
-    cfg = EngineConfig(**shape, vision_hidden_size=1024, vit=VIT_SHAPE, kv_pool_tokens=kv_tokens, weight_dtype=args.weight_dtype)
-    log(f"building engine ({args.model} + siglip-l16-384), kv pool {kv_tokens} tokens")
+    vit_shape = VIT_SHAPES[args.vit]
+    vit_gflop = VIT_GFLOP_PER_FRAME if args.vit == "siglip-l16-384" else vit_gflop_per_frame(vit_shape, shape["hidden_size"])
+    cfg = EngineConfig(**shape, vision_hidden_size=vit_shape["hidden_size"], vit=vit_shape, kv_pool_tokens=kv_tokens, weight_dtype=args.weight_dtype)
+    log(f"building engine ({args.model} + {args.vit}), kv pool {kv_tokens} tokens")
     tp = args.tp and world > 1
     if tp:
         # every rank builds the SAME full random weights (same seed) and keeps its shard; the RCCL communicator is
@@ -498,7 +502,7 @@ def main():
             "data": "synthetic",
             "p50_frame_latency_ms": round(statistics.median(costs) * 1e3, 4),
             "p95_frame_latency_ms": round(sorted(costs)[int(0.95 * (len(costs) - 1))] * 1e3, 4),
-            "config": {"workload": f"{args.model} + siglip-l16-384, "
+            "config": {"workload": f"{args.model} + {args.vit}, "
                                    + (f"the LAST {K} frames (frames {preroll}..{total - 1}) of a {total}-frame stream = {minutes:g} min @ {args.fps:g} FPS 384x384 uint8 "
                                       f"(frames 0..{preroll - 1} pre-rolled un-timed through the same engine steps on the same session; KV at "
                                       f"{kv_start} tokens when the clock starts, {final_len} when it stops), "
@@ -516,9 +520,10 @@ def main():
                                                         "the exchange is latency-bound at this size",
                                                 **(eng.p2p_status() if args.tp_allreduce == "p2p" else {}))} if tp else {})},
             "encode_stage": {"batch": max(1, args.prefetch_frames), "ms_per_frame": round(vit_ms, 4),
-                             "tflops": round(VIT_GFLOP_PER_FRAME / vit_ms, 1), "mfma_peak_tflops": MFMA_PEAK_TFLOPS,
-                             "frac_of_mfma_peak": round(VIT_GFLOP_PER_FRAME / vit_ms / MFMA_PEAK_TFLOPS, 4),
-                             "note": "SigLIP-L/16-384 + connector, 384.4 GFLOP/frame (SURVEY.md §8d), fp16 MFMA, measured alone"},
+                             "tflops": round(vit_gflop / vit_ms, 1), "mfma_peak_tflops": MFMA_PEAK_TFLOPS,
+                             "frac_of_mfma_peak": round(vit_gflop / vit_ms / MFMA_PEAK_TFLOPS, 4),
+                             "note": ("SigLIP-L/16-384 + connector, 384.4 GFLOP/frame (SURVEY.md §8d), fp16 MFMA, measured alone" if args.vit == "siglip-l16-384"
+                                      else f"{args.vit} + connector, {vit_gflop:.1f} GFLOP/frame (encoder + patch embed + head K/V + connector), fp16 MFMA, measured alone")},
             **({"full_stream": full_stream} if full_stream else {}),
             "stream_hbm_roofline": {"algorithmic_llm_bytes": alg_bytes, "frac_of_hbm_peak": round(alg_bytes / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
             "roofline": {"bound": "hbm", "kernel": "gemv16_kernel<KF,EPI_SWIGLU> (gate/up projection + SwiGLU)" + (", fp8 weight image" if args.weight_dtype == "fp8" else ""),
@@ -562,7 +567,9 @@ def main():
             effs = {name: leg.get("scaling_efficiency") for name, leg in (("tp", tp_leg), ("tp_p2p", tp_p2p_leg)) if leg and leg.get("scaling_efficiency")}
             out["tp_scaling_efficiency"] = max(effs.values()) if effs else None
             out["tp_scaling_efficiency_by_leg"] = effs or None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.vit != "siglip-l16-384":
+            out["cpu_baseline"] = {"value": None, "note": "the CPU baseline is the reference's own path, which only accepts SigLIP-L (models/vision_live.py:56-60)"}
+        elif world == 1 and not args.no_cpu_baseline:
             log("cpu_baseline: building CPU oracle")
             try:
                 out["cpu_baseline"] = cpu_baseline(args.model, frames[:max(args.cpu_sample_frames, 10)].cpu(), toks, args.mode,

@@ -13,6 +13,19 @@ LLM_SHAPES = {
                            num_key_value_heads=4, vocab_size=32000, rope_theta=10000.0, rms_norm_eps=1e-5),
 }
 VIT_SHAPE = dict(hidden_size=1024, intermediate_size=4096, num_layers=24, num_heads=16, image_size=384, patch_size=16)
+# BASELINE.json configs[4]'s tower (HF google/siglip-so400m-patch14-384): head dim 72, 729 patches of 14 pixels
+VIT_SHAPE_SO400M = dict(hidden_size=1152, intermediate_size=4304, num_layers=27, num_heads=16, image_size=384, patch_size=14)
+VIT_SHAPES = {"siglip-l16-384": VIT_SHAPE, "siglip-so400m14-384": VIT_SHAPE_SO400M}
+
+
+def vit_gflop_per_frame(v: dict, llm_hidden: int) -> float:
+    """Encoder layers + patch embed + the MAP head's K / V projection + the 10-token connector (SURVEY.md §8d counts the same terms:
+    384.4 for SigLIP-L into a 4096-wide LLM; this formula gives 384.2)."""
+    D, I, L, P = v["hidden_size"], v["intermediate_size"], v["num_layers"], v["patch_size"]
+    S = (v["image_size"] // P) ** 2
+    enc = L * (2 * S * D * (4 * D + 2 * I) + 4 * S * S * D) + 2 * S * 3 * P * P * D + 2 * S * D * 2 * D
+    conn = 2 * 10 * (D * llm_hidden + llm_hidden * llm_hidden)
+    return (enc + conn) / 1e9
 
 
 def gpu_random_weights(eng, cfg, seed=0):
