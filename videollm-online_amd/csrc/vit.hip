@@ -181,7 +181,7 @@ __global__ void f16_to_f32_kernel(const f16_t *__restrict__ a, float *__restrict
 // ------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------
-static size_t attn_lds(int hdv) { return (size_t)4 * 4 * (hdv / 16) * 64 * 16 + 4 * 4 * 16 * 2 * 4; }     // O partials + (m, l) of vit_attn_kernel
+static size_t attn_lds(int hdv, int qs = 4) { return (size_t)4 * qs * (hdv / 16) * 64 * 16 + 4 * qs * 16 * 2 * 4; }     // O partials + (m, l) of vit_attn_kernel
 static const size_t kAttnLds = attn_lds(64);
 
 struct VitLayer {
@@ -365,6 +365,7 @@ int vit_finalize(vlo_engine *e) {
 #undef PAD
     VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnLds));
     VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_kernel<96, 80>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds(80)));
+    VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_kernel<96, 80, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds(80, 2)));
     {
         const int cpr = v->Sp / 8;                                   // 16-byte chunks per V^T row
         v->attn_vrs = (cpr + ((10 - cpr % 16) + 16) % 16) * 16;
@@ -489,8 +490,13 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
                                scale * 1.4426950408889634f, v->attn_vrs);
         else if (v->hdk == 64)
             hipLaunchKernelGGL((vit_attn_kernel<64>), dim3((S + 63) / 64, v->nh, B), dim3(256), kAttnLds, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
-        else
-            hipLaunchKernelGGL((vit_attn_kernel<96, 80>), dim3((S + 63) / 64, v->nh, B), dim3(256), attn_lds(80), st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
+        else {
+            static const int qs = getenv("VLO_VIT_ATTN_QS") ? atoi(getenv("VLO_VIT_ATTN_QS")) : 4;     // 16-query sub-tiles per block for the padded-head kernel
+            if (qs == 2)
+                hipLaunchKernelGGL((vit_attn_kernel<96, 80, 2>), dim3((S + 31) / 32, v->nh, B), dim3(256), attn_lds(80, 2), st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
+            else
+                hipLaunchKernelGGL((vit_attn_kernel<96, 80>), dim3((S + 63) / 64, v->nh, B), dim3(256), attn_lds(80), st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
+        }
         VIT_TRY(resid_gemm(w_att16, Ly.wo, Ly.bo, D, ks_out));
         layernorm(Ly.ln2_w, Ly.ln2_b, w_x16, nullptr);
         {
