@@ -420,7 +420,7 @@ def test_vit_small_tile_direct_to_lds_kernels_in_emulation(E, tmp_path):
     base = str(tmp_path / "ring.pt")
     _vitpp_child(dict(VLO_VIT_PP="0", VLO_VIT_ATTN_HEAD_MIN="0", VLO_VIT_SMALL_STAGES="0"), base)
     want = torch.load(base)
-    for stages in ("4", "6"):
+    for stages in (("4", "6") if FULL else ("4",)):          # 4 is what ships (3 differs only in the stage count); 6 with VLO_EMUL_FULL=1
         f = str(tmp_path / f"glds_{stages}.pt")
         _vitpp_child(dict(VLO_VIT_PP="0", VLO_VIT_ATTN_HEAD_MIN="0", VLO_VIT_SMALL_STAGES=stages, VLO_EMUL_GLDS="late"), f)
         assert torch.equal(torch.load(f), want), stages
