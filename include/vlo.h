@@ -66,7 +66,9 @@ typedef struct vlo_config {
     /* connector / frame tokens */
     int32_t vision_hidden_size;   /* LiveConfigMixin.vision_hidden_size */
     int32_t frame_num_tokens;     /* 1 (CLS) + pool_h*pool_w */
-    /* SigLIP vision tower (has_vit = 0: LLM only, vlo_visual_embed unavailable) */
+    /* SigLIP vision tower (has_vit = 0: LLM only, vlo_visual_embed unavailable).  Shapes: hidden % 64 == 0 and <= 2048, head dim 64
+     * (SigLIP-L/16-384, what the reference accepts: models/vision_live.py:56-60) or 68..80 in steps of 4 (SigLIP-so400m/14-384: 72),
+     * any MLP width % 4 == 0, any patch size; image_size / patch_size rounds down like the strided conv (HF modeling_siglip.py:175-186) */
     int32_t has_vit;
     int32_t vit_hidden_size;
     int32_t vit_intermediate_size;
@@ -111,7 +113,7 @@ void    vlo_session_destroy(vlo_session *s);
  *      models/live_llama/modeling_live_llama.py:18-22).
  *      frames_dev: uint8 [B,3,R,R] NCHW;  out_dev: bf16 [B*frame_num_tokens, hidden_size].
  *      The encode workspace belongs to the ENGINE: encodes of one engine issued on different streams must be ordered by the caller
- *      (LiveInfer issues all of them on its one encode stream).  From 12 frames up the batch runs as two parallel half-batch branches
+ *      (LiveInfer issues all of them on its one encode stream).  From 4 frames up the batch runs as two parallel half-batch branches
  *      (the second on an internal stream, joined back before the call's work on `stream` ends). */
 int vlo_visual_embed(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_dev, void *stream);
 /* ---- vision tokens only: `vision_encode(model, frames)` as the offline feature extraction uses it
