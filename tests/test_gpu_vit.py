@@ -32,7 +32,8 @@ def _engine(spec, vspec, w, vw):
 
 
 @pytest.mark.parametrize("llm,vit,B", [("toy128", "toy", 3), ("toy128", "toy", 1), ("tinyllama-2l", "siglip-l16-384-2l", 2),
-                                       ("tinyllama-2l", "siglip-l16-384-2l", 4),      # B=4 takes the 128x128-tile GEMM path
+                                       ("tinyllama-2l", "siglip-l16-384-2l", 4),      # B=4: two branches of two frames
+                                       ("tinyllama-2l", "siglip-l16-384-2l", 1),      # one frame: out-proj / fc2 as split-K slabs + reducing LayerNorm
                                        # BASELINE.json configs[4]'s tower: head dim 72, MLP 4304, 729 patches of 14 pixels — padded
                                        # heads / MLP width / patch K (csrc/vit.hip::vit_finalize); 1 frame: 64x64 tiles; 9 frames:
                                        # two branches on 128x128 tiles
