@@ -53,9 +53,13 @@ def test_llama_step_sequence_matches_hf(dtype, which):
         assert past.get_seq_length() == len(cache)
 
 
-def test_siglip_tower_matches_hf():
+# toy-hd72: SigLIP-so400m/14's irregularities (head dim 72, MLP % 64 != 0, 14-pixel patches); so400m-1l: one layer at its true geometry
+# (hidden 1152, MLP 4304, 384 / 14 -> 27 x 27 patches: the strided conv drops the last 6 pixels)
+@pytest.mark.parametrize("which", ["toy", "toy-hd72", "so400m-1l"])
+def test_siglip_tower_matches_hf(which):
+    import dataclasses
     from transformers import SiglipVisionConfig, SiglipVisionModel
-    vspec = O.VIT_SPECS["toy"]
+    vspec = dataclasses.replace(O.VIT_SPECS["siglip-so400m14-384-2l"], num_layers=1) if which == "so400m-1l" else O.VIT_SPECS[which]
     vw = O.init_vit_weights(vspec, seed=1)
     cfg = SiglipVisionConfig(hidden_size=vspec.hidden_size, intermediate_size=vspec.intermediate_size,
                              num_hidden_layers=vspec.num_layers, num_attention_heads=vspec.num_heads,

@@ -42,9 +42,13 @@ class LiveConfig:
 def _vit_config(vision_pretrained: str) -> dict:
     cfg = json.load(open(os.path.join(vision_pretrained, "config.json")))
     v = cfg.get("vision_config", cfg)
-    if v.get("hidden_size", 1024) // v.get("num_attention_heads", 16) != 64:
-        # the reference itself only accepts SigLIP-L and two CLIPs (models/vision_live.py:56-60)
-        raise ValueError(f"unsupported vision tower {vision_pretrained!r}: head_dim must be 64 (SigLIP-L/16-384)")
+    D, nh = v.get("hidden_size", 1024), v.get("num_attention_heads", 16)
+    hd = D // nh
+    if hd * nh != D or D % 64 or D > 2048 or not (hd == 64 or (68 <= hd <= 80 and hd % 4 == 0)):
+        # the reference itself only accepts SigLIP-L and two CLIPs (models/vision_live.py:56-60); the engine also runs SigLIP-so400m/14
+        # (head dim 72, BASELINE.json configs[4]) — the shape rule is csrc/vit.hip::vit_finalize's
+        raise ValueError(f"unsupported vision tower {vision_pretrained!r}: head_dim {hd} (64 = SigLIP-L/16-384, or 68..80 = SigLIP-so400m/14), "
+                         f"hidden {D} (a multiple of 64, at most 2048)")
     return dict(hidden_size=v.get("hidden_size", 1024), intermediate_size=v.get("intermediate_size", 4096),
                 num_layers=v.get("num_hidden_layers", 24), num_heads=v.get("num_attention_heads", 16),
                 image_size=v.get("image_size", 384), patch_size=v.get("patch_size", 16), ln_eps=v.get("layer_norm_eps", 1e-6))
