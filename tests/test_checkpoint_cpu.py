@@ -87,3 +87,25 @@ def test_siglip_key_mapping(tmp_path):
     got = dict(CK.iter_vision_weights(str(d)))
     assert set(got) == set(vw)
     assert all(torch.equal(got[k], vw[k]) for k in vw)
+
+
+def test_builder_vision_config_accepts_the_towers_the_engine_runs(tmp_path):
+    """builder._vit_config reads the vision tower's config.json: SigLIP-L/16-384 (what the reference accepts, models/vision_live.py:56-60)
+    and SigLIP-so400m/14-384 (BASELINE.json configs[4]; head dim 72) map to the engine's vit dict, a head dim the kernels do not cover
+    is refused up front (the same rule as csrc/vit.hip::vit_finalize)."""
+    import json
+    from videollm_online_amd.builder import _vit_config
+
+    def cfg_dir(name, **vision):
+        d = tmp_path / name
+        d.mkdir()
+        (d / "config.json").write_text(json.dumps({"vision_config": vision}))
+        return str(d)
+
+    l = _vit_config(cfg_dir("l", hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=384, patch_size=16))
+    assert (l["hidden_size"], l["num_heads"], l["patch_size"], l["num_layers"]) == (1024, 16, 16, 24)
+    so = _vit_config(cfg_dir("so", hidden_size=1152, intermediate_size=4304, num_hidden_layers=27, num_attention_heads=16, image_size=384, patch_size=14))
+    assert (so["hidden_size"], so["intermediate_size"], so["num_heads"], so["patch_size"], so["num_layers"]) == (1152, 4304, 16, 14, 27)
+    with pytest.raises(ValueError, match="unsupported vision tower"):
+        _vit_config(cfg_dir("big", hidden_size=1536, intermediate_size=6144, num_hidden_layers=40, num_attention_heads=16, image_size=224, patch_size=14))
+
