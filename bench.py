@@ -189,7 +189,8 @@ def run_tp_leg(args, rank, world, local, allreduce="rccl", port_offset=17):
     steps = max(20, min(args.steps, args.tp_leg_steps))
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(steps), "--warmup", "10", "--tp",
            "--tp-allreduce", allreduce, "--no-cpu-baseline", "--model", args.model, "--mode", args.mode, "--fps", str(args.fps),
-           "--prefetch-frames", str(args.prefetch_frames), "--tp-vit", getattr(args, "tp_vit", "frame-parallel")]
+           "--prefetch-frames", str(args.prefetch_frames), "--tp-vit", getattr(args, "tp_vit", "frame-parallel"),
+           "--vit", getattr(args, "vit", "siglip-l16-384"), "--weight-dtype", getattr(args, "weight_dtype", "bf16")]
     log(f"tp leg: {' '.join(cmd[1:])}")
     t0 = time.time()
     try:
