@@ -1,5 +1,5 @@
-"""Long GPU parity runs (opt-in: VLO_LONG_TESTS=1 — minutes of CPU oracle time each; the numbers they print are kept in
-profiles/r3_parity_measurements.txt).
+"""Long GPU parity runs (opt-in: VLO_LONG_TESTS=1 — the whole file takes ~23 minutes on an MI355X box, most of it the oracle
+following the two 1 200-frame traces; the numbers they print are kept in profiles/r3_parity_measurements.txt).
 
 * the TIMED PATH AS ONE TRACE: the package's LiveInfer with the bench's settings (batched prefetch of 28 frames on the encode
   stream, staging buffer, fused sampler, speculative greedy loop) over all 1 200 frames of BASELINE.json configs[1]'s stream

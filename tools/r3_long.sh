@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# Round-3 long parity runs (tests/test_gpu_long.py) on the GPU box; the printed numbers go to profiles/r3_parity_measurements.txt
+# Round-3 long parity runs (tests/test_gpu_long.py) on the GPU box — ~23 GPU-minutes for the whole file (R3ARGS='-k scheduled' etc. to pick one); the printed numbers go to profiles/r3_parity_measurements.txt
 set -u
 cd "$(dirname "$0")/.."
 OUT=$PWD/gpurun_out/${R3OUT:-r3long}
