@@ -288,6 +288,7 @@ def main():
                          "demo/inference.py:105-106).  56 frames = 32256 token rows = 126 row tiles of 256: every GEMM of the tower is a whole "
                          "number of 256-CU rounds within 2 % (504 / 1512 / 2016 tiles); 28 frames give 252 / 756 / 1008")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-feed", action="store_true", help="skip the two no-look-ahead re-runs of the timed frames (`live_feed`)")
     ap.add_argument("--cpu-sample-frames", type=int, default=20)
     ap.add_argument("--cpu-windows", default="", help="comma-separated cache lengths (e.g. 1024,4096,13312): the CPU baseline additionally times "
                                                       "10-frame windows with the KV cache pre-filled to these lengths (BASELINE.md section 4); "
@@ -427,6 +428,8 @@ def main():
         log(f"pre-roll done: {pre[0]:.2f}s, KV at {len(li.past_key_values)} tokens")
     kv_start = len(li.past_key_values) if li.past_key_values else 0
     log(f"timing {K} frames (frames {preroll}..{total - 1})")
+    # session state at the start of the timed region: the live-feed legs below re-run the SAME frames from the SAME context
+    snap = dict(last_ids=list(li.last_ids), last_frame_idx=li.last_frame_idx, video_time=li.video_time, frames_done=li._frames_done)
     eng.profile_enable(args.prof_stride)
     elapsed, costs, alg_bytes, llm_steps = run(preroll, total)
     log(f"timed region done: {elapsed:.3f}s -> {K / elapsed:.1f} frames/s on this rank")
@@ -450,6 +453,33 @@ def main():
         enc.synchronize()
         vit_ms = e0.elapsed_time(e1) / 8 / B
     final_len = len(li.past_key_values)
+    # live feed: the same K frames at the same context WITHOUT look-ahead.  `value` encodes frames in batches of
+    # `prefetch_frames` ahead of the Llama steps — legitimate for a recorded video (the reference's demo loads the whole file,
+    # demo/inference.py:111-115) but prefetch_frames / fps seconds of look-ahead a live camera does not have.  Leg 1: no look-ahead
+    # at all (frame t is encoded when it arrives, then its step runs: the encoder sits on the critical path of every frame).
+    # Leg 2: one frame of look-ahead (frame t+1 encoded on the encode stream while the step of frame t runs).
+    live_feed = None
+    if not tp and kv_start > 0 and not args.no_live_feed:
+        live_feed = {}
+        saved = (li.prefetch, li.prefetch_frames)
+        for name, (pf, pfn) in (("no_lookahead", (False, 1)), ("one_frame_lookahead", (True, 1))):
+            li.past_key_values.crop(kv_start)
+            li.last_ids, li.last_frame_idx, li.video_time, li._frames_done = list(snap["last_ids"]), snap["last_frame_idx"], snap["video_time"], snap["frames_done"]
+            li.query_queue.clear(); li.frame_embeds_queue.clear()
+            li.prefetch, li.prefetch_frames = pf, pfn
+            el, cs, _, st_n = run(preroll, total)
+            el = reduce_elapsed_max(dist, el, device="cuda" if backend == "nccl" else "cpu")
+            if args.mode != "free":       # a fixed schedule: exactly the same Llama steps as the timed region
+                assert len(li.past_key_values) == final_len and st_n == llm_steps, (len(li.past_key_values), final_len, st_n, llm_steps)
+            live_feed[name] = {"frames_per_s": round(aggregate_fps(K, world, el), 3), "p50_frame_latency_ms": round(statistics.median(cs) * 1e3, 4),
+                               "p95_frame_latency_ms": round(sorted(cs)[int(0.95 * (len(cs) - 1))] * 1e3, 4)}
+            log(f"live_feed {name}: {K / el:.1f} frames/s, p50 {statistics.median(cs) * 1e3:.2f} ms")
+        li.prefetch, li.prefetch_frames = saved
+        live_feed["note"] = (f"the same {K} frames from the same context ({kv_start} cached tokens, KV cropped back) with the encoder on the critical path: "
+                             f"`value` batches {args.prefetch_frames} frames of look-ahead per ViT call (= {args.prefetch_frames / args.fps:g} s of video at {args.fps:g} FPS, fine for a "
+                             f"recorded file, not available to a live camera); no_lookahead = encode(frame t) then step(t) serially; "
+                             f"one_frame_lookahead = encode(t+1) overlaps step(t)")
+        live_feed["frames_per_s"] = live_feed["no_lookahead"]["frames_per_s"]
     # tensor-parallel runs: latency of ONE exchange (all-reduce of [n, H] fp32 + residual add + RMSNorm) at the frame-step and the
     # decode-step size, every rank in lock-step — the number the xGMI all-reduce discussion of SURVEY.md §8e is about
     tp_exchange_us = None
@@ -526,6 +556,7 @@ def main():
                              "note": ("SigLIP-L/16-384 + connector, 384.4 GFLOP/frame (SURVEY.md §8d), fp16 MFMA, measured alone" if args.vit == "siglip-l16-384"
                                       else f"{args.vit} + connector, {vit_gflop:.1f} GFLOP/frame (encoder + patch embed + head K/V + connector), fp16 MFMA, measured alone")},
             **({"full_stream": full_stream} if full_stream else {}),
+            **({"live_feed": live_feed} if live_feed else {}),
             "stream_hbm_roofline": {"algorithmic_llm_bytes": alg_bytes, "frac_of_hbm_peak": round(alg_bytes / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
             "roofline": {"bound": "hbm", "kernel": "gemv16_kernel<KF,EPI_SWIGLU> (gate/up projection + SwiGLU)" + (", fp8 weight image" if args.weight_dtype == "fp8" else ""),
                          "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -170,7 +170,9 @@ int vlo_stream_sample(vlo_session *s, float threshold, int interval_id, int64_t 
  *      force_len > 0: scheduled mode for throughput runs — argmax still computed each step,
  *      but exactly force_len tokens are produced and the last is eos.
  *      *n_written (host) receives i+1.  Synchronises the stream (the reference syncs once
- *      per token at :179). */
+ *      per token at :179).  After a response that ended with eos the session holds NO logits
+ *      (vlo_stream_sample then returns VLO_E_STATE until the next vlo_llm_step), whichever
+ *      internal path produced the eos. */
 int vlo_greedy_generate(vlo_session *s, const void *embeds_dev, int m, int eos_token_id,
                         int64_t *out_ids_dev, int max_new, int force_len, int *n_written, void *stream);
 

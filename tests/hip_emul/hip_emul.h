@@ -59,6 +59,7 @@ typedef emul_dim3 dim3;
 struct uint2 { unsigned x, y; };
 struct alignas(16) uint4 { unsigned x, y, z, w; };
 struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(8) float2 { float x, y; };
 struct alignas(8) ushort4 { unsigned short x, y, z, w; };
 static inline uint2 make_uint2(unsigned x, unsigned y) { return {x, y}; }
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return {x, y, z, w}; }

@@ -583,3 +583,39 @@ def test_vision_tower_with_padded_head_dim_mlp_width_and_patch_k(E):
                                                                     - want.float()).abs().max().item() + 2 * 2 ** -8 * want.abs().max().item()
     eng.close()
 
+
+
+def test_unsupported_head_dims_are_rejected_not_silently_wrong(E):
+    """vit_finalize takes head dim 64 exactly or 68..80 (padded storage).  52 / 56 / 60 also round up to 64 columns / rows, but the
+    unpadded kernel would store 64 columns per head at a stride of hd — the engine must refuse them (round-3 advisor finding)."""
+    import dataclasses
+    base = O.VIT_SPECS["toy"]
+    spec = O.LlmSpec(128, 192, 1, 2, 2, 256, 10000.0, 1e-5, vision_hidden_size=base.hidden_size)
+    for hd, nh in ((56, 8), (60, 32)):            # hidden sizes 448 / 1920: multiples of 64 the connector's GEMV has a plan for
+        vs = dataclasses.replace(base, hidden_size=hd * nh, num_heads=nh, intermediate_size=128)
+        sp = dataclasses.replace(spec, vision_hidden_size=vs.hidden_size)
+        w, vw = O.init_llm_weights(sp, seed=3), O.init_vit_weights(vs, seed=2)
+        eng = E.EmulEngine(sp, vit=vs)
+        with pytest.raises(RuntimeError, match="vision tower shape"):
+            eng.load_weights({**w, **vw}, O.rope_inv_freq(sp.head_dim, sp.rope_theta))
+        eng.close()
+
+
+def test_greedy_eos_leaves_no_logits_on_either_path(E):
+    """vlo_greedy_generate after an EOS: the session holds no logits whether the EOS was found behind a speculative step (inside
+    owned pages) or on the blocking path (no speculation: page / position boundary, or the last allowed token — max_new = 1 here)
+    — a sampler call then fails with VLO_E_STATE on both (round-3 advisor finding)."""
+    spec = TINY
+    w = O.init_llm_weights(spec, seed=3)
+    toks = O.default_tokens(spec)
+    ref = O.LlamaOracle(spec, w, torch.bfloat16)
+    eng = E.EmulEngine(spec).load_weights(w, O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+    x = ref.embed(torch.tensor(toks.stream_generation_ids))
+    t0 = eng.greedy_generate(eng.new_session(), x, -1, 1)[0]             # the first token this prompt produces (eos = -1: never)
+    for max_new in (4, 1):                                               # speculative path | blocking path
+        s = eng.new_session()
+        assert eng.greedy_generate(s, x, t0, max_new) == [t0]             # ... declared EOS: the response ends right there
+        assert eng.session_len(s) == x.shape[0]                           # the EOS token is never fed to the model
+        with pytest.raises(RuntimeError):
+            eng.stream_sample(s, 0.725, toks.interval_id)
+    eng.close()

@@ -1,12 +1,16 @@
-"""Long GPU parity runs (opt-in: VLO_LONG_TESTS=1 — the whole file takes ~23 minutes on an MI355X box, most of it the oracle
-following the two 1 200-frame traces; the numbers they print are kept in profiles/r3_parity_measurements.txt).
+"""Long-horizon GPU parity.
 
-* the TIMED PATH AS ONE TRACE: the package's LiveInfer with the bench's settings (batched prefetch of 28 frames on the encode
-  stream, staging buffer, fused sampler, speculative greedy loop) over all 1 200 frames of BASELINE.json configs[1]'s stream
-  (2 distinct Llama-3-8B-width layers + 2 SigLIP-L layers, KV to > 13 k tokens), scheduled AND free-running, followed decision by
-  decision by the oracle's restatement of demo/inference.py:40-123 teacher-forced with the engine's own tokens and frame
-  embeddings: every sampler decision and every greedy token must be the reference-bf16 path's, except at a near-tie of the
-  reference's own logits where the engine may pick the runner-up;
+DEFAULT (runs with the driver's `pytest tests -m gpu`, about a minute): the TIMED PATH AS ONE TRACE on a 150-frame slice of
+BASELINE.json configs[1]'s stream — the package's LiveInfer with the bench's settings (batched prefetch of 56 frames on the encode
+stream, i.e. the 256-row ping-pong GEMM + whole-head attention kernels, staging buffer, fused sampler, speculative greedy loop),
+2 distinct Llama-3-8B-width layers + 2 SigLIP-L layers, scheduled AND free-running, followed decision by decision by the oracle's
+restatement of demo/inference.py:40-123 teacher-forced with the engine's own tokens and frame embeddings: every sampler decision
+and every greedy token must be the reference-bf16 path's, except at a near-tie of the reference's own logits where the engine
+may pick another of the tied candidates (rule in Follower._judge; DESIGN.md §2 states it and its history).
+
+OPT-IN (VLO_LONG_TESTS=1, ~23 minutes on an MI355X box, most of it the oracle following two 1 200-frame traces; numbers kept in
+profiles/r*_parity_measurements.txt):
+* the same trace over all 1 200 frames (KV to > 13 k tokens);
 * config 3's context: all-row logits 3-way at 66 000 cached tokens (narrow 3-layer model with the 8B head geometry);
 * tensor-parallel logical ranks T = 8 at 13 k cached tokens.
 """
@@ -19,8 +23,10 @@ import torch
 
 from oracle import vlo_oracle as O
 from tests.parity_util import fmt, ulp_report
+from videollm_online_amd.trace import FRAME, RESPONSE, FrameEvent, ResponseEvent      # the ONE event schema
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("VLO_LONG_TESTS") != "1", reason="long parity runs: VLO_LONG_TESTS=1")]
+pytestmark = pytest.mark.gpu
+long_only = pytest.mark.skipif(os.environ.get("VLO_LONG_TESTS") != "1", reason="long parity runs: VLO_LONG_TESTS=1")
 
 NEAR_TIE = 0.12     # logit units, as tests/test_gpu_liveinfer.py
 
@@ -79,49 +85,59 @@ class Follower(O.LiveInferOracle):
             self._frames_done += 1
             if self.query_queue and video_time >= self.query_queue[0][0]:
                 return self.query_queue.popleft()
-            ev = self.ev.popleft()
-            assert ev[0] == "frame" and ev[1] == video_time and ev[3] == len(self.past_key_values), (ev, video_time, len(self.past_key_values))
+            ev = FrameEvent(*self.ev.popleft())                        # the shared schema: a field added there fails HERE, loudly
+            assert ev.kind == FRAME and ev.video_time == video_time and ev.kv_len == len(self.past_key_values), (ev, video_time, len(self.past_key_values))
             zeroed = float(logits[-1].softmax(dim=-1)[self.tok.interval_id]) < self.threshold
             tok, _ = O.stream_sample(logits[-1], self.tok.interval_id, self.threshold)
-            self._judge("sampler", tok, ev[4], logits[-1], self.tok.interval_id if zeroed else None)
-            self.last_ids = [ev[2]]                                    # the token the engine went on with (scheduled or sampled)
-            if ev[2] != self.tok.interval_id:
+            self._judge("sampler", tok, ev.sampled, logits[-1], self.tok.interval_id if zeroed else None)
+            self.last_ids = [ev.token]                                 # the token the engine went on with (scheduled or sampled)
+            if ev.token != self.tok.interval_id:
                 return video_time, None
         return None, None
 
     def _call_for_response(self, video_time, query):                   # :40-52, teacher-forced with the engine's tokens
-        ev = self.ev.popleft()
-        assert ev[0] == "response" and ev[1] == video_time and ev[2] == query, (ev[:3], video_time, query)
+        ev = ResponseEvent(*self.ev.popleft())
+        assert ev.kind == RESPONSE and ev.video_time == video_time and ev.query == query, (ev[:3], video_time, query)
         self.last_ids = list(self.tok.query_ids[query]) if query is not None else list(self.tok.stream_generation_ids)
         forced = self.schedule(self._frames_done - 1) if self.schedule is not None else None
         x = self.llm.embed(torch.tensor(self.last_ids))
         eos, V = self.tok.eos_token_id, self.llm.spec.vocab_size
-        for i, t in enumerate(ev[3]):
+        for i, t in enumerate(ev.output_ids):
             logits, self.past_key_values = self.llm.forward(x, self.past_key_values)
             mine = int(logits[-1].argmax(dim=-1))
             if forced is not None:                                     # forced_generate's rules
-                if i == len(ev[3]) - 1:
+                if i == len(ev.output_ids) - 1:
                     mine = t if t == eos else mine
                 elif mine == eos:
                     mine = (eos + 1) % V
-            if not (forced is not None and i == len(ev[3]) - 1):
+            if not (forced is not None and i == len(ev.output_ids) - 1):
                 self._judge("greedy", mine, t, logits[-1])
-            if i < len(ev[3]) - 1:
+            if i < len(ev.output_ids) - 1:
                 x = self.llm.embed(torch.tensor([t]))
         if forced is None:
-            assert ev[3][-1] == eos or len(ev[3]) == self.max_new
-        self.last_ids = list(ev[3][-1:])
-        return query, ev[3]
+            assert ev.output_ids[-1] == eos or len(ev.output_ids) == self.max_new
+        self.last_ids = list(ev.output_ids[-1:])
+        return query, ev.output_ids
 
 
 @pytest.mark.parametrize("mode", ["scheduled", "free"])
+def test_liveinfer_150_frame_slice_is_the_reference_trace(mode):
+    """The default-suite slice: 150 frames, prefetch batches of 56 (the bench's), KV to ~2 k tokens."""
+    _trace_vs_reference(mode, int(os.environ.get("VLO_SLICE_FRAMES", "150")), prefetch_frames=56)
+
+
+@long_only
+@pytest.mark.parametrize("mode", ["scheduled", "free"])
 def test_liveinfer_1200_frame_stream_is_the_reference_trace(mode):
+    _trace_vs_reference(mode, int(os.environ.get("VLO_LONG_FRAMES", "1200")), prefetch_frames=int(os.environ.get("VLO_LONG_PREFETCH", "56")))
+
+
+def _trace_vs_reference(mode, T, prefetch_frames):
     from videollm_online_amd.engine import Engine, EngineConfig
     from videollm_online_amd.inference import LiveInfer, StreamTokens
     from videollm_online_amd.modeling_live import LiveModel
     from videollm_online_amd.synthetic import gpu_synthetic_frames
     spec, vspec = O.LLM_SPECS["llama-3-8b-2l"], O.VIT_SPECS["siglip-l16-384-2l"]
-    T = int(os.environ.get("VLO_LONG_FRAMES", "1200"))
     w, vw = O.init_llm_weights(spec, seed=31), O.init_vit_weights(vspec, seed=32)
     toks = O.default_tokens(spec, seed=7, n_start=35)
     cfg = EngineConfig(hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size, num_hidden_layers=spec.num_layers,
@@ -140,9 +156,9 @@ def test_liveinfer_1200_frame_stream_is_the_reference_trace(mode):
     st = StreamTokens(toks.start_ids, toks.stream_prompt_ids, toks.stream_generation_ids, toks.eos_token_id, toks.interval_id, dict(toks.query_ids))
     sched = (lambda i: (i % 10 == 9, 16)) if mode == "scheduled" else None          # bench.py make_schedule("scheduled")
     max_new = 100 if mode == "scheduled" else 8
-    li = LiveInfer(model, tokens=st, frame_fps=2, prefetch=True, prefetch_frames=28, schedule=sched, max_new_tokens=max_new, record=1 << 22)
+    li = LiveInfer(model, tokens=st, frame_fps=2, prefetch=True, prefetch_frames=prefetch_frames, schedule=sched, max_new_tokens=max_new, record=1 << 22)
     frames = gpu_synthetic_frames(T, seed=1234)
-    # the embeddings LiveInfer consumes, as it batches them (first frame alone, then 28 at a time on the encode stream)
+    # the embeddings LiveInfer consumes, as it batches them (first frame alone, then `prefetch_frames` at a time on the encode stream)
     embeds = {}
     inner = eng.visual_embed
 
@@ -190,6 +206,7 @@ def _gpu_oracles(spec, w):
     return O.LlamaOracle(spec, wg, torch.bfloat16), O.LlamaOracle(spec, wg, torch.float32)
 
 
+@long_only
 def test_config3_context_66k_logits_parity():
     """BASELINE.json configs[2] ends at ~66 k cached tokens: the cache of a narrow 3-layer model with the 8B head geometry (4 query
     heads of 128 on 2 kv heads) is filled to 66 000 tokens through the engine's block path and, in lock-step, through the oracle in
@@ -232,6 +249,7 @@ def test_config3_context_66k_logits_parity():
     eng.close()
 
 
+@long_only
 def test_tensor_parallel_8_logical_ranks_at_13k_context():
     """TP = 8 logical ranks (sharding arithmetic + exchanges on one GPU, sum kernels and the peer-to-peer mailboxes) at configs[1]'s
     context: two distinct 8B-width layers, the cache filled to 13 245 tokens through the TP step path and through the oracle (bf16 +

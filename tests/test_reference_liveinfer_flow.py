@@ -11,6 +11,7 @@ import torch
 
 from oracle import vlo_oracle as O
 from test_gpu_liveinfer import _build
+from videollm_online_amd.trace import frame_event, response_event      # the ONE event schema (also LiveInfer's and Follower's)
 
 pytestmark = pytest.mark.gpu
 
@@ -61,7 +62,7 @@ class ReferenceFlow:
                                                          past_key_values=self.past_key_values, eos_token_id=self.eos_token_id,
                                                          inplace_output_ids=self.inplace_output_ids)
         self.last_ids = output_ids[:, -1:]
-        self.events.append(("response", video_time, query, output_ids[0].tolist()))
+        self.events.append(response_event(video_time, query, output_ids[0].tolist()))
 
     def _call_for_streaming(self):                                                    # :54-82
         while self.frame_embeds_queue:
@@ -82,7 +83,7 @@ class ReferenceFlow:
             if next_score[:, :, self.frame_token_interval_id] < self.frame_token_interval_threshold:
                 next_score[:, :, self.frame_token_interval_id].zero_()
             self.last_ids = next_score.argmax(dim=-1)
-            self.events.append(("frame", video_time, int(self.last_ids), len(self.past_key_values)))
+            self.events.append(frame_event(video_time, int(self.last_ids), len(self.past_key_values)))   # no schedule: sampled == token
             if int(self.last_ids) != self.frame_token_interval_id:
                 return video_time, None
         return None, None

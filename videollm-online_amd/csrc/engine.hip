@@ -863,10 +863,10 @@ int vlo_greedy_generate(vlo_session *s, const void *embeds_dev, int m, int eos_t
         }
         HIP_TRY(hipEventSynchronize(s->tok_ev[i & 1]));
         if (*slot == eos_token_id) {
-            if (spec) {
-                s->len -= 1;                 // the EOS token is never fed to the model (:179-181)
-                s->has_logits = false;
-            }
+            if (spec) s->len -= 1;           // the EOS token is never fed to the model (:179-181)
+            // same session state after EOS on both paths: the logits that produced EOS are consumed (the speculative step has
+            // overwritten them anyway), a sampler call needs a new step first
+            s->has_logits = false;
             break;
         }
         if (last) break;

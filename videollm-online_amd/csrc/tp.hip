@@ -740,7 +740,7 @@ int vlo_tp_greedy_generate(vlo_tp_session *t, const void *embeds_dev, int m, int
         if (!forced) {          // every rank reads the same token (the logits are gathered on every rank)
             TP_TRY(hipMemcpyAsync(s->host_tok, out_ids_dev + i, 8, hipMemcpyDeviceToHost, st));
             TP_TRY(hipStreamSynchronize(st));
-            if (*s->host_tok == eos_token_id) break;
+            if (*s->host_tok == eos_token_id) { s->has_logits = false; break; }   // same post-EOS state as vlo_greedy_generate
         }
         if (last) break;
         TP_TRY(embed_gather_launch((const unsigned short *)e->embed, out_ids_dev + i, 1, e->cfg.hidden_size, V, s->emb1, st));

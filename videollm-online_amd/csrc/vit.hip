@@ -260,7 +260,9 @@ int vit_finalize(vlo_engine *e) {
     v->I = Ip;
     v->Kpe_real = 3 * v->P * v->P; v->Kpe = (v->Kpe_real + 63) / 64 * 64;
     v->hdk = (v->hd + 31) / 32 * 32; v->hdv = (v->hd + 15) / 16 * 16;
-    const bool heads_ok = (v->hdk == 64 && v->hdv == 64) || (v->hdk == 96 && v->hdv == 80);
+    // head dim 64 exactly, or 68..80 (padded to 96 q|k columns / 80 V^T rows).  52..60 would also round up to 64 / 64, but the
+    // unpadded kernel stores 64 columns per head at a stride of hd: rejected, not silently wrong
+    const bool heads_ok = v->hd == 64 || (v->hd >= 68 && v->hd <= 80 && v->hdk == 96 && v->hdv == 80);
     if (v->nh <= 0 || v->hd * v->nh != D || (v->hd & 3) || !heads_ok || (D % 64) || D > 2048 || (I & 3) || c.vision_hidden_size != D ||
         c.frame_num_tokens != 1 + v->ph * v->pw || v->G <= 0)          // G = R / P rounded down: a strided 'valid' conv ignores the remainder (384 / 14)
         { delete v; return vlo_fail(VLO_E_UNSUPPORTED, "vision tower shape not covered by the kernels (head dim 64 or 68..80 in steps of 4, hidden % 64 == 0 and <= 2048)"); }

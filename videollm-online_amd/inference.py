@@ -15,6 +15,7 @@ from dataclasses import dataclass, field
 import torch
 
 from .modeling_live import LiveModel, fast_greedy_generate
+from .trace import frame_event, response_event
 
 
 @dataclass
@@ -107,7 +108,7 @@ class LiveInfer:
         self.past_key_values = None
         self._encoded = {}                 # frame idx -> (embeds [T,H], ready event)
         self._frames_done = 0
-        self.trace = collections.deque(maxlen=self._record or 1)       # ("frame" | "response", ...) events, newest last
+        self.trace = collections.deque(maxlen=self._record or 1)       # trace.FrameEvent / trace.ResponseEvent, newest last
         self.step_log = collections.deque(maxlen=self._record or 1)    # (cache length before, new tokens) of the Llama steps
         self.steps_total = 0               # Llama steps executed since reset() (step_log keeps the newest `record` of them)
 
@@ -190,12 +191,14 @@ class LiveInfer:
                     raise RuntimeError(f"input_video_stream({video_time}) needs frames [{ranger.start}, {ranger.stop}) at once but the FrameRing holds "
                                        f"{self._ring.capacity}: advance the stream in smaller steps (or build a larger ring)")
                 self._ring.wait_for(ranger.stop, self.frame_wait_s)   # a live feed: the frames of this instant may still be on their way
-            feed_error = getattr(getattr(self._ring, "feed", None), "error", None)
-            if feed_error is not None:
-                raise RuntimeError(f"the video decoder feeding the FrameRing failed: {feed_error}") from feed_error
             self._encode_async(ranger.start, ranger.stop)
             for r in ranger:
                 if r not in self._encoded:
+                    # a decoder failure matters only when a frame this instant needs never arrived (a late error — e.g. at
+                    # process teardown after every frame was pushed — is reported by the caller at the end, cli.py)
+                    feed_error = getattr(getattr(self._ring, "feed", None), "error", None)
+                    if feed_error is not None:
+                        raise RuntimeError(f"the video decoder feeding the FrameRing failed before frame {r} arrived: {feed_error}") from feed_error
                     raise RuntimeError(f"frame {r} is not available: the video has {self.num_video_frames} frames"
                                        + (" so far (push it into the FrameRing first)" if self._ring is not None else ""))
                 self.frame_embeds_queue.append((r / self.frame_fps, self._encoded.pop(r)))
@@ -224,7 +227,7 @@ class LiveInfer:
             self._log_step(L0 + len(self.last_ids) + j, 1)
         self.last_ids = out[-1:]
         if self._record:
-            self.trace.append(("response", video_time, query, out))
+            self.trace.append(response_event(video_time, query, out))
         if query:
             query = f"(Video Time = {video_time}s) User: {query}"
         if self.tokenizer is not None:
@@ -276,8 +279,8 @@ class LiveInfer:
                 tok = self._added_stream_generation_ids[0] if forced[0] else self.frame_token_interval_id
             self.last_ids = [tok]
             if self._record:
-                # (kind, time, token used, KV length, token the sampler chose — differs from the one used only under a schedule)
-                self.trace.append(("frame", video_time, tok, len(self.past_key_values), sampled))
+                # trace.FrameEvent: the sampler's own choice differs from the token used only under a schedule
+                self.trace.append(frame_event(video_time, tok, len(self.past_key_values), sampled))
             if tok != self.frame_token_interval_id:
                 return video_time, None
         return None, None
