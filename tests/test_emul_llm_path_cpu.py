@@ -619,3 +619,43 @@ def test_greedy_eos_leaves_no_logits_on_either_path(E):
         with pytest.raises(RuntimeError):
             eng.stream_sample(s, 0.725, toks.interval_id)
     eng.close()
+
+
+GEMV_BATCH_CHILD = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from tests.hip_emul import emul_engine as E
+from videollm_online_amd.checkpoint import quantize_fp8_per_channel
+K, N, n = 8192, 22 * 16 + 8, 11          # 23 column tiles (the last one half full) = 12 groups, the last with ONE tile, on VLO_GEMV_CUS = 2 blocks:
+g = torch.Generator().manual_seed(8192)  # block 0 walks 6 groups (a batch of 4 + a batch of 2), block 1 likewise
+x = torch.randn(n, K, generator=g).bfloat16()
+W = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16()
+assert E.gemv_plan(K, False) == (8, 16, 2, 1), E.gemv_plan(K, False)        # 8 waves x 16 fragments, KC = 2 chunks, one K slice
+y = E.test_gemv(x, W)
+want = x.double() @ W.double().T
+assert torch.allclose(y.double(), want, rtol=1e-4, atol=1e-4), (y.double() - want).abs().max()
+q, s = quantize_fp8_per_channel(W)
+y8 = E.test_gemv_fp8(x, q, s)
+ref = x.double() @ (q.float().double() * s.double()[:, None]).T
+assert (y8.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()) * (K / 256) ** 0.5 + 1e-5
+torch.save((y, y8), sys.argv[1])
+print("OKGEMV")
+"""
+
+
+def test_gemv_chunk_outer_batches_in_emulation(E, tmp_path):
+    """K = 8192 as ONE K slice (the 70B model's qkv / o / gate-up / lm_head): 8 waves x 16 fragments x KC = 2 chunks.  The batch loop
+    (gemv_body.inc GB = 4: chunk-outer over four groups, the activation fragments of a chunk built once per batch) against an fp64
+    matmul, bf16 and fp8 images, full + partial batches and a one-tile last group — and bit-identical to the group-outer loop
+    (VLO_GEMV_BATCH=0): same MFMAs in the same k order per output."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for batch in ("1", "0"):
+        f = str(tmp_path / f"b{batch}.pt")
+        env = dict(os.environ, VLO_TEST_GEMV_WHOLE_K="1", VLO_GEMV_CUS="2", VLO_GEMV_BATCH=batch)
+        r = subprocess.run([sys.executable, "-c", GEMV_BATCH_CHILD % root, f], env=env, capture_output=True, text=True, timeout=1800)
+        assert r.returncode == 0 and "OKGEMV" in r.stdout, r.stderr[-2000:]
+        outs[batch] = torch.load(f)
+    assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1])

@@ -43,6 +43,7 @@ class Follower(O.LiveInferOracle):
         self.ev = collections.deque(engine_trace)
         self.emb = engine_embeds
         self.stats = collections.Counter()
+        self.flip_margins = []
 
     def input_video_stream(self, video_time):
         frame_idx = int(video_time * self.frame_fps)
@@ -69,6 +70,7 @@ class Follower(O.LiveInferOracle):
         assert margin <= tie, f"{kind} #{self.stats[kind]}: engine {theirs} vs reference {mine}: the engine's token is {margin:.4f} below the reference's top logit (near-tie bound {tie:.4f})"
         self.stats[kind + "_near_tie"] += 1
         self.worst_tie = max(getattr(self, "worst_tie", 0.0), margin)
+        self.flip_margins.append((round(margin, 4), round(abs(top), 2)))      # (reference-logit margin of the engine's token, |top logit|)
 
     def _call_for_streaming(self):                                     # demo/inference.py:54-82, decisions taken from the engine
         while self.frame_embeds_queue:
@@ -192,6 +194,9 @@ def _trace_vs_reference(mode, T, prefetch_frames):
     s = f.stats
     print(f"[liveinfer {mode} {T} frames] KV {kv_end} tokens, {len(trace)} events | sampler decisions {s['sampler']}: identical {s['sampler_same']}, "
           f"near-tie runner-up {s['sampler_near_tie']} | greedy tokens {s['greedy']}: identical {s['greedy_same']}, near-tie runner-up {s['greedy_near_tie']} | largest margin at a flip {getattr(f, 'worst_tie', 0.0):.4f}")
+    hist = collections.Counter(m for m, _ in f.flip_margins)
+    print(f"[liveinfer {mode} {T} frames] margins at the {len(f.flip_margins)} flips (reference-logit distance of the engine's token from the reference's top; count): "
+          + ", ".join(f"{m:g}: {c}" for m, c in sorted(hist.items())) + f" | |top logit| at the flips {min((t for _, t in f.flip_margins), default=0):g} .. {max((t for _, t in f.flip_margins), default=0):g}")
     assert s["sampler"] >= T - 2 and s["sampler_same"] >= 0.93 * s["sampler"]      # regression floors (measured 0.968 - 0.993): every difference above was individually a near-tie
     assert s["greedy"] == 0 or s["greedy_same"] >= 0.93 * s["greedy"]
     li.reset()

@@ -85,7 +85,9 @@ def test_visual_embed_parity(llm, vit, B, how):
     a = (amp.float() - gold).abs().max().item()
     r = (ref.float() - gold).abs().max().item()
     print(f"[{llm}/{vit} B={B} {how}] engine err {e:.4g}  fp16-autocast-emulation err {a:.4g}  cpu-ref(bf16 connector) err {r:.4g}  scale {scale:.3g}")
-    assert e <= 2.0 * max(a, r) + 2 * 2 ** -8 * scale
+    # measured on MI355X (profiles/r4_parity_measurements.txt): e / max(a, r) = 0.86 .. 1.19 over all eleven cases — both yardsticks end in
+    # the same bf16 connector, so there is no additive ulp term (round 3's gate was 2 x + 2 bf16 ulps of the scale)
+    assert e <= 1.5 * max(a, r), (e, a, r)
     # mean error should be at the bf16-output rounding level
     assert (out.float() - gold).abs().mean().item() <= 2.0 * max((amp.float() - gold).abs().mean().item(), 1e-3 * scale)
     eng.close()

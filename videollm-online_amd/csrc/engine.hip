@@ -1053,7 +1053,9 @@ int vlo_test_gemv(const void *x_dev, const void *W_dev, float *y_dev, int n, int
     if (!x_dev || !W_dev || !y_dev || n <= 0 || n > 16 || N <= 0 || (N & 3)) return fail(VLO_E_INVALID, "bad test_gemv arguments");
     hipStream_t st = (hipStream_t)stream;
     GemvPlan plan;
-    if (gemv_plan(K, true, &plan)) return fail(VLO_E_UNSUPPORTED, "no GEMV plan for K");
+    // VLO_TEST_GEMV_WHOLE_K=1 (tests): one K slice per block, the waves walk KC chunks — the plan the step's whole-K launches use
+    const bool whole_k = getenv("VLO_TEST_GEMV_WHOLE_K") && atoi(getenv("VLO_TEST_GEMV_WHOLE_K"));
+    if (gemv_plan(K, !whole_k, &plan)) return fail(VLO_E_UNSUPPORTED, "no GEMV plan for K");
     const int NT = (N + 15) / 16;
     ScratchBufs sc;
     void *Wp = nullptr, *xp = nullptr;
@@ -1081,7 +1083,8 @@ int vlo_test_gemv_fp8(const void *x_dev, const void *Wq_dev, const float *scale_
     if (!x_dev || !Wq_dev || !scale_dev || !y_dev || n <= 0 || n > 16 || N <= 0 || (N & 3)) return fail(VLO_E_INVALID, "bad test_gemv_fp8 arguments");
     hipStream_t st = (hipStream_t)stream;
     GemvPlan plan;
-    if (gemv_plan(K, true, &plan)) return fail(VLO_E_UNSUPPORTED, "no GEMV plan for K");
+    const bool whole_k = getenv("VLO_TEST_GEMV_WHOLE_K") && atoi(getenv("VLO_TEST_GEMV_WHOLE_K"));
+    if (gemv_plan(K, !whole_k, &plan)) return fail(VLO_E_UNSUPPORTED, "no GEMV plan for K");
     if ((plan.KF & 1) || plan.NW != 8 || (K & 63)) return fail(VLO_E_UNSUPPORTED, "fp8 weight image needs an even fragment count per wave for this K");
     const int NT = (N + 15) / 16;
     ScratchBufs sc;

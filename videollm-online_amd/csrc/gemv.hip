@@ -123,7 +123,7 @@ VLO_DEV float gelu_python_bf16(float x) {    // HF GELUActivation(use_gelu_pytho
 VLO_DEV float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 VLO_DEV float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 
-template <int KF, int NW, int XSRC, int EPI, int WQ>
+template <int KF, int NW, int XSRC, int EPI, int WQ, int GB = 1>
 __global__ __launch_bounds__(NW * 64) void gemv16_kernel(GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 red[];      // [2][NW][CTG][64] float4, then scratch
 #define VLO_GEMV_BX blockIdx.x
@@ -186,7 +186,7 @@ static int groups_of(const GemvArgs &a, const GemvPlan &p, int epi) {
 
 int gemv_grid_x(const GemvArgs &a, const GemvPlan &p, int epi) {
     static const int kBPC = env_int("VLO_GEMV_BPC", 1);          // resident blocks per CU aimed at
-    static const int kCUs = 256;
+    static const int kCUs = env_int("VLO_GEMV_CUS", 256);        // (tests shrink the grid so that a block walks many groups)
     const int ngroups = groups_of(a, p, epi);
     int gx = (kCUs * kBPC) / p.ksplit;
     if (gx < 1) gx = 1;
@@ -198,14 +198,28 @@ int gemv_grid_x(const GemvArgs &a, const GemvPlan &p, int epi) {
 template <int KF, int NW>
 static hipError_t launch_variant(const GemvArgs &a, int xsrc, int epi, dim3 grid, size_t lds, hipStream_t st) {
     dim3 block(NW * 64);
+    // K chunks walked sequentially (KC > 1: K = 8192 at 8 waves x 16 fragments) take the chunk-outer batch loop (gemv_body.inc): batches of
+    // 4 groups, 2 for the bf16 norm-on-load kernel (4 would spill: 16 + 16 fragment registers + the normalisation's temporaries).  Measured on the
+    // 70B shapes (MI355X, profiles/r4_gemv_batch_loop.txt): fp8 gate/up 121.5 -> 87.9 us, qkv 26.2 -> 21.1, lm_head 184 -> 171; bf16 gate/up
+    // 161.9 -> 155.4, qkv 36.6 -> 33.6; the bf16 lm_head (15.7 groups per block, the longest steady state) 313.6 -> 324.5: left on the group-outer loop
+    static const int kBatch = env_int("VLO_GEMV_BATCH", 1);
 #define VLO_GO(XS, EP)                                                                            \
     do {                                                                                          \
+        constexpr bool kHasBatch = (KF == 16 && NW == 8);                                         \
+        const bool batch = kHasBatch && kBatch && a.KC > 1 && (EP) != EPI_BF16_GELU_ERF; \
         if (a.wq) {                                                                               \
-            if constexpr ((KF & 1) == 0 && NW == 8)                                               \
+            if constexpr ((KF & 1) == 0 && NW == 8) {                                             \
+                if constexpr (kHasBatch && (EP) != EPI_BF16_GELU_ERF) { \
+                    if (batch) { hipLaunchKernelGGL((gemv16_kernel<KF, NW, XS, EP, 1, 4>), grid, block, lds, st, a); return hipGetLastError(); } \
+                }                                                                                 \
                 hipLaunchKernelGGL((gemv16_kernel<KF, NW, XS, EP, 1>), grid, block, lds, st, a);  \
-            else                                                                                  \
+            } else {                                                                              \
                 return hipErrorInvalidValue;      /* fp8 image: two fragments per 16-byte load */ \
+            }                                                                                     \
         } else {                                                                                  \
+            if constexpr (kHasBatch && (EP) != EPI_BF16_GELU_ERF && (EP) != EPI_BF16) {    \
+                if (batch) { hipLaunchKernelGGL((gemv16_kernel<KF, NW, XS, EP, 0, ((XS) == XSRC_NORM ? 2 : 4)>), grid, block, lds, st, a); return hipGetLastError(); } \
+            }                                                                                     \
             hipLaunchKernelGGL((gemv16_kernel<KF, NW, XS, EP, 0>), grid, block, lds, st, a);      \
         }                                                                                         \
         return hipGetLastError();                                                                 \
