@@ -13,6 +13,7 @@
 // the matrix core adds its 32 products (fp32, sequential here), timing, occupancy or register pressure.
 #pragma once
 #define VLO_HIP_EMUL 1
+#define ENG_SPIN_TICKS 60000000000ll      // csrc/gemv_engine.inc: bounded spins of the loader / consumer waves — OS threads are slow, never time out here
 #include <math.h>
 #include <pthread.h>
 #include <sched.h>
@@ -189,6 +190,7 @@ static inline long long wall_clock64() {      // s_memrealtime: a 100 MHz counte
     return (long long)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10);
 }
 
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
@@ -207,6 +209,8 @@ static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __A
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_s_barrier() emul_raw_barrier()
+// a wave is in lockstep on the hardware (the builtin emits no instruction); here its 64 lanes are OS threads: rendezvous
+#define __builtin_amdgcn_wave_barrier() pthread_barrier_wait(&emul_ctx->waves[threadIdx.x >> 6].bar)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)      /* instruction-scheduling fence: nothing to order on the CPU */
 // OCP e4m3fn pair -> two floats (v_cvt_pk_f32_fp8): bytes 0,1 (sel = false) or 2,3 of src
 static inline float emul_fp8_e4m3(unsigned b) {
