@@ -660,62 +660,3 @@ def test_gemv_chunk_outer_batches_in_emulation(E, tmp_path):
         outs[batch] = torch.load(f)
     assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1])
 
-
-GEMV_ENGINE_CHILD = r"""
-import sys, torch
-sys.path.insert(0, %r)
-from oracle import vlo_oracle as O
-from tests.hip_emul import emul_engine as E
-# raw GEMVs (fp32 partial epilogue): K = 4096 (2 x 16 fragments per consumer), K = 2048 (1 x 16), K = 14336 as four K slices of 2 x 14;
-# 5 column tiles on VLO_GEMV_CUS = 2 blocks: a block walks 3 / 2 tiles (the finishing consumer rotates), rows 11 / 16 / 1
-for K, N, n in ((4096, 80, 11), (2048, 72, 16), (14336, 48, 1)):
-    g = torch.Generator().manual_seed(K)
-    x = torch.randn(n, K, generator=g).bfloat16()
-    W = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16()
-    y = E.test_gemv(x, W)
-    want = x.double() @ W.double().T
-    assert torch.allclose(y.double(), want, rtol=1e-4, atol=1e-4), (K, (y.double() - want).abs().max())
-# the fused forms on a model whose hidden size the engine takes (H = 2048): norm-on-load + SwiGLU (gate/up), residual + row sums
-# of squares (o-proj), bf16 logits (lm_head) — against the oracle, same band as the shipped pipeline's test
-spec = O.LlmSpec(2048, 512, 1, 16, 4, 256, 10000.0, 1e-5, vision_hidden_size=128)
-w = O.init_llm_weights(spec, seed=3)
-toks = O.default_tokens(spec)
-ref, gold = O.LlamaOracle(spec, w, torch.bfloat16), O.LlamaOracle(spec, w, torch.float32)
-eng = E.EmulEngine(spec).load_weights(w, O.rope_inv_freq(spec.head_dim, spec.rope_theta))
-s = eng.new_session()
-rc = gc = None
-gg = torch.Generator().manual_seed(0)
-outs = []
-for i, n in enumerate((11, 1)):
-    x = torch.cat([ref.embed(torch.tensor([toks.interval_id])), torch.randn(n - 1, spec.hidden_size, generator=gg).bfloat16()])[:n]
-    rl, rc = ref.forward(x, rc)
-    gl, gc = gold.forward(x, gc)
-    last, allr = eng.llm_step(s, x)
-    e = (allr.float() - gl).abs().max().item()
-    r = (rl.float() - gl).abs().max().item()
-    assert e <= 1.5 * r + 1e-3 * gl.abs().max().item(), (i, e, r)
-    outs.append(allr)
-eng.close()
-torch.save(outs, sys.argv[1])
-print("OKENG")
-"""
-
-
-def test_gemv_loader_consumer_engine_in_emulation(E, tmp_path):
-    """csrc/gemv_engine.inc — the GEMV as one loader wave (direct-to-LDS fills of a ring of eight 16-KiB slots, counted vmcnt, the
-    emulated loads landing only at the wait that retires them) + four consumer waves meeting through LDS words: raw products for the
-    three (slots per tile, fragments per slot) shapes, and the three fused forms (norm-on-load + SwiGLU, residual + sums of
-    squares, bf16 logits) inside a Llama step at H = 2048, against the oracle; the same step with the engine switched off
-    (VLO_GEMV_ENGINE=0: gemv16_kernel) stays in the same band (the two differ only in the fp32 summation order over K)."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = {}
-    for engine in ("1", "0"):
-        f = str(tmp_path / f"e{engine}.pt")
-        env = dict(os.environ, VLO_GEMV_CUS="2", VLO_GEMV_ENGINE=engine, VLO_EMUL_GLDS="late")
-        r = subprocess.run([sys.executable, "-c", GEMV_ENGINE_CHILD % root, f], env=env, capture_output=True, text=True, timeout=3000)
-        assert r.returncode == 0 and "OKENG" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
-        outs[engine] = torch.load(f)
-    for a, b in zip(outs["1"], outs["0"]):
-        assert (a.float() - b.float()).abs().max().item() <= 2 * 2.0 ** -7 * b.float().abs().max().item()

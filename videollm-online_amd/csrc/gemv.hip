@@ -184,23 +184,9 @@ static int groups_of(const GemvArgs &a, const GemvPlan &p, int epi) {
     return single_tile_groups(a, p, epi) ? a.NT : (a.NT + 1) / 2;
 }
 
-#include "gemv_engine.inc"
-
-// the engine's grid: single tiles, one block per CU and K slice, the same number of tiles per block where possible
-static int gemv_eng_grid_x(const GemvArgs &a, const GemvPlan &p) {
-    static const int kCUs = env_int("VLO_GEMV_CUS", 256);
-    int gx = kCUs / p.ksplit;
-    if (gx < 1) gx = 1;
-    if (gx > a.NT) gx = a.NT;
-    const int per = (a.NT + gx - 1) / gx;
-    return (a.NT + per - 1) / per;
-}
-
 int gemv_grid_x(const GemvArgs &a, const GemvPlan &p, int epi) {
     static const int kBPC = env_int("VLO_GEMV_BPC", 1);          // resident blocks per CU aimed at
     static const int kCUs = env_int("VLO_GEMV_CUS", 256);        // (tests shrink the grid so that a block walks many groups)
-    int h2, pp;
-    if (gemv_eng_eligible(a, p, XSRC_PLAIN, epi, &h2, &pp)) return gemv_eng_grid_x(a, p);      // (norm-on-load launches never ask: no sq_out)
     const int ngroups = groups_of(a, p, epi);
     int gx = (kCUs * kBPC) / p.ksplit;
     if (gx < 1) gx = 1;
@@ -264,17 +250,6 @@ hipError_t gemv_prepare(GemvArgs *a, const GemvPlan &p, int epi, int *grid_x, in
 }
 
 hipError_t gemv_launch(GemvArgs a, const GemvPlan &p, int xsrc, int epi, hipStream_t st) {
-    {   // the loader / consumer engine where it is built (gemv_engine.inc)
-        int h2 = 0, pp = 0;
-        if (gemv_eng_eligible(a, p, xsrc, epi, &h2, &pp)) {
-            if (epi != EPI_PARTIAL_F32 && p.ksplit != 1) return hipErrorInvalidValue;
-            const dim3 grid(gemv_eng_grid_x(a, p), p.ksplit);
-            if (h2 == 2 && pp == 16) return gemv_eng_go<2, 16>(a, xsrc, epi, grid, st);
-            if (h2 == 2 && pp == 14) return gemv_eng_go<2, 14>(a, xsrc, epi, grid, st);
-            if (h2 == 1 && pp == 16) return gemv_eng_go<1, 16>(a, xsrc, epi, grid, st);
-            return hipErrorInvalidValue;
-        }
-    }
     int gx = 0, gy = 0;
     size_t lds = 0;
     const hipError_t pe = gemv_prepare(&a, p, epi, &gx, &gy, &lds);
