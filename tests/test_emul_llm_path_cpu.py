@@ -660,3 +660,31 @@ def test_gemv_chunk_outer_batches_in_emulation(E, tmp_path):
         outs[batch] = torch.load(f)
     assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1])
 
+
+
+def test_prefill_path_gemms_in_emulation(E):
+    """Inputs of >= 256 tokens take the prefill path (csrc/engine.hip::run_prefill): the projections as ping-pong GEMMs over the PACKED
+    weight image (vit_gemm.inc instantiated for bf16 with the Llama epilogues: plain bf16, SwiGLU over the interleaved gate/up tile,
+    bf16 residual read-modify-write), RoPE + KV append as a row kernel, attention per 64-query sub-block.  300 tokens (a full
+    256-row tile + a partial one; the 128-row tile variant) then a frame step and a decode step on the cache the prefill wrote,
+    all rows' logits 3-way against the oracle — with the emulated direct-to-LDS loads landing as late as the hardware may."""
+    spec = O.LlmSpec(256, 256, 2, 2, 1, 256, 10000.0, 1e-5, vision_hidden_size=128)      # hd 128; qkv 512, gate/up 512, vocab 256 columns
+    w = O.init_llm_weights(spec, seed=9)
+    toks = O.default_tokens(spec)
+    ref, gold = O.LlamaOracle(spec, w, torch.bfloat16), O.LlamaOracle(spec, w, torch.float32)
+    os.environ["VLO_EMUL_GLDS"] = "late"
+    try:
+        eng = E.EmulEngine(spec, kv_pool_tokens=1024).load_weights(w, O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+        s = eng.new_session()
+        g = torch.Generator().manual_seed(4)
+        rc = gc = None
+        for i, n in enumerate((300, 11, 1)):
+            x = (torch.randn(n, spec.hidden_size, generator=g) * 0.7).bfloat16()
+            rl, rc = ref.forward(x, rc)
+            gl, gc = gold.forward(x, gc)
+            last, allr = eng.llm_step(s, x)
+            assert eng.session_len(s) == len(rc) and torch.equal(last, allr[-1])
+            _three_way("prefill path", i, allr, rl, gl)
+        eng.close()
+    finally:
+        os.environ.pop("VLO_EMUL_GLDS", None)

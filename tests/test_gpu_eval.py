@@ -70,9 +70,9 @@ def test_session_fork_and_crop():
     scale = full.float().abs().max().item()
 
     def same(got, want, aligned):
-        # a restart on a 16-token boundary that replays whole 16-query sub-chunks through the same kernels is bit-identical;
-        # otherwise chunk boundaries (and with them the fp32 summation order of the attention splits / the projection path:
-        # 64-token block GEMM vs 16-row GEMV) move -> bf16 noise only
+        # a restart that replays the same rows through the SAME kernels with the same attention sub-blocks is bit-identical; otherwise the
+        # projection path (prefill GEMMs for >= 256 tokens, 64-token block GEMM, 16-row GEMV) or the sub-block boundaries (and with
+        # them the fp32 summation order of the attention splits) move -> bf16 noise only
         if aligned:
             return torch.equal(got, want)
         return (got.float() - want.float()).abs().max().item() <= 0.03 * scale
@@ -80,16 +80,24 @@ def test_session_fork_and_crop():
     for keep in (0, 1, 255, 256, 304, 699):
         b = a.fork(keep)
         assert len(b) == keep and len(a) == 700
-        _, tail = eng.llm_step(b, x[keep:keep + 64], want_last=False, want_all=True)
-        assert same(tail, full[keep:keep + 64], keep % 16 == 0), keep
+        _, tail = eng.llm_step(b, x[keep:keep + 64], want_last=False, want_all=True)     # 64 tokens: the block path; `full` came out of the prefill path
+        assert same(tail, full[keep:keep + 64], False), keep
+        # ... and exactly what the SAME continuation gives on a cropped copy of the prefix (fork == crop, bit for bit)
+        c = a.fork(min(700, keep + 100))
+        c.crop(keep)
+        _, tail_c = eng.llm_step(c, x[keep:keep + 64], want_last=False, want_all=True)
+        assert torch.equal(tail, tail_c), keep
         b.close()
+        c.close()
     k5 = a.read_kv(1, 0, 0, 0, 700).clone()
+    a.crop(256)
+    assert len(a) == 256
+    _, again = eng.llm_step(a, x[256:], want_last=False, want_all=True)    # 444 tokens: the prefill path again, the same 64-query sub-blocks
+    assert same(again, full[256:], True)
+    assert torch.equal(a.read_kv(1, 0, 0, 0, 700), k5)
     a.crop(304)
-    assert len(a) == 304
-    _, again = eng.llm_step(a, x[304:], want_last=False, want_all=True)
-    assert same(again[:384], full[304:688], True)                          # whole 64-token blocks
-    assert same(again[384:], full[688:], False)                            # the 12-token tail ran as a 16-row chunk this time
-    assert torch.equal(a.read_kv(1, 0, 0, 0, 688), k5[:688])
+    _, again = eng.llm_step(a, x[304:], want_last=False, want_all=True)    # sub-blocks start at 304 now: other attention splits
+    assert len(a) == 700 and same(again, full[304:], False)
     a.crop(77)                                                             # releases two pages, keeps a partial one
     _, again = eng.llm_step(a, x[77:], want_last=False, want_all=True)
     assert len(a) == 700 and same(again, full[77:], False)

@@ -1,5 +1,6 @@
-"""Teacher-forced prefill timing on the true Llama-3-8B shape: N tokens through vlo_llm_step (64-token block path, or
-16-row chunks with VLO_BLOCK_PATH=0), with and without all-row logits + per-row statistics (the stream_evaluate pass)."""
+"""Teacher-forced prefill timing on the true Llama-3-8B shape: N tokens through vlo_llm_step (prefill path = GEMMs over blocks of up to
+4096 tokens; VLO_PREFILL=0: the 64-token block path; VLO_BLOCK_PATH=0: 16-row chunks), with and without all-row logits + per-row
+statistics (the stream_evaluate pass)."""
 import argparse
 import os
 import sys
@@ -24,10 +25,11 @@ def main():
     H = cfg.hidden_size
     x = (torch.randn(args.tokens, H, device="cuda") * 0.5).bfloat16()
     labels = torch.randint(0, cfg.vocab_size, (args.tokens,), device="cuda")
-    mode = "16-row chunks" if os.environ.get("VLO_BLOCK_PATH") == "0" else "64-token blocks"
+    mode = "16-row chunks" if os.environ.get("VLO_BLOCK_PATH") == "0" else ("64-token blocks" if os.environ.get("VLO_PREFILL") == "0" or args.weight_dtype != "bf16"
+                                                                        else "prefill GEMMs")
     for want_all in (False, True):
         sess = eng.new_session()
-        eng.llm_step(sess, x[:80], want_last=True, want_all=want_all)          # warm-up (allocates the block workspaces)
+        eng.llm_step(sess, x[:min(args.tokens, 600)], want_last=True, want_all=want_all)          # warm-up (allocates the block / prefill workspaces)
         sess.reset()
         torch.cuda.synchronize()
         t0 = time.time()

@@ -93,6 +93,10 @@ struct vlo_session {
     int *page_table = nullptr, *host_pt = nullptr;
     // workspaces of the 64-token block path (allocated on first use): residual stream, normed rows, q, attention out, MLP act
     unsigned short *bh = nullptr, *bx = nullptr, *bq = nullptr, *battn = nullptr, *bact = nullptr;
+    // workspaces of the prefill path (blocks of up to VLO_PREFILL_TOKENS tokens as real GEMMs, prefill.h; allocated on first use):
+    // residual stream, normed rows / attention output (the GEMMs' X operand: 256 spare rows), qkv projection, q after RoPE, MLP act
+    unsigned short *ph = nullptr, *px = nullptr, *pqkv = nullptr, *pq = nullptr, *pact = nullptr;
+    float *ppart_o = nullptr, *ppart_ml = nullptr;   // attention partials of a whole prefill block: VLO_PREFILL_TOKENS / 16 sub-chunk states
 };
 
 int dev_alloc(void **p, size_t bytes);

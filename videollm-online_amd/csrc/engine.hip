@@ -752,6 +752,97 @@ static int run_block(vlo_session *s, const unsigned short *src, int m, bool want
     return VLO_OK;
 }
 
+// ---- prefill path: up to VLO_PREFILL_TOKENS new tokens per weight pass, the projections as MFMA-bound GEMMs (prefill.h) ------------------
+static int ensure_prefill_ws(vlo_session *s) {
+    if (s->pact) return VLO_OK;                 // the LAST buffer allocated below: set only when all of them exist
+    vlo_engine *e = s->e;
+    const size_t H = e->cfg.hidden_size, I = e->I_l, qd = (size_t)e->nh_l * e->head_dim, kvd = (size_t)e->nkv_l * e->head_dim;
+    const size_t R = VLO_PREFILL_TOKENS, RX = R + 256;        // X operands: the GEMM reads whole 256-row tiles
+    struct { unsigned short **p; size_t elems; } want[] = {{&s->ph, R * H}, {&s->px, RX * std::max(H, qd)}, {&s->pqkv, R * (qd + 2 * kvd)},
+                                                            {&s->pq, R * qd}, {&s->pact, RX * I}};
+    HIP_TRY(hipSetDevice(e->device));
+    if (!s->ppart_o) {
+        void *po = nullptr, *pm = nullptr;
+        int rc = dev_alloc(&po, (size_t)(VLO_PREFILL_TOKENS / 16) * e->nh_l * 16 * e->head_dim * 4);
+        if (rc) return rc;
+        s->owned.push_back(po);
+        if ((rc = dev_alloc(&pm, (size_t)(VLO_PREFILL_TOKENS / 16) * e->nh_l * 16 * 2 * 4))) return rc;
+        s->owned.push_back(pm);
+        s->ppart_o = (float *)po; s->ppart_ml = (float *)pm;
+    }
+    for (auto &w : want) {
+        if (*w.p) continue;
+        void *p = nullptr;
+        int rc = dev_alloc(&p, w.elems * 2);
+        if (rc) return rc;
+        s->owned.push_back(p);
+        HIP_TRY(hipMemset(p, 0, w.elems * 2));  // the spare rows are read (and dropped) by the GEMMs: keep them finite
+        *w.p = (unsigned short *)p;
+    }
+    return VLO_OK;
+}
+
+// one block of VLO_PREFILL_MIN <= m <= VLO_PREFILL_TOKENS new tokens.  Per decoder layer: RMSNorm rows -> qkv GEMM -> RoPE + KV append ->
+// attention in one launch (the block path's kernel, grid.z = 16-query sub-chunks: the whole block's keys are already appended) ->
+// o GEMM [residual add] -> RMSNorm rows -> gate/up GEMM [SwiGLU] -> down GEMM [residual add].  Rounding points as run_chunk / run_block
+// (projection outputs, RoPE products and sums, residual sums in bf16; accumulation fp32); only the summation order over K differs.
+static int run_prefill(vlo_session *s, const unsigned short *src, int m, bool want_last, unsigned short *all_logits, hipStream_t st) {
+    vlo_engine *e = s->e;
+    const vlo_config &c = e->cfg;
+    const int H = c.hidden_size, I = c.intermediate_size, hd = e->head_dim, nh = c.num_heads, nkv = c.num_kv_heads, V = c.vocab_size;
+    const int qd = nh * hd, Nqkv = qd + 2 * nkv * hd;
+    int rc;
+    if ((rc = ensure_prefill_ws(s))) return rc;
+    if ((rc = ensure_pages(s, s->len + m, st))) return rc;
+    const KvGeom kv = kv_geom(s);
+    HIP_TRY(copy_rows_launch(src, s->ph, m, H, st));
+    for (int l = 0; l < c.num_layers; ++l) {
+        const LayerWeights &L = e->layers[l];
+        HIP_TRY(add_rmsnorm_launch(s->ph, nullptr, 0, H, (const unsigned short *)L.ln_in, s->px, H, H, c.rms_eps, m, st));
+        HIP_TRY(llm_gemm_launch(s->px, L.qkv.Wp, m, Nqkv, H, s->pqkv, Nqkv, LLM_GEMM_BF16, st));
+        HIP_TRY(rope_kv_append_launch(s->pqkv, m, nh, (const unsigned short *)e->cos_tab, (const unsigned short *)e->sin_tab, kv, l, s->len, s->pq, st));
+        // the whole block's keys are appended: ONE attention launch, grid.z = the block's 16-query sub-chunks (causal mask per sub-chunk,
+        // one split each); the output lands in px (the o-proj's X operand)
+        HIP_TRY(attention_launch(s->pq, kv, l, nh, s->len, m, s->ppart_o, s->ppart_ml, s->px, st, -1, VLO_PREFILL_TOKENS / 16));
+        HIP_TRY(llm_gemm_launch(s->px, L.o.Wp, m, H, qd, s->ph, H, LLM_GEMM_RESID, st));
+        HIP_TRY(add_rmsnorm_launch(s->ph, nullptr, 0, H, (const unsigned short *)L.ln_post, s->px, H, H, c.rms_eps, m, st));
+        HIP_TRY(llm_gemm_launch(s->px, L.gate_up.Wp, m, 2 * I, H, s->pact, I, LLM_GEMM_SWIGLU, st));
+        HIP_TRY(llm_gemm_launch(s->pact, L.down.Wp, m, H, I, s->ph, H, LLM_GEMM_RESID, st));
+    }
+    if (want_last || all_logits) {
+        HIP_TRY(add_rmsnorm_launch(s->ph, nullptr, 0, H, (const unsigned short *)e->norm_w, s->px, H, H, c.rms_eps, m, st));
+        if (all_logits) {                       // every row, straight into the caller's matrix
+            if (V % 256 == 0) {
+                HIP_TRY(llm_gemm_launch(s->px, e->lm_head.Wp, m, V, H, all_logits, V, LLM_GEMM_BF16, st));
+            } else {                            // vocabularies that are not whole 256-column tiles: 16 rows at a time through the GEMV
+                for (int r0 = 0; r0 < m; r0 += 16) {
+                    GemvArgs a = gemv_args(e->lm_head, s->px + (size_t)r0 * H, H, std::min(16, m - r0));
+                    a.out_bf16 = all_logits + (size_t)r0 * V; a.ldo = V;
+                    HIP_TRY(gemv_launch(a, e->lm_head.plan, XSRC_PLAIN, EPI_BF16, st));
+                }
+            }
+            HIP_TRY(hipMemcpyAsync(s->logits, all_logits + (size_t)(m - 1) * V, (size_t)V * 2, hipMemcpyDeviceToDevice, st));
+        } else {                                // only the row that is read
+            GemvArgs a = gemv_args(e->lm_head, s->px + (size_t)(m - 1) * H, H, 1);
+            a.out_bf16 = s->logits; a.ldo = V;
+            HIP_TRY(gemv_launch(a, e->lm_head.plan, XSRC_PLAIN, EPI_BF16, st));
+        }
+        s->last_logits = s->logits;
+        s->has_logits = true;
+    }
+    s->len += m;
+    return VLO_OK;
+}
+
+// shapes the prefill GEMMs take: bf16 image, every projection width a multiple of 256 and every K a multiple of 128
+static bool prefill_ok(const vlo_engine *e) {
+    static const bool on = getenv("VLO_PREFILL") ? atoi(getenv("VLO_PREFILL")) != 0 : true;
+    const vlo_config &c = e->cfg;
+    const int hd = e->head_dim, qd = c.num_heads * hd, Nqkv = qd + 2 * c.num_kv_heads * hd;
+    return on && c.weight_dtype == 0 && e->tp_size == 1 && !(Nqkv & 255) && !(c.hidden_size & 255) && !((2 * c.intermediate_size) & 255) &&
+           !(c.intermediate_size & 127) && !(qd & 127) && (hd == 64 || hd == 128);
+}
+
 int vlo_llm_step(vlo_session *s, const void *embeds_dev, int n, void *last_logits_dev, void *all_logits_dev, void *stream) {
     if (!s || !embeds_dev || n <= 0) return fail(VLO_E_INVALID, "bad llm_step arguments");
     vlo_engine *e = s->e;
@@ -767,6 +858,14 @@ int vlo_llm_step(vlo_session *s, const void *embeds_dev, int n, void *last_logit
         const int left = n - c0;
         const unsigned short *src = (const unsigned short *)embeds_dev + (size_t)c0 * H;
         unsigned short *all = all_logits_dev ? (unsigned short *)all_logits_dev + (size_t)c0 * V : nullptr;
+        if (block_path && left >= VLO_PREFILL_MIN && prefill_ok(e)) {
+            // long inputs: blocks of up to VLO_PREFILL_TOKENS tokens with the projections as GEMMs; what is left below VLO_PREFILL_MIN
+            // goes through the 64-token block path (so a remainder never starts a new kind of weight pass for a handful of tokens)
+            const int m = std::min(VLO_PREFILL_TOKENS, left);
+            if ((rc = run_prefill(s, src, m, c0 + m == n, all, st))) return rc;
+            c0 += m;
+            continue;
+        }
         if (block_path && left > 16) {
             const int m = std::min(VLO_BLOCK_TOKENS, left);
             if ((rc = run_block(s, src, m, c0 + m == n, all, st))) return rc;

@@ -36,12 +36,15 @@ hipError_t add_rmsnorm_launch(unsigned short *h, const float *partial, int kspli
 // chunk attention (n <= 16 queries at positions pos0..pos0+n-1 against keys [0, pos0+n); the block path passes n <= 64
 // = up to four 16-query sub-chunks in one launch)
 // pack_row0 >= 0: `out` is a packed-64 matrix and query i goes to row pack_row0 + i (block path); -1: row-major [n][nh*hd]
+// part_cap: capacity of part_o / part_ml in (16-query sub-chunk x split) partial states of [nh][16][hd] / [nh][16][2] floats: the
+// session's buffers hold VLO_MAX_SPLITS (n <= 64); the prefill path brings VLO_PREFILL_TOKENS / 16 and runs a whole block of new
+// tokens as ONE launch (grid.z = its 16-query sub-chunks, one split each)
 hipError_t attention_launch(const unsigned short *q, KvGeom kv, int layer, int num_heads, int64_t pos0, int n,
-                            float *part_o, float *part_ml, unsigned short *out, hipStream_t st, int pack_row0 = -1);
+                            float *part_o, float *part_ml, unsigned short *out, hipStream_t st, int pack_row0 = -1, int part_cap = VLO_MAX_SPLITS);
 
 // launch geometry of the chunk attention for n new tokens at cache length pos0 (what attention_launch computes first)
 struct AttnGeom { int G, KS, hpw, nhg, nz, chunk, nsplit, nct; float scale; size_t lds_bytes; };
-hipError_t attention_geometry(const KvGeom &kv, int num_heads, int64_t pos0, int n, AttnGeom *g);
+hipError_t attention_geometry(const KvGeom &kv, int num_heads, int64_t pos0, int n, AttnGeom *g, int part_cap = VLO_MAX_SPLITS);
 
 hipError_t embed_gather_launch(const unsigned short *table, const int64_t *ids, int k, int H, int64_t vocab,
                                unsigned short *out, hipStream_t st);

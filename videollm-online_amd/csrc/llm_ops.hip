@@ -315,7 +315,7 @@ static hipError_t attn_combine_launch(const float *part_o, const float *part_ml,
     return hipGetLastError();
 }
 
-hipError_t attention_geometry(const KvGeom &kv, int num_heads, int64_t pos0, int n, AttnGeom *g) {
+hipError_t attention_geometry(const KvGeom &kv, int num_heads, int64_t pos0, int n, AttnGeom *g, int part_cap) {
     const int nkv = kv.num_kv_heads, hd = kv.head_dim, G = num_heads / nkv;
     const int L = (int)(pos0 + n);
     const int hpw = (G % 2 == 0) ? 2 : 1;
@@ -330,7 +330,7 @@ hipError_t attention_geometry(const KvGeom &kv, int num_heads, int64_t pos0, int
     // n > 16 (block path): grid.z sub-chunks of 16 queries share one launch and one split geometry; sub-chunk z sees the
     // keys [0, pos0 + 16 z + n_z), splits beyond that write empty partials
     const int nz = (n + 15) / 16;
-    if (nz > 4) return hipErrorInvalidValue;
+    if (nz > part_cap || nz > 65535) return hipErrorInvalidValue;
     // short steps whose G * n (head, token) columns fit 3 MFMA column tiles take the column-packed kernel: 8 key sub-splits per block
     static const int cols_off = getenv("VLO_ATTN_COLS") ? !atoi(getenv("VLO_ATTN_COLS")) : 0;
     g->nct = 0;
@@ -343,7 +343,9 @@ hipError_t attention_geometry(const KvGeom &kv, int num_heads, int64_t pos0, int
     static const int want_blocks = getenv("VLO_ATTN_BLOCKS") ? atoi(getenv("VLO_ATTN_BLOCKS")) : 256;
     const int want = (want_blocks + nkv * nz - 1) / (nkv * nz);
     if (target > want) target = want;
-    if (target > VLO_MAX_SPLITS / nz) target = VLO_MAX_SPLITS / nz;
+    if (target > VLO_MAX_SPLITS / nz) target = VLO_MAX_SPLITS / nz;      // (the merge kernel holds one split per lane; 0 for nz > 64: one split below)
+    if (target > part_cap / nz) target = part_cap / nz;
+    if (nz > 4) target = 1;          // prefill blocks: the sub-chunks alone fill the chip, and one split keeps a row's result independent of the block's length
     if (target < 1) target = 1;
     int chunk = (L + target - 1) / target;
     chunk = (chunk + 31) & ~31;
@@ -356,9 +358,9 @@ hipError_t attention_geometry(const KvGeom &kv, int num_heads, int64_t pos0, int
 }
 
 hipError_t attention_launch(const unsigned short *q, KvGeom kv, int layer, int num_heads, int64_t pos0, int n,
-                            float *part_o, float *part_ml, unsigned short *out, hipStream_t st, int pack_row0) {
+                            float *part_o, float *part_ml, unsigned short *out, hipStream_t st, int pack_row0, int part_cap) {
     AttnGeom ag;
-    const hipError_t ge = attention_geometry(kv, num_heads, pos0, n, &ag);
+    const hipError_t ge = attention_geometry(kv, num_heads, pos0, n, &ag, part_cap);
     if (ge != hipSuccess) return ge;
     const int nkv = kv.num_kv_heads, hd = kv.head_dim, G = ag.G, hpw = ag.hpw, nhg = ag.nhg, KS = ag.KS, nz = ag.nz, chunk = ag.chunk,
               nsplit = ag.nsplit;

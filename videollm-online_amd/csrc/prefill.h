@@ -13,3 +13,21 @@ int gemm64_plan(int K, Gemm64Plan *p, bool even_kf = false);     // even_kf: the
 // x is a PACKED-64 matrix (llm_ops.h::vlo_pack64_elem); EPI_SWIGLU also writes its output packed-64 (it feeds the down
 // projection).  Uses of GemvArgs: Wp, x, K, NT, N_valid, n_rows (<= 64), out_bf16 (+ ldo), h + ldo, cos/sin/kv/layer/num_heads/pos0.
 hipError_t gemm64_launch(GemvArgs a, const Gemm64Plan &p, int epi, hipStream_t st);
+
+// ---- long inputs (teacher-forced evaluation, first step of a long prompt): blocks of up to VLO_PREFILL_TOKENS tokens ------------------
+// The projections run as real GEMMs (MFMA-bound: hundreds of tokens per weight byte instead of 64): the ViT's ping-pong kernel
+// (vit_gemm.inc: 256 x 256 tiles, direct-to-LDS double buffering, persistent XCD-aware tile walk) instantiated for bf16 operands with
+// the weight operand read from the SAME packed fragment image the GEMV streams (a per-lane source address of the direct-to-LDS load)
+// and the Llama epilogues with the GEMV path's rounding points.  bf16 images only (fp8 engines keep the 64-token block path).
+#define VLO_PREFILL_TOKENS 4096   // rows of the prefill workspace; x must stay readable 256 rows past M (the kernel reads whole tiles)
+#define VLO_PREFILL_MIN 256       // shorter inputs take the 64-token block path
+enum { LLM_GEMM_BF16 = 0, LLM_GEMM_SWIGLU = 1, LLM_GEMM_RESID = 2 };
+// X bf16 [M][K] row-major; Wp = packed image of W [N][K]; N % 256 == 0, K % 128 == 0.
+//   LLM_GEMM_BF16:   out bf16 [M][ldo] = bf16(X W^T)
+//   LLM_GEMM_SWIGLU: Wp = the gate/up image (N = 2 I): out bf16 [M][ldo = I] = bf16(silu(bf16 g) * bf16 u)
+//   LLM_GEMM_RESID:  out = the residual stream bf16 [M][N]: out = bf16(out + bf16(X W^T))
+hipError_t llm_gemm_launch(const unsigned short *X, const void *Wp, int M, int N, int K, unsigned short *out, int ldo, int kind, hipStream_t st);
+// qkv bf16 [M][(nh + 2 nkv) hd] (projection outputs) -> RoPE (HF rounding points) -> q bf16 [M][nh hd], K / V^T appended to the paged pool
+// at positions pos0 .. pos0 + M - 1
+hipError_t rope_kv_append_launch(const unsigned short *qkv, int M, int num_heads, const unsigned short *cos_tab, const unsigned short *sin_tab,
+                                 KvGeom kv, int layer, long long pos0, unsigned short *q_out, hipStream_t st);

@@ -283,3 +283,85 @@ hipError_t gemm64_launch(GemvArgs a, const Gemm64Plan &p, int epi, hipStream_t s
     }
     return hipErrorInvalidValue;
 }
+
+
+// ------------------------------------------------------------------------------------
+// long inputs: the projections as ping-pong GEMMs over the packed weight image (prefill.h)
+// ------------------------------------------------------------------------------------
+#include <algorithm>
+
+#define VLO_GEMM_KERNELS_ONLY
+#include "vit_gemm.inc"
+
+hipError_t llm_gemm_launch(const unsigned short *X, const void *Wp, int M, int N, int K, unsigned short *out, int ldo, int kind, hipStream_t st) {
+    if (!X || !Wp || !out || M <= 0 || (N & 255) || (K & 127) || K < 128) return hipErrorInvalidValue;
+    GemmArgs a{};
+    a.X = (const f16_t *)X; a.W = (const f16_t *)Wp; a.M = M; a.N = N; a.K = K; a.ldx = K; a.ldo = ldo; a.outb = out; a.xpad = 1;
+    const int tx = N / 256;
+    // tile height: 256 rows once such tiles fill the chip, else 128 (twice the tiles, half the work each)
+    static const int force_bm = getenv("VLO_PREFILL_BM") ? atoi(getenv("VLO_PREFILL_BM")) : 0;
+    const int t256 = ((M + 255) / 256) * tx;
+    const int bm = force_bm ? force_bm : (t256 >= 200 ? 256 : 128);
+    // column groups of the 2-D XCD split: the smallest split whose W slice (N / cb columns x K) stays inside an XCD's L2 (vit_gemm.inc)
+    int cb = 1;
+    while (cb < 8 && tx % (cb * 2) == 0 && (size_t)(N / cb) * K * 2 > ((size_t)9 << 18)) cb *= 2;
+    a.cb = cb;
+    const int tiles = ((M + bm - 1) / bm) * tx, grid = std::min(tiles, vit_num_cus());
+#define VLO_LLM_GO(EP_)                                                                                         \
+    do {                                                                                                        \
+        if (bm == 256) hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP_>), dim3(grid), dim3(512), 0, st, a);     \
+        else hipLaunchKernelGGL((vit_gemm_pp_kernel<128, EP_>), dim3(grid), dim3(512), 0, st, a);               \
+        return hipGetLastError();                                                                               \
+    } while (0)
+    if (kind == LLM_GEMM_BF16) VLO_LLM_GO(EP_LLM_BF16);
+    if (kind == LLM_GEMM_SWIGLU) VLO_LLM_GO(EP_LLM_SWIGLU);
+    if (kind == LLM_GEMM_RESID) VLO_LLM_GO(EP_LLM_RESID);
+#undef VLO_LLM_GO
+    return hipErrorInvalidValue;
+}
+
+// one thread per (token, head, 4 rotary columns): the GEMV path's EPI_ROPE on a [M][(nh + 2 nkv) hd] matrix
+__global__ __launch_bounds__(256) void rope_kv_append_kernel(const bf16_t *__restrict__ qkv, int M, int nh, const bf16_t *__restrict__ cos_tab,
+                                                             const bf16_t *__restrict__ sin_tab, KvGeom kv, int layer, long long pos0,
+                                                             bf16_t *__restrict__ q_out) {
+    const int hd = kv.head_dim, half = hd >> 1, nkv = kv.num_kv_heads, heads = nh + 2 * nkv, per_head = half >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)M * heads * per_head) return;
+    const int i = (int)(idx % per_head) * 4, head = (int)((idx / per_head) % heads), m = (int)(idx / ((long long)per_head * heads));
+    const bf16_t *src = qkv + (size_t)m * heads * hd + (size_t)head * hd;
+    const ushort4 a4 = *reinterpret_cast<const ushort4 *>(src + i), b4 = *reinterpret_cast<const ushort4 *>(src + half + i);
+    const bf16_t va[4] = {a4.x, a4.y, a4.z, a4.w}, vb[4] = {b4.x, b4.y, b4.z, b4.w};
+    const long long pos = pos0 + m;
+    const int page = kv.page_table[pos / VLO_PAGE_TOKENS], tok = (int)(pos % VLO_PAGE_TOKENS);
+    if (head < nh + nkv) {
+        bf16_t *dst = (head < nh) ? q_out + (size_t)m * nh * hd + (size_t)head * hd
+                                  : kv.k_pool + (size_t)layer * kv.layer_stride + (size_t)page * kv.page_elems + ((size_t)(head - nh) * VLO_PAGE_TOKENS + tok) * hd;
+        const ushort4 c4 = *reinterpret_cast<const ushort4 *>(cos_tab + pos * half + i), s4 = *reinterpret_cast<const ushort4 *>(sin_tab + pos * half + i);
+        const bf16_t cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+        bf16_t lo[4], hi[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x1 = bf2f(va[r]), x2 = bf2f(vb[r]), c = bf2f(cc[r]), sn = bf2f(ss[r]);
+            lo[r] = f2bf(rbf(x1 * c) + rbf(-x2 * sn));            // q*cos + rotate_half(q)*sin, each product and the sum rounded to bf16 (HF :157-158)
+            hi[r] = f2bf(rbf(x2 * c) + rbf(x1 * sn));
+        }
+        *reinterpret_cast<ushort4 *>(dst + i) = *reinterpret_cast<const ushort4 *>(lo);
+        *reinterpret_cast<ushort4 *>(dst + half + i) = *reinterpret_cast<const ushort4 *>(hi);
+    } else {
+        bf16_t *dst = kv.vt_pool + (size_t)layer * kv.layer_stride + (size_t)page * kv.page_elems + ((size_t)(head - nh - nkv) * hd) * VLO_PAGE_TOKENS + tok;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dst[(size_t)(i + r) * VLO_PAGE_TOKENS] = va[r];
+            dst[(size_t)(half + i + r) * VLO_PAGE_TOKENS] = vb[r];
+        }
+    }
+}
+
+hipError_t rope_kv_append_launch(const unsigned short *qkv, int M, int num_heads, const unsigned short *cos_tab, const unsigned short *sin_tab,
+                                 KvGeom kv, int layer, long long pos0, unsigned short *q_out, hipStream_t st) {
+    if (M <= 0 || (kv.head_dim & 7)) return hipErrorInvalidValue;
+    const long long total = (long long)M * (num_heads + 2 * kv.num_kv_heads) * (kv.head_dim >> 3);
+    hipLaunchKernelGGL(rope_kv_append_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, qkv, M, num_heads, cos_tab, sin_tab, kv, layer,
+                       pos0, q_out);
+    return hipGetLastError();
+}
