@@ -662,13 +662,18 @@ def test_gemv_chunk_outer_batches_in_emulation(E, tmp_path):
 
 
 
-def test_prefill_path_gemms_in_emulation(E):
+@pytest.mark.parametrize("shape", ["hd128-g2", "hd64-g2", "hd128-g4"] if FULL else ["hd128-g2", "hd64-g2"])
+def test_prefill_path_gemms_in_emulation(E, shape):
     """Inputs of >= 256 tokens take the prefill path (csrc/engine.hip::run_prefill): the projections as ping-pong GEMMs over the PACKED
     weight image (vit_gemm.inc instantiated for bf16 with the Llama epilogues: plain bf16, SwiGLU over the interleaved gate/up tile,
-    bf16 residual read-modify-write), RoPE + KV append as a row kernel, attention per 64-query sub-block.  300 tokens (a full
+    bf16 residual read-modify-write), RoPE + KV append as a row kernel, flash-style attention over LDS-staged key tiles.  300 tokens (a full
     256-row tile + a partial one; the 128-row tile variant) then a frame step and a decode step on the cache the prefill wrote,
     all rows' logits 3-way against the oracle — with the emulated direct-to-LDS loads landing as late as the hardware may."""
-    spec = O.LlmSpec(256, 256, 2, 2, 1, 256, 10000.0, 1e-5, vision_hidden_size=128)      # hd 128; qkv 512, gate/up 512, vocab 256 columns
+    # (hidden, MLP, layers, heads, kv heads, vocab): every projection width a multiple of 256; the flash-style prefill attention
+    # (llm_ops.hip::attn_prefill_kernel) for head dim 128 / 64 and GQA groups of 2 / 4
+    spec = {"hd128-g2": O.LlmSpec(256, 256, 2, 2, 1, 256, 10000.0, 1e-5, vision_hidden_size=128),
+            "hd64-g2": O.LlmSpec(256, 256, 1, 4, 2, 256, 10000.0, 1e-5, vision_hidden_size=128),
+            "hd128-g4": O.LlmSpec(512, 256, 1, 4, 1, 256, 10000.0, 1e-5, vision_hidden_size=128)}[shape]
     w = O.init_llm_weights(spec, seed=9)
     toks = O.default_tokens(spec)
     ref, gold = O.LlamaOracle(spec, w, torch.bfloat16), O.LlamaOracle(spec, w, torch.float32)

@@ -803,7 +803,10 @@ static int run_prefill(vlo_session *s, const unsigned short *src, int m, bool wa
         HIP_TRY(rope_kv_append_launch(s->pqkv, m, nh, (const unsigned short *)e->cos_tab, (const unsigned short *)e->sin_tab, kv, l, s->len, s->pq, st));
         // the whole block's keys are appended: ONE attention launch, grid.z = the block's 16-query sub-chunks (causal mask per sub-chunk,
         // one split each); the output lands in px (the o-proj's X operand)
-        HIP_TRY(attention_launch(s->pq, kv, l, nh, s->len, m, s->ppart_o, s->ppart_ml, s->px, st, -1, VLO_PREFILL_TOKENS / 16));
+        static const bool flash = getenv("VLO_PREFILL_FLASH") ? atoi(getenv("VLO_PREFILL_FLASH")) != 0 : true;
+        hipError_t ae = flash ? attention_prefill_launch(s->pq, kv, l, nh, s->len, m, s->px, st) : hipErrorNotSupported;
+        if (ae == hipErrorNotSupported) ae = attention_launch(s->pq, kv, l, nh, s->len, m, s->ppart_o, s->ppart_ml, s->px, st, -1, VLO_PREFILL_TOKENS / 16);
+        HIP_TRY(ae);
         HIP_TRY(llm_gemm_launch(s->px, L.o.Wp, m, H, qd, s->ph, H, LLM_GEMM_RESID, st));
         HIP_TRY(add_rmsnorm_launch(s->ph, nullptr, 0, H, (const unsigned short *)L.ln_post, s->px, H, H, c.rms_eps, m, st));
         HIP_TRY(llm_gemm_launch(s->px, L.gate_up.Wp, m, 2 * I, H, s->pact, I, LLM_GEMM_SWIGLU, st));

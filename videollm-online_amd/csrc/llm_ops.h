@@ -42,6 +42,11 @@ hipError_t add_rmsnorm_launch(unsigned short *h, const float *partial, int kspli
 hipError_t attention_launch(const unsigned short *q, KvGeom kv, int layer, int num_heads, int64_t pos0, int n,
                             float *part_o, float *part_ml, unsigned short *out, hipStream_t st, int pack_row0 = -1, int part_cap = VLO_MAX_SPLITS);
 
+// flash-style attention for a block of n new tokens at positions pos0 .. pos0 + n - 1 whose keys are already appended (prefill path):
+// out bf16 [n][nh * hd] row-major.  hipErrorNotSupported for GQA shapes it is not instantiated for (the caller uses attention_launch).
+hipError_t attention_prefill_launch(const unsigned short *q, KvGeom kv, int layer, int num_heads, int64_t pos0, int n, unsigned short *out,
+                                    hipStream_t st);
+
 // launch geometry of the chunk attention for n new tokens at cache length pos0 (what attention_launch computes first)
 struct AttnGeom { int G, KS, hpw, nhg, nz, chunk, nsplit, nct; float scale; size_t lds_bytes; };
 hipError_t attention_geometry(const KvGeom &kv, int num_heads, int64_t pos0, int n, AttnGeom *g, int part_cap = VLO_MAX_SPLITS);

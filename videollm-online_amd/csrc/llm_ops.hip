@@ -315,6 +315,175 @@ static hipError_t attn_combine_launch(const float *part_o, const float *part_ml,
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------
+// Prefill attention (blocks of hundreds to thousands of new tokens, engine.hip::run_prefill): flash-style.  One workgroup = one kv head x
+// QB = 256 / G consecutive queries: its 256 (query, head) columns are 16 column tiles, two per wave (8 waves), and ALL waves walk the SAME
+// 32-key tiles, which are staged once per workgroup in LDS (K 32 x HD, V^T HD x 32: 16 KiB at HD = 128, double-buffered) by direct-to-LDS
+// loads — a K / V^T byte leaves L2 once per 256 columns instead of once per 16-query sub-chunk (the decode-shaped kernel above re-reads
+// the whole prefix for every sub-chunk: 232 TFLOP/s at 13 k tokens).  No split-KV, no merge kernel: a workgroup sees every key its
+// queries may attend to and writes normalised bf16 rows.
+//   * LDS layout = the MFMA A-operand fragments themselves: piece (1 KiB) = [16-byte chunk c][row r] so lane l = 16 c + r reads slot l
+//     (conflict-free ds_read_b128); the direct-to-LDS destination is lane-linear, so the gather happens on the per-lane SOURCE address;
+//   * keys are permuted inside a 32-key tile as in attn_cols_kernel (row r of key tile t = key (r >> 2) * 8 + (r & 3) + 4 t): the lane
+//     that holds S rows 4 qd .. 4 qd + 3 of both tiles owns 8 CONSECUTIVE keys, P^T is a B operand as produced and a V^T fragment is one chunk;
+//   * the loads are issued in inline asm (invisible to hipcc, which would drain them before every LDS read) and retired by one
+//     s_waitcnt vmcnt(0) + barrier per tile: tile i + 1 lands while tile i is multiplied.
+// grid = (ceil(n / QB), nkv); 512 threads.  Rounding points as the other attention kernels (P -> bf16 before P.V, bf16 output).
+// ------------------------------------------------------------------------------------
+VLO_DEV void attn_glds16(const void *gsrc, void *lds_dst) {        // lds_dst: wave-uniform; lane l lands at lds_dst + 16 l
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
+template <int HD, int G>
+__global__ __launch_bounds__(512) void attn_prefill_kernel(const bf16_t *__restrict__ q, KvGeom kv, int layer, int nh, int64_t pos0, int n, float scale,
+                                                           bf16_t *__restrict__ out) {
+    constexpr int NKK = HD / 32, NDT = HD / 16, QB = 256 / G, NCT = 2;
+    constexpr int PK = 2 * NKK, PV = NDT, PIECES = PK + PV;             // 1-KiB pieces of one key tile: K (t, kk) then V^T (dt)
+    static_assert(PIECES % 8 == 0, "eight waves share the staging");
+    constexpr int PPW = PIECES / 8;
+    __shared__ __attribute__((aligned(16))) char tile[2][PIECES * 1024];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 15, qd = lane >> 4;
+    const int kvh = blockIdx.y;
+    const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;                  // the longest key ranges start first
+    const int q0 = qb * QB;
+    // this wave's two column tiles: column cc = 32 w + 16 ct + col -> query q0 + cc / G, head kvh G + cc % G
+    int qi[NCT], hh[NCT], qpos[NCT];
+    frag_ab qf[NCT][NKK];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const int cc = w * 32 + ct * 16 + col;
+        qi[ct] = q0 + cc / G;
+        hh[ct] = kvh * G + cc % G;
+        qpos[ct] = (int)pos0 + min(qi[ct], n - 1);
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            frag_ab z = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (qi[ct] < n) z = *reinterpret_cast<const frag_ab *>(q + (size_t)qi[ct] * nh * HD + (size_t)hh[ct] * HD + kk * 32 + qd * 8);
+            qf[ct][kk] = z;
+        }
+    }
+    f32x4 O[NCT][NDT];
+    float mrun[NCT], lrun[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        mrun[ct] = -INFINITY;
+        lrun[ct] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) O[ct][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bf16_t *kbase = kv.k_pool + (size_t)layer * kv.layer_stride;
+    const bf16_t *vbase = kv.vt_pool + (size_t)layer * kv.layer_stride;
+    // keys this workgroup needs: [0, pos0 + last query of the block]
+    const int L = (int)pos0 + min(q0 + QB, n);
+    const int ntiles = (L + 31) >> 5;
+    // stage key tile kt into buffer b: this wave's PPW pieces.  Piece p < PK: K (t = p / NKK, kk = p % NKK): lane (c = qd, r = col) fetches
+    // bytes [(4 kk + c) 16, + 16) of key row (r >> 2) * 8 + (r & 3) + 4 t; piece PK + dt: V^T rows 16 dt + r, keys 8 c .. 8 c + 7.
+    auto stage = [&](int kt, int b) {
+        const int kt0 = kt * 32;
+        const int page = kv.page_table[kt0 / VLO_PAGE_TOKENS], tok0 = kt0 % VLO_PAGE_TOKENS;     // a 32-key tile never straddles a 256-token page
+        const bf16_t *kp = kbase + (size_t)page * kv.page_elems + ((size_t)kvh * VLO_PAGE_TOKENS + tok0) * HD;
+        const bf16_t *vp = vbase + (size_t)page * kv.page_elems + ((size_t)kvh * HD) * VLO_PAGE_TOKENS + tok0;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int p = w * PPW + i;                                      // wave-uniform
+            const bf16_t *src;
+            if (p < PK) {
+                const int t = p / NKK, kk = p - t * NKK;
+                src = kp + (size_t)((col >> 2) * 8 + (col & 3) + 4 * t) * HD + (kk * 4 + qd) * 8;
+            } else {
+                src = vp + (size_t)((p - PK) * 16 + col) * VLO_PAGE_TOKENS + qd * 8;
+            }
+            attn_glds16(src, &tile[b][p * 1024]);
+        }
+    };
+    stage(0, 0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int b = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // this wave's pieces of tile kt have landed ...
+        __syncthreads();                                                    // ... and everybody's; everybody is also done reading buffer b ^ 1
+        if (kt + 1 < ntiles) stage(kt + 1, b ^ 1);
+        const frag_ab *fr = reinterpret_cast<const frag_ab *>(&tile[b][0]) + lane;
+        const int kb = kt * 32 + qd * 8;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                s0 = mfma_bf16(fr[(0 * NKK + kk) * 64], qf[ct][kk], s0);
+                s1 = mfma_bf16(fr[(1 * NKK + kk) * 64], qf[ct][kk], s1);
+            }
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = (kb + r <= qpos[ct]) ? s0[r] * scale : -INFINITY;
+                v[4 + r] = (kb + 4 + r <= qpos[ct]) ? s1[r] * scale : -INFINITY;
+            }
+            float tmax = v[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) tmax = fmaxf(tmax, v[j]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(mrun[ct], tmax);
+            const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __expf(mrun[ct] - m_safe);
+            mrun[ct] = m_new;
+            float psum = 0.f;
+            float pr[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                pr[j] = __expf(v[j] - m_safe);
+                psum += pr[j];
+            }
+            const frag_ab pb = __builtin_bit_cast(frag_ab, make_uint4(pack2bf(pr[0], pr[1]), pack2bf(pr[2], pr[3]), pack2bf(pr[4], pr[5]), pack2bf(pr[6], pr[7])));
+            lrun[ct] = lrun[ct] * alpha + psum;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                f32x4 o = O[ct][dt];
+                o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
+                O[ct][dt] = mfma_bf16(fr[(PK + dt) * 64], pb, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        float l = lrun[ct];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (qi[ct] >= n) continue;
+        bf16_t *orow = out + (size_t)qi[ct] * nh * HD + (size_t)hh[ct] * HD;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            const f32x4 o = O[ct][dt];
+            bf16_t o4[4] = {f2bf(o[0] / l), f2bf(o[1] / l), f2bf(o[2] / l), f2bf(o[3] / l)};
+            *reinterpret_cast<ushort4 *>(orow + dt * 16 + qd * 4) = *reinterpret_cast<const ushort4 *>(o4);
+        }
+    }
+}
+
+hipError_t attention_prefill_launch(const unsigned short *q, KvGeom kv, int layer, int num_heads, int64_t pos0, int n, unsigned short *out, hipStream_t st) {
+    const int nkv = kv.num_kv_heads, hd = kv.head_dim, G = num_heads / nkv;
+    if (n <= 0 || nkv * G != num_heads) return hipErrorInvalidValue;
+    const float scale = 1.0f / sqrtf((float)hd);
+#define VLO_ATTN_PF(HD_, G_)                                                                                                          \
+    do {                                                                                                                              \
+        constexpr int QB_ = 256 / G_;                                                                                                 \
+        hipLaunchKernelGGL((attn_prefill_kernel<HD_, G_>), dim3((n + QB_ - 1) / QB_, nkv), dim3(512), 0, st, q, kv, layer, num_heads, pos0, n, scale, out); \
+        return hipGetLastError();                                                                                                     \
+    } while (0)
+    if (hd == 128 && G == 4) VLO_ATTN_PF(128, 4);
+    if (hd == 128 && G == 8) VLO_ATTN_PF(128, 8);
+    if (hd == 128 && G == 2) VLO_ATTN_PF(128, 2);
+    if (hd == 128 && G == 1) VLO_ATTN_PF(128, 1);
+    if (hd == 64 && G == 8) VLO_ATTN_PF(64, 8);
+    if (hd == 64 && G == 4) VLO_ATTN_PF(64, 4);
+    if (hd == 64 && G == 2) VLO_ATTN_PF(64, 2);
+#undef VLO_ATTN_PF
+    return hipErrorNotSupported;                 // the caller falls back to attention_launch
+}
+
 hipError_t attention_geometry(const KvGeom &kv, int num_heads, int64_t pos0, int n, AttnGeom *g, int part_cap) {
     const int nkv = kv.num_kv_heads, hd = kv.head_dim, G = num_heads / nkv;
     const int L = (int)(pos0 + n);
