@@ -556,6 +556,9 @@ def main():
                              "note": ("SigLIP-L/16-384 + connector, 384.4 GFLOP/frame (SURVEY.md §8d), fp16 MFMA, measured alone" if args.vit == "siglip-l16-384"
                                       else f"{args.vit} + connector, {vit_gflop:.1f} GFLOP/frame (encoder + patch embed + head K/V + connector), fp16 MFMA, measured alone")},
             **({"full_stream": full_stream} if full_stream else {}),
+            **({"first_frame_ms": {"value": round(pre[1][0] * 1e3, 3),
+                                   "note": "frame 0 of the stream, host wall time: its one-frame encode, the first Llama step (start prompt + 10 frame tokens "
+                                           "through the 64-token block path), the t = 0 query and its 16-token response"}} if pre is not None and pre[1] else {}),
             **({"live_feed": live_feed} if live_feed else {}),
             "stream_hbm_roofline": {"algorithmic_llm_bytes": alg_bytes, "frac_of_hbm_peak": round(alg_bytes / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
             "roofline": {"bound": "hbm", "kernel": "gemv16_kernel<KF,EPI_SWIGLU> (gate/up projection + SwiGLU)" + (", fp8 weight image" if args.weight_dtype == "fp8" else ""),

@@ -231,6 +231,10 @@ int  vlo_tp_session_create(vlo_tp_group *g, int64_t max_tokens_hint, vlo_tp_sess
 int  vlo_tp_session_reset(vlo_tp_session *t);
 int64_t vlo_tp_session_len(const vlo_tp_session *t);
 void vlo_tp_session_destroy(vlo_tp_session *t);
+/* trim_past_key_values(past, 0, n) (models/modeling_live.py:170-171) for a tensor-parallel KV handle: every local rank's shard is
+ * forked / cropped alike (vlo_session_fork / vlo_session_crop per shard); one process per GPU: every rank makes the same call */
+int  vlo_tp_session_fork(vlo_tp_session *src, int64_t n_tokens, vlo_tp_session **out, void *stream);
+int  vlo_tp_session_crop(vlo_tp_session *t, int64_t n_tokens);
 int  vlo_tp_llm_step(vlo_tp_session *t, const void *embeds_dev, int n, void *last_logits_dev, void *all_logits_dev, void *stream);
 int  vlo_tp_stream_sample(vlo_tp_session *t, float threshold, int interval_id, int64_t *tok_dev, float *p_interval_dev, void *stream);
 int  vlo_tp_greedy_generate(vlo_tp_session *t, const void *embeds_dev, int m, int eos_token_id, int64_t *out_ids_dev, int max_new,

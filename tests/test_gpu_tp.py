@@ -81,3 +81,45 @@ def test_rccl_binding_one_rank_roundtrip():
     unique id -> ncclCommInitRank -> fp32 sum all-reduce -> byte all-gather, data checked in the library."""
     from videollm_online_amd import _C
     _C.check(_C.lib().vlo_tp_selftest(0))
+
+
+def test_tp_session_fork_crop_and_stream_evaluate(golden_dir):
+    """`trim_past_key_values` under tensor parallelism (vlo_tp_session_fork / _crop: every rank's KV shard forked / cropped alike) and,
+    on top of it, LiveModel.stream_evaluate over a TpGroup (T = 2 logical ranks): a fork continues exactly like a cropped copy, and
+    the evaluation metrics equal the reference class's fixture (tests/golden/eval_toy128.npz) as they do at TP = 1."""
+    import os
+
+    import numpy as np
+    from videollm_online_amd.modeling_live import LiveModel
+    spec = O.LLM_SPECS["toy128"]
+    w = O.init_llm_weights(spec, seed=3)
+    grp = _group(spec, w, 2)
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(150, spec.hidden_size, generator=g) * 0.05).bfloat16().cuda()
+    a = grp.new_session()
+    _, full = grp.llm_step(a, x, want_last=False, want_all=True)
+    for keep in (0, 17, 64, 149):
+        b = a.fork(keep)
+        assert len(b) == keep and len(a) == 150
+        _, tail = grp.llm_step(b, x[keep:keep + 20], want_last=False, want_all=True)
+        c = a.fork(min(150, keep + 40))
+        c.crop(keep)
+        _, tail_c = grp.llm_step(c, x[keep:keep + 20], want_last=False, want_all=True)
+        assert torch.equal(tail, tail_c), keep                                        # fork == crop, bit for bit
+        assert (tail.float() - full[keep:keep + tail.shape[0]].float()).abs().max().item() <= 0.03 * full.float().abs().max().item()
+        b.close()
+        c.close()
+    with pytest.raises(RuntimeError):
+        a.fork(151)
+    a.close()
+    grp.close()
+    gold = np.load(os.path.join(golden_dir, "eval_toy128.npz"))
+    for c in range(int(gold["n_cases"])):
+        w2, toks, ids, labels, feats, thr = O.eval_case_from_golden(gold, c, spec)
+        grp = _group(spec, w2, 2)
+        model = LiveModel(grp, eos_token_id=toks.eos_token_id, frame_token_interval_id=toks.interval_id)
+        out = model.stream_evaluate(ids[None].cuda(), labels[None].cuda(), feats.cuda(), frame_token_interval_threshold=thr).cpu().numpy()
+        ref_bf16, fp32 = gold[f"c{c}_bf16"], gold[f"c{c}_fp32"]
+        np.testing.assert_allclose(out[1:], ref_bf16[1:], rtol=0, atol=1e-6, err_msg=f"case {c}")
+        assert abs(out[0] - fp32[0]) <= 1.5 * abs(ref_bf16[0] - fp32[0]) + 0.01 * fp32[0], (c, out[0], ref_bf16[0], fp32[0])
+        grp.close()

@@ -39,6 +39,7 @@ EXPORTS = [
     "vlo_joint_embed", "vlo_logit_rows", "vlo_session_fork", "vlo_session_crop", "vlo_tp_selftest", "vlo_debug_gemm64_plan", "vlo_debug_pack64_elem",
     "vlo_step_input", "vlo_build_id", "vlo_frame_ingest", "vlo_frame_ingest_geometry", "vlo_test_gemv_fp8", "vlo_tp_comm_info", "vlo_tp_allgather",
     "vlo_tp_p2p_export", "vlo_tp_p2p_enable", "vlo_tp_p2p_status", "vlo_debug_p2p_layout", "vlo_tp_bench_exchange",
+    "vlo_tp_session_fork", "vlo_tp_session_crop",
 ]
 
 
@@ -120,6 +121,8 @@ def bind(L):
     L.vlo_tp_session_len.restype = i64
     L.vlo_tp_session_destroy.argtypes = [vp]
     L.vlo_tp_session_destroy.restype = None
+    L.vlo_tp_session_fork.argtypes = [vp, i64, C.POINTER(vp), vp]
+    L.vlo_tp_session_crop.argtypes = [vp, i64]
     L.vlo_tp_llm_step.argtypes = [vp, vp, i32, vp, vp, vp]
     L.vlo_tp_stream_sample.argtypes = [vp, C.c_float, i32, vp, vp, vp]
     L.vlo_tp_greedy_generate.argtypes = [vp, vp, i32, i32, vp, i32, i32, C.POINTER(i32), vp]

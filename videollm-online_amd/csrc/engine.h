@@ -108,4 +108,6 @@ KvGeom kv_geom(const vlo_session *s);
 void ingest_create(vlo_engine *e);
 void ingest_destroy(vlo_engine *e);
 int connector_run(vlo_engine *e, int slot, const void *feats_dev, int rows, void *out_dev, hipStream_t st);   // slot 0 / 1: scratch set
+int session_fork_shard(vlo_session *src, int64_t n_tokens, vlo_session **out, void *stream);   // one KV shard (engine.hip)
+int session_crop_shard(vlo_session *s, int64_t n_tokens);
 int vlo_fail(int code, const std::string &msg);   // sets the thread-local error string, returns code

@@ -1088,10 +1088,10 @@ int vlo_logit_rows(vlo_engine *e, const void *logits_dev, int n, const int64_t *
     return VLO_OK;
 }
 
-int vlo_session_fork(vlo_session *src, int64_t n_tokens, vlo_session **out, void *stream) {
+// fork / crop of ONE KV shard (a whole TP = 1 session, or one rank's shard of a tensor-parallel session: tp.hip)
+int session_fork_shard(vlo_session *src, int64_t n_tokens, vlo_session **out, void *stream) {
     if (!src || !out || n_tokens < 0 || n_tokens > src->len) return fail(VLO_E_INVALID, "bad session_fork arguments");
     vlo_engine *e = src->e;
-    if (e->tp_size > 1) return fail(VLO_E_STATE, "tensor-parallel sessions cannot be forked");
     hipStream_t st = (hipStream_t)stream;
     vlo_session *d = nullptr;
     int rc = vlo_session_create(e, n_tokens, &d);
@@ -1111,10 +1111,14 @@ int vlo_session_fork(vlo_session *src, int64_t n_tokens, vlo_session **out, void
     return VLO_OK;
 }
 
-int vlo_session_crop(vlo_session *s, int64_t n_tokens) {
+int vlo_session_fork(vlo_session *src, int64_t n_tokens, vlo_session **out, void *stream) {
+    if (src && src->e->tp_size > 1) return fail(VLO_E_STATE, "a tensor-parallel shard is forked through vlo_tp_session_fork");
+    return session_fork_shard(src, n_tokens, out, stream);
+}
+
+int session_crop_shard(vlo_session *s, int64_t n_tokens) {
     if (!s || n_tokens < 0 || n_tokens > s->len) return fail(VLO_E_INVALID, "bad session_crop arguments");
     vlo_engine *e = s->e;
-    if (e->tp_size > 1) return fail(VLO_E_STATE, "tensor-parallel sessions cannot be cropped");
     const size_t keep = (size_t)((n_tokens + VLO_PAGE_TOKENS - 1) / VLO_PAGE_TOKENS);
     if (keep < s->pages.size()) {
         // pages go back to the pool (and page-table slots will be rewritten): let queued kernels that still read them drain
@@ -1129,6 +1133,11 @@ int vlo_session_crop(vlo_session *s, int64_t n_tokens) {
     s->len = n_tokens;
     s->has_logits = false;
     return VLO_OK;
+}
+
+int vlo_session_crop(vlo_session *s, int64_t n_tokens) {
+    if (s && s->e->tp_size > 1) return fail(VLO_E_STATE, "a tensor-parallel shard is cropped through vlo_tp_session_crop");
+    return session_crop_shard(s, n_tokens);
 }
 
 // device scratch of the test / micro-benchmark entry points: freed on every return path

@@ -289,6 +289,34 @@ int vlo_tp_session_reset(vlo_tp_session *t) {
 }
 int64_t vlo_tp_session_len(const vlo_tp_session *t) { return t && !t->ss.empty() ? t->ss[0]->len : -1; }
 
+// trim_past_key_values(past, 0, n) (models/modeling_live.py:170-171) under tensor parallelism: every local rank's KV shard is forked /
+// cropped the same way (each shard holds its own kv heads of the same positions; no exchange is involved).  One process per GPU:
+// every rank makes the same call, as for every other vlo_tp_* entry point.
+int vlo_tp_session_fork(vlo_tp_session *src, int64_t n_tokens, vlo_tp_session **out, void *stream) {
+    if (!src || !out || n_tokens < 0 || n_tokens > vlo_tp_session_len(src)) return vlo_fail(VLO_E_INVALID, "bad tp_session_fork arguments");
+    vlo_tp_session *t = new vlo_tp_session();
+    t->g = src->g;
+    for (vlo_session *s : src->ss) {
+        vlo_session *d = nullptr;
+        TP_TRY(hipSetDevice(s->e->device));
+        const int rc = session_fork_shard(s, n_tokens, &d, stream);
+        if (rc) { vlo_tp_session_destroy(t); return rc; }
+        t->ss.push_back(d);
+    }
+    vlo_engine *e0 = src->g->eng[0];
+    if (dev_alloc((void **)&t->gather_tmp, (size_t)src->g->tp_size * 16 * e0->V_l * 2)) { vlo_tp_session_destroy(t); return VLO_E_HIP; }
+    *out = t;
+    return VLO_OK;
+}
+int vlo_tp_session_crop(vlo_tp_session *t, int64_t n_tokens) {
+    if (!t || n_tokens < 0 || n_tokens > vlo_tp_session_len(t)) return vlo_fail(VLO_E_INVALID, "bad tp_session_crop arguments");
+    for (vlo_session *s : t->ss) {
+        const int rc = session_crop_shard(s, n_tokens);
+        if (rc) return rc;
+    }
+    return VLO_OK;
+}
+
 // ---- p2p exchange ------------------------------------------------------------------------------------------------
 // Every rank owns a MAILBOX in its own HBM, mapped by every peer (hipIpc across processes, plain pointers inside one):
 //   reduce region  [2 slots][T sources][16 rows][H]        8-byte granules {tag = epoch, fp32 partial sum}

@@ -390,12 +390,18 @@ class TpSession:
         except Exception:
             pass
 
-    def fork(self, n_tokens: int, stream=None):
-        raise NotImplementedError("tensor-parallel sessions cannot be forked (include/vlo.h: vlo_session_fork); "
-                                  "run stream_evaluate / trim_past_key_values on a TP=1 engine")
+    def fork(self, n_tokens: int, stream=None) -> "TpSession":
+        """A new tensor-parallel session holding a copy of the first ``n_tokens`` positions of every local KV shard
+        (trim_past_key_values(past, 0, n), models/modeling_live.py:170-171); one process per GPU: every rank calls it."""
+        h = C.c_void_p()
+        _C.check(_C.lib().vlo_tp_session_fork(self._h, n_tokens, C.byref(h), _stream_handle(stream)))
+        out = TpSession.__new__(TpSession)
+        out.group, out._h = self.group, h
+        return out
 
     def crop(self, n_tokens: int):
-        raise NotImplementedError("tensor-parallel sessions cannot be cropped (include/vlo.h: vlo_session_crop)")
+        """Forget every position >= n_tokens in place, on every local KV shard."""
+        _C.check(_C.lib().vlo_tp_session_crop(self._h, n_tokens))
 
 
 class TpGroup:
