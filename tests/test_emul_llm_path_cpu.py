@@ -526,6 +526,37 @@ def test_fp8_weight_image_gemv(E, n, N, K):
 FP8_TINY = O.LlmSpec(512, 1024, 1, 4, 2, 256, 10000.0, 1e-5, vision_hidden_size=128)    # K = 512 / 1024: the smallest shapes the fp8 image takes
 
 
+def test_fp8_engine_prefill_path_in_emulation(E):
+    """An fp8 engine on the prefill path: the e4m3 image expanded to the packed bf16 image per GEMM (prefill.hip::expand_fp8_image_kernel)
+    and the per-channel scales applied in the GEMM epilogues (plain, SwiGLU, residual): 300 tokens, then a decode step, all rows' logits
+    3-way against the reference arithmetic on the dequantised weights."""
+    from videollm_online_amd.checkpoint import quantize_fp8_per_channel
+    spec = O.LlmSpec(512, 512, 1, 4, 1, 256, 10000.0, 1e-5, vision_hidden_size=128)      # K = 512: the smallest the fp8 image takes; head dim 128, GQA 4
+    w = O.init_llm_weights(spec, seed=12)
+    eng_w, ora_w, keep = {}, {}, set()
+    for k, v in w.items():
+        if k.endswith(O.FP8_STREAMED):
+            q, sc = quantize_fp8_per_channel(v)
+            eng_w[k], eng_w[k + "_scale"] = q, sc
+            ora_w[k] = q.float() * sc[:, None]
+            keep.add(k)
+        else:
+            eng_w[k] = ora_w[k] = v
+    ref, gold = O.LlamaOracle(spec, ora_w, torch.bfloat16, keep_fp32=keep), O.LlamaOracle(spec, ora_w, torch.float32)
+    eng = E.EmulEngine(spec, kv_pool_tokens=1024, weight_dtype=1).load_weights(eng_w, O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+    s = eng.new_session()
+    g = torch.Generator().manual_seed(4)
+    rc = gc = None
+    for i, n in enumerate((300, 1)):
+        x = (torch.randn(n, spec.hidden_size, generator=g) * 0.7).bfloat16()
+        rl, rc = ref.forward(x, rc)
+        gl, gc = gold.forward(x, gc)
+        last, allr = eng.llm_step(s, x)
+        assert eng.session_len(s) == len(rc)
+        _three_way("fp8 prefill path", i, allr, rl, gl)
+    eng.close()
+
+
 def test_fp8_engine_block_path_and_chunks(E):
     """An fp8 engine (weight_dtype = 1) end to end in emulation: a 45-token first step through the 64-token block path
     (csrc/prefill.hip::gemm64_kernel<KF, EPI, WQ = 1>: one e4m3 -> bf16 expansion per fragment pair feeds four token tiles, scales on

@@ -185,6 +185,35 @@ def test_fp8_block_path_teacher_forced_rows():
     eng.close()
 
 
+def test_fp8_prefill_path_teacher_forced_rows():
+    """A 700-token teacher-forced input on an fp8 engine takes the prefill path (csrc/engine.hip::run_prefill): every projection's e4m3
+    image is expanded to bf16 (exactly) right before its ping-pong GEMM and the per-channel scales multiply the fp32 sums in the GEMM's
+    epilogue — every row's logits against the reference arithmetic on the dequantised weights, then the stream continues on the 16-row
+    path over the KV the prefill appended."""
+    from videollm_online_amd.engine import Engine
+    spec = O.LLM_SPECS["llama-3-8b-2l"]
+    w = O.init_llm_weights(spec, seed=9)
+    eng_w, ora_w, keep = _quantized(w)
+    ref, gold = _oracles(spec, ora_w, keep)
+    eng = Engine(_cfg(spec))
+    eng.load_weights(eng_w)
+    eng.load_weight("rope.inv_freq", O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+    eng.finalize()
+    sess = eng.new_session()
+    g = torch.Generator().manual_seed(33)
+    ids = torch.randint(0, spec.vocab_size, (700,), generator=g)
+    rc = gc = None
+    for i, x in enumerate([ref.embed(ids), torch.randn(11, spec.hidden_size, generator=g).bfloat16(), ref.embed(torch.tensor([5]))]):
+        rl, rc = ref.forward(x, rc)
+        gl, gc = gold.forward(x, gc)
+        last, allr = eng.llm_step(sess, x.cuda(), want_last=True, want_all=True)
+        torch.cuda.synchronize()
+        assert sess.get_seq_length() == len(rc) and torch.equal(last, allr[-1])
+        _check("fp8 8b-2l prefill path", i, allr.cpu(), rl, gl)
+    sess.close()
+    eng.close()
+
+
 def test_fp8_70b_width_two_layer_stream_on_one_gpu():
     """configs[4]'s LLM half as ONE rank holds it at TP = 1 (the bench's `--model llama-3-70b --weight-dtype fp8` line): H 8192, I 28672,
     64 q / 8 kv heads, two distinct layers, fp8 weights — the streaming step sequence (block-path prompt, frame steps, decode steps)

@@ -25,8 +25,7 @@ def main():
     H = cfg.hidden_size
     x = (torch.randn(args.tokens, H, device="cuda") * 0.5).bfloat16()
     labels = torch.randint(0, cfg.vocab_size, (args.tokens,), device="cuda")
-    mode = "16-row chunks" if os.environ.get("VLO_BLOCK_PATH") == "0" else ("64-token blocks" if os.environ.get("VLO_PREFILL") == "0" or args.weight_dtype != "bf16"
-                                                                        else "prefill GEMMs")
+    mode = "16-row chunks" if os.environ.get("VLO_BLOCK_PATH") == "0" else ("64-token blocks" if os.environ.get("VLO_PREFILL") == "0" else "prefill GEMMs")
     for want_all in (False, True):
         sess = eng.new_session()
         eng.llm_step(sess, x[:min(args.tokens, 600)], want_last=True, want_all=want_all)          # warm-up (allocates the block / prefill workspaces)

@@ -62,6 +62,9 @@ struct vlo_engine {
     std::vector<int> free_pages;
     std::mutex pool_mu;
 
+    void *pf_wexp = nullptr;                     // prefill path of an fp8 engine: bf16 expansion of ONE projection's image (the largest), reused per GEMM
+    size_t pf_wexp_bytes = 0;
+
     VitState *vit = nullptr;
     void *ingest = nullptr;                      // ingest.hip: cached tap tables + scratch of vlo_frame_ingest
 

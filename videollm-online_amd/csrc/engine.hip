@@ -796,10 +796,27 @@ static int run_prefill(vlo_session *s, const unsigned short *src, int m, bool wa
     if ((rc = ensure_pages(s, s->len + m, st))) return rc;
     const KvGeom kv = kv_geom(s);
     HIP_TRY(copy_rows_launch(src, s->ph, m, H, st));
+    // fp8 engines: a projection's e4m3 image is expanded to bf16 (exactly) into one scratch right before its GEMM — 3 bytes of extra traffic
+    // per weight against hundreds of tokens of MFMA work per weight — and its per-channel scales go to the GEMM's epilogue
+    auto gemm = [&](const unsigned short *X, const PackedLinear &pl, int N, int K, unsigned short *out, int ldo, int kind) -> int {
+        if (!pl.wq) { HIP_TRY(llm_gemm_launch(X, pl.Wp, m, N, K, out, ldo, kind, st)); return VLO_OK; }
+        const size_t need = (size_t)pl.NT * 16 * K * 2;
+        if (e->pf_wexp_bytes < need) {
+            HIP_TRY(hipStreamSynchronize(st));                       // (grows once: the largest projection)
+            void *p = nullptr;
+            int rc2 = dev_alloc(&p, need);
+            if (rc2) return rc2;
+            e->owned.push_back(p);
+            e->pf_wexp = p; e->pf_wexp_bytes = need;
+        }
+        HIP_TRY(expand_fp8_image_launch(pl.Wp, e->pf_wexp, pl.NT, K, st));
+        HIP_TRY(llm_gemm_launch(X, e->pf_wexp, m, N, K, out, ldo, kind, st, pl.wscale));
+        return VLO_OK;
+    };
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerWeights &L = e->layers[l];
         HIP_TRY(add_rmsnorm_launch(s->ph, nullptr, 0, H, (const unsigned short *)L.ln_in, s->px, H, H, c.rms_eps, m, st));
-        HIP_TRY(llm_gemm_launch(s->px, L.qkv.Wp, m, Nqkv, H, s->pqkv, Nqkv, LLM_GEMM_BF16, st));
+        if ((rc = gemm(s->px, L.qkv, Nqkv, H, s->pqkv, Nqkv, LLM_GEMM_BF16))) return rc;
         HIP_TRY(rope_kv_append_launch(s->pqkv, m, nh, (const unsigned short *)e->cos_tab, (const unsigned short *)e->sin_tab, kv, l, s->len, s->pq, st));
         // the whole block's keys are appended: ONE attention launch, grid.z = the block's 16-query sub-chunks (causal mask per sub-chunk,
         // one split each); the output lands in px (the o-proj's X operand)
@@ -807,16 +824,16 @@ static int run_prefill(vlo_session *s, const unsigned short *src, int m, bool wa
         hipError_t ae = flash ? attention_prefill_launch(s->pq, kv, l, nh, s->len, m, s->px, st) : hipErrorNotSupported;
         if (ae == hipErrorNotSupported) ae = attention_launch(s->pq, kv, l, nh, s->len, m, s->ppart_o, s->ppart_ml, s->px, st, -1, VLO_PREFILL_TOKENS / 16);
         HIP_TRY(ae);
-        HIP_TRY(llm_gemm_launch(s->px, L.o.Wp, m, H, qd, s->ph, H, LLM_GEMM_RESID, st));
+        if ((rc = gemm(s->px, L.o, H, qd, s->ph, H, LLM_GEMM_RESID))) return rc;
         HIP_TRY(add_rmsnorm_launch(s->ph, nullptr, 0, H, (const unsigned short *)L.ln_post, s->px, H, H, c.rms_eps, m, st));
-        HIP_TRY(llm_gemm_launch(s->px, L.gate_up.Wp, m, 2 * I, H, s->pact, I, LLM_GEMM_SWIGLU, st));
-        HIP_TRY(llm_gemm_launch(s->pact, L.down.Wp, m, H, I, s->ph, H, LLM_GEMM_RESID, st));
+        if ((rc = gemm(s->px, L.gate_up, 2 * I, H, s->pact, I, LLM_GEMM_SWIGLU))) return rc;
+        if ((rc = gemm(s->pact, L.down, H, I, s->ph, H, LLM_GEMM_RESID))) return rc;
     }
     if (want_last || all_logits) {
         HIP_TRY(add_rmsnorm_launch(s->ph, nullptr, 0, H, (const unsigned short *)e->norm_w, s->px, H, H, c.rms_eps, m, st));
         if (all_logits) {                       // every row, straight into the caller's matrix
             if (V % 256 == 0) {
-                HIP_TRY(llm_gemm_launch(s->px, e->lm_head.Wp, m, V, H, all_logits, V, LLM_GEMM_BF16, st));
+                if ((rc = gemm(s->px, e->lm_head, V, H, all_logits, V, LLM_GEMM_BF16))) return rc;
             } else {                            // vocabularies that are not whole 256-column tiles: 16 rows at a time through the GEMV
                 for (int r0 = 0; r0 < m; r0 += 16) {
                     GemvArgs a = gemv_args(e->lm_head, s->px + (size_t)r0 * H, H, std::min(16, m - r0));
@@ -837,12 +854,12 @@ static int run_prefill(vlo_session *s, const unsigned short *src, int m, bool wa
     return VLO_OK;
 }
 
-// shapes the prefill GEMMs take: bf16 image, every projection width a multiple of 256 and every K a multiple of 128
+// shapes the prefill GEMMs take (bf16 image, or the fp8 image expanded per GEMM): every projection width a multiple of 256, every K of 128
 static bool prefill_ok(const vlo_engine *e) {
     static const bool on = getenv("VLO_PREFILL") ? atoi(getenv("VLO_PREFILL")) != 0 : true;
     const vlo_config &c = e->cfg;
     const int hd = e->head_dim, qd = c.num_heads * hd, Nqkv = qd + 2 * c.num_kv_heads * hd;
-    return on && c.weight_dtype == 0 && e->tp_size == 1 && !(Nqkv & 255) && !(c.hidden_size & 255) && !((2 * c.intermediate_size) & 255) &&
+    return on && e->tp_size == 1 && !(Nqkv & 255) && !(c.hidden_size & 255) && !((2 * c.intermediate_size) & 255) &&
            !(c.intermediate_size & 127) && !(qd & 127) && (hd == 64 || hd == 128);
 }
 

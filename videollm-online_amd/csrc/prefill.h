@@ -26,7 +26,12 @@ enum { LLM_GEMM_BF16 = 0, LLM_GEMM_SWIGLU = 1, LLM_GEMM_RESID = 2 };
 //   LLM_GEMM_BF16:   out bf16 [M][ldo] = bf16(X W^T)
 //   LLM_GEMM_SWIGLU: Wp = the gate/up image (N = 2 I): out bf16 [M][ldo = I] = bf16(silu(bf16 g) * bf16 u)
 //   LLM_GEMM_RESID:  out = the residual stream bf16 [M][N]: out = bf16(out + bf16(X W^T))
-hipError_t llm_gemm_launch(const unsigned short *X, const void *Wp, int M, int N, int K, unsigned short *out, int ldo, int kind, hipStream_t st);
+// wscale: null (bf16 image) or the fp32 per-output-channel scales of an fp8 engine, packed row order; Wp is then the bf16 EXPANSION of the
+// fp8 image (expand_fp8_image_launch below), the scales multiply the fp32 sums in the epilogue as they do in the GEMV
+hipError_t llm_gemm_launch(const unsigned short *X, const void *Wp, int M, int N, int K, unsigned short *out, int ldo, int kind, hipStream_t st,
+                           const float *wscale = nullptr);
+// fp8 e4m3 image Wp8[tile][kf2][lane] (gemv.hip) -> bf16 image Wp[tile][kf][lane], exact (every e4m3 value is a bf16 value); NT tiles of K
+hipError_t expand_fp8_image_launch(const void *Wp8, void *Wp_bf16, int NT, int K, hipStream_t st);
 // qkv bf16 [M][(nh + 2 nkv) hd] (projection outputs) -> RoPE (HF rounding points) -> q bf16 [M][nh hd], K / V^T appended to the paged pool
 // at positions pos0 .. pos0 + M - 1
 hipError_t rope_kv_append_launch(const unsigned short *qkv, int M, int num_heads, const unsigned short *cos_tab, const unsigned short *sin_tab,

@@ -293,10 +293,31 @@ hipError_t gemm64_launch(GemvArgs a, const Gemm64Plan &p, int epi, hipStream_t s
 #define VLO_GEMM_KERNELS_ONLY
 #include "vit_gemm.inc"
 
-hipError_t llm_gemm_launch(const unsigned short *X, const void *Wp, int M, int N, int K, unsigned short *out, int ldo, int kind, hipStream_t st) {
+// one 16-byte register of the fp8 image = the 8 + 8 codes of fragments 2 kf2 and 2 kf2 + 1 of a lane -> two 16-byte bf16 fragments
+__global__ __launch_bounds__(256) void expand_fp8_image_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n_regs, int KF2tot) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_regs; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t lane = i & 63, t = i >> 6, kf2 = t % KF2tot, tile = t / KF2tot;
+        frag_ab f0, f1;
+        fp8x16_to_bf16(__builtin_bit_cast(frag_ab, src[i]), f0, f1);
+        uint4 *d = dst + ((tile * KF2tot + kf2) * 2) * 64 + lane;
+        d[0] = __builtin_bit_cast(uint4, f0);
+        d[64] = __builtin_bit_cast(uint4, f1);
+    }
+}
+hipError_t expand_fp8_image_launch(const void *Wp8, void *Wp_bf16, int NT, int K, hipStream_t st) {
+    if (!Wp8 || !Wp_bf16 || NT <= 0 || (K & 63)) return hipErrorInvalidValue;
+    const size_t n_regs = (size_t)NT * (K >> 6) * 64;
+    const int blocks = (int)std::min<size_t>((n_regs + 255) / 256, 4096);
+    hipLaunchKernelGGL(expand_fp8_image_kernel, dim3(blocks), dim3(256), 0, st, (const uint4 *)Wp8, (uint4 *)Wp_bf16, n_regs, K >> 6);
+    return hipGetLastError();
+}
+
+hipError_t llm_gemm_launch(const unsigned short *X, const void *Wp, int M, int N, int K, unsigned short *out, int ldo, int kind, hipStream_t st,
+                           const float *wscale) {
     if (!X || !Wp || !out || M <= 0 || (N & 255) || (K & 127) || K < 128) return hipErrorInvalidValue;
     GemmArgs a{};
     a.X = (const f16_t *)X; a.W = (const f16_t *)Wp; a.M = M; a.N = N; a.K = K; a.ldx = K; a.ldo = ldo; a.outb = out; a.xpad = 1;
+    a.bias = wscale;
     const int tx = N / 256;
     // tile height: 256 rows once such tiles fill the chip, else 128 (twice the tiles, half the work each)
     static const int force_bm = getenv("VLO_PREFILL_BM") ? atoi(getenv("VLO_PREFILL_BM")) : 0;
