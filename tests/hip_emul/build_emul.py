@@ -60,7 +60,7 @@ def build(force=False, sanitize=None):
     # textually included kernel bodies are patched too: the copies in OUT shadow the originals (quote includes resolve next to
     # the including file first)
     for inc in os.listdir(CSRC):
-        if inc.endswith(".inc"):
+        if inc.endswith((".inc", ".cuh")):                  # (.cuh: common.cuh carries the inline-asm direct-to-LDS helper)
             with open(os.path.join(OUT, inc), "w") as f:
                 f.write(f'#line 1 "{os.path.join(CSRC, inc)}"\n' + patch(open(os.path.join(CSRC, inc)).read()))
     for s in SOURCES:

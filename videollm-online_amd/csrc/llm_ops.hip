@@ -330,12 +330,6 @@ static hipError_t attn_combine_launch(const float *part_o, const float *part_ml,
 //     s_waitcnt vmcnt(0) + barrier per tile: tile i + 1 lands while tile i is multiplied.
 // grid = (ceil(n / QB), nkv); 512 threads.  Rounding points as the other attention kernels (P -> bf16 before P.V, bf16 output).
 // ------------------------------------------------------------------------------------
-VLO_DEV void attn_glds16(const void *gsrc, void *lds_dst) {        // lds_dst: wave-uniform; lane l lands at lds_dst + 16 l
-    unsigned keep;
-    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_dst);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
-}
-
 template <int HD, int G>
 __global__ __launch_bounds__(512) void attn_prefill_kernel(const bf16_t *__restrict__ q, KvGeom kv, int layer, int nh, int64_t pos0, int n, float scale,
                                                            bf16_t *__restrict__ out) {
@@ -396,7 +390,7 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const bf16_t *__restr
             } else {
                 src = vp + (size_t)((p - PK) * 16 + col) * VLO_PAGE_TOKENS + qd * 8;
             }
-            attn_glds16(src, &tile[b][p * 1024]);
+            glds16_untracked(src, &tile[b][p * 1024]);
         }
     };
     stage(0, 0);

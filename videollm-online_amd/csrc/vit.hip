@@ -487,11 +487,15 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
         }
         // batched frames: one workgroup per (frame, head) with K and V^T resident in LDS; few frames: 64-query tiles, keys split over 4 waves
         static const int head_min = getenv("VLO_VIT_ATTN_HEAD_MIN") ? atoi(getenv("VLO_VIT_ATTN_HEAD_MIN")) : 96;     // workgroups; 0 = never
+        static const int tiles_min = getenv("VLO_VIT_ATTN_TILES_MIN") ? atoi(getenv("VLO_VIT_ATTN_TILES_MIN")) : 192;   // workgroups of the tile-streamed padded-head kernel; 0 = never
         if (head_min > 0 && B * v->nh >= head_min && v->attn_head_lds > 0)
             hipLaunchKernelGGL((vit_attn_head_kernel<0>), dim3((S + 575) / 576, v->nh, B), dim3(768), v->attn_head_lds, st, w_qk16, w_vT, w_att16, S, D, v->nh,
                                scale * 1.4426950408889634f, v->attn_vrs);
         else if (v->hdk == 64)
             hipLaunchKernelGGL((vit_attn_kernel<64>), dim3((S + 63) / 64, v->nh, B), dim3(256), kAttnLds, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
+        else if (B * v->nh * ((S + 255) / 256) >= tiles_min && tiles_min > 0)
+            // padded heads, batched frames: 256-query workgroups over LDS-staged key tiles (vit_attn.inc::vit_attn_tiles_kernel)
+            hipLaunchKernelGGL((vit_attn_tiles_kernel<96, 80>), dim3((S + 255) / 256, v->nh, B), dim3(512), 0, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
         else {
             static const int qs = getenv("VLO_VIT_ATTN_QS") ? atoi(getenv("VLO_VIT_ATTN_QS")) : 4;     // 16-query sub-tiles per block for the padded-head kernel
             if (qs == 2)
