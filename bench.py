@@ -520,6 +520,21 @@ def main():
                 traffic_source = "profiles/pmc_gemv_gate_up.json (stored result of a rocprofv3 --pmc run, NOT measured in this run)"
             except Exception:
                 traffic = None
+        # the same kernel's kernel-only average from the builder's committed `rocprofv3 --kernel-trace --stats` run of this command
+        # (the newest profiles/rN_kernel_stats_bench200*.csv): a stored cross-check beside the live figure, labelled as such
+        rocprof = {}
+        if args.model == "llama-3-8b" and args.weight_dtype == "bf16":
+            try:
+                import csv, glob
+                path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_kernel_stats_bench200*.csv")),
+                              key=lambda q: (int(os.path.basename(q)[1:].split("_")[0]), q))[-1]
+                row = next(r for r in csv.DictReader(open(path)) if r["kernel"].startswith("void gemv16_kernel<16, 8, 1, 3, 0"))
+                us = float(row["avg_us"])
+                rocprof = {"rocprof_avg_launch_us": us, "frac_rocprof": round(bytes_per_launch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                           "rocprof_source": f"profiles/{os.path.basename(path)} ({row['calls']} launches; stored result of a rocprofv3 --kernel-trace --stats run, "
+                                             "NOT measured in this run)"}
+            except Exception:
+                rocprof = {}
         minutes = total / args.fps / 60.0
         out = {
             "metric": ("streaming FPS + p50 per-frame latency, Llama-3-8B+SigLIP-L, 10 min @ 2 FPS, 1/2/4/8 GPU"
@@ -566,7 +581,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                          "traffic": traffic if args.weight_dtype == "bf16" else None, "traffic_source": traffic_source if args.weight_dtype == "bf16" else None,
                          "launches_timed": n_launch, "avg_launch_us": round(net_ms * 1e3, 2), "avg_bracket_us_raw": round(avg_ms * 1e3, 2),
-                         "empty_bracket_us": round(empty_us, 2), "bytes_per_launch": bytes_per_launch},
+                         "empty_bracket_us": round(empty_us, 2), "bytes_per_launch": bytes_per_launch, **rocprof},
         }
     # N > 1, replica mode: also measure ONE stream tensor-parallel over the same N GPUs (BASELINE.json north_star).  It
     # runs in child processes (one per rank, own rendezvous port) so that a failure or hang of the RCCL leg — which no

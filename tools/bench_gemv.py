@@ -1,7 +1,7 @@
-"""GEMV micro-benchmark: the step's weight-streaming shapes (Llama-3-8B; Llama-3-70B at TP = 8 per rank), bf16 and fp8 e4m3
+"""GEMV micro-benchmark: the step's weight-streaming shapes (Llama-3-8B and Llama-3-70B, whole or one rank's shard at TP = 8), bf16 and fp8 e4m3
 weight images, TB/s of weight bytes per shape (weights cycled through > 1 GB so the Infinity Cache cannot serve re-reads).
 
-    python tools/bench_gemv.py [8b|70b|70b-tp8] [bf16|fp8|both]
+    python tools/bench_gemv.py [8b|70b|8b-tp8|70b-tp8] [bf16|fp8|both]
 """
 import ctypes as C
 import os
@@ -19,6 +19,8 @@ SHAPES = {"8b": [("qkv+rope", 6144, 4096, 5), ("o+resid", 4096, 4096, 4), ("gate
                  ("lm_head", 128256, 4096, 1)],
           "70b": [("qkv+rope", 10240, 8192, 5), ("o+resid", 8192, 8192, 4), ("gate_up", 57344, 8192, 3), ("down/ks", 8192, 28672, 0),
                   ("lm_head", 128256, 8192, 1)],
+          "8b-tp8": [("qkv+rope", 768, 4096, 5), ("o/ks", 4096, 512, 0), ("gate_up", 3584, 4096, 3), ("down/ks", 4096, 1792, 0),
+                     ("lm_head", 16032, 4096, 1)],
           "70b-tp8": [("qkv+rope", 1280, 8192, 5), ("o/ks", 8192, 1024, 0), ("gate_up", 7168, 8192, 3), ("down/ks", 8192, 3584, 0),
                       ("lm_head", 16032, 8192, 1)]}
 model = sys.argv[1] if len(sys.argv) > 1 else "8b"
