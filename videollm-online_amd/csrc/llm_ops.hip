@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include "common.cuh"
+#include "glds_asm.cuh"
 #include "llm_ops.h"
 
 // ------------------------------------------------------------------------------------

@@ -20,6 +20,7 @@
 #include <map>
 
 #include "common.cuh"
+#include "glds_asm.cuh"
 #include "vit.h"
 
 #include "vit_gemm.inc"
