@@ -327,18 +327,20 @@ static hipError_t attn_combine_launch(const float *part_o, const float *part_ml,
 //     (conflict-free ds_read_b128); the direct-to-LDS destination is lane-linear, so the gather happens on the per-lane SOURCE address;
 //   * keys are permuted inside a 32-key tile as in attn_cols_kernel (row r of key tile t = key (r >> 2) * 8 + (r & 3) + 4 t): the lane
 //     that holds S rows 4 qd .. 4 qd + 3 of both tiles owns 8 CONSECUTIVE keys, P^T is a B operand as produced and a V^T fragment is one chunk;
-//   * the loads are issued in inline asm (invisible to hipcc, which would drain them before every LDS read) and retired by one
-//     s_waitcnt vmcnt(0) + barrier per tile: tile i + 1 lands while tile i is multiplied.
+//   * the loads are issued in inline asm (invisible to hipcc, which would drain them before every LDS read) into a ring of NS tile buffers and
+//     retired by ONE COUNTED s_waitcnt vmcnt + a raw s_barrier per tile: NS - 1 tiles are in flight while one is multiplied (one 16-KiB tile per CU
+//     in flight — NS = 2 — leaves the kernel waiting for L2 latency: a tile's MFMAs take ~0.5 us, its round trip ~2).
 // grid = (ceil(n / QB), nkv); 512 threads.  Rounding points as the other attention kernels (P -> bf16 before P.V, bf16 output).
 // ------------------------------------------------------------------------------------
-template <int HD, int G>
+template <int HD, int G, int NS>
 __global__ __launch_bounds__(512) void attn_prefill_kernel(const bf16_t *__restrict__ q, KvGeom kv, int layer, int nh, int64_t pos0, int n, float scale,
                                                            bf16_t *__restrict__ out) {
     constexpr int NKK = HD / 32, NDT = HD / 16, QB = 256 / G, NCT = 2;
     constexpr int PK = 2 * NKK, PV = NDT, PIECES = PK + PV;             // 1-KiB pieces of one key tile: K (t, kk) then V^T (dt)
     static_assert(PIECES % 8 == 0, "eight waves share the staging");
     constexpr int PPW = PIECES / 8;
-    __shared__ __attribute__((aligned(16))) char tile[2][PIECES * 1024];
+    constexpr int AHEAD = NS - 1;                                         // tiles issued ahead of the one being multiplied
+    __shared__ __attribute__((aligned(16))) char tile[NS][PIECES * 1024];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 15, qd = lane >> 4;
     const int kvh = blockIdx.y;
@@ -376,9 +378,22 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const bf16_t *__restr
     const int ntiles = (L + 31) >> 5;
     // stage key tile kt into buffer b: this wave's PPW pieces.  Piece p < PK: K (t = p / NKK, kk = p % NKK): lane (c = qd, r = col) fetches
     // bytes [(4 kk + c) 16, + 16) of key row (r >> 2) * 8 + (r & 3) + 4 t; piece PK + dt: V^T rows 16 dt + r, keys 8 c .. 8 c + 7.
+    // The page ids travel in a register, one per lane for 64 consecutive pages (16 384 keys), and reach the staging code by a shuffle: a
+    // page-table read inside the loop is a VECTOR load for hipcc (the kernel stores to global memory, so nothing is provably scalar), and the
+    // s_waitcnt vmcnt(0) it puts in front of the value's first use would drain the whole ring of direct-to-LDS tiles on every iteration.  The
+    // refill every 512 tiles waits for its load INSIDE its branch (the empty asm consumes the value), so that no wait is left at the join.
+    const int npages = (L + VLO_PAGE_TOKENS - 1) / VLO_PAGE_TOKENS;
+    int ptv = lane < npages ? kv.page_table[lane] : 0, ptchunk = 0;
+    asm volatile("" : "+v"(ptv));
     auto stage = [&](int kt, int b) {
         const int kt0 = kt * 32;
-        const int page = kv.page_table[kt0 / VLO_PAGE_TOKENS], tok0 = kt0 % VLO_PAGE_TOKENS;     // a 32-key tile never straddles a 256-token page
+        const int pg = kt0 / VLO_PAGE_TOKENS, tok0 = kt0 % VLO_PAGE_TOKENS;       // a 32-key tile never straddles a 256-token page
+        if ((pg >> 6) != ptchunk) {
+            ptchunk = pg >> 6;
+            ptv = ptchunk * 64 + lane < npages ? kv.page_table[ptchunk * 64 + lane] : 0;
+            asm volatile("" : "+v"(ptv));
+        }
+        const int page = __builtin_amdgcn_readfirstlane(__shfl(ptv, pg & 63, 64));
         const bf16_t *kp = kbase + (size_t)page * kv.page_elems + ((size_t)kvh * VLO_PAGE_TOKENS + tok0) * HD;
         const bf16_t *vp = vbase + (size_t)page * kv.page_elems + ((size_t)kvh * HD) * VLO_PAGE_TOKENS + tok0;
 #pragma unroll
@@ -394,12 +409,17 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const bf16_t *__restr
             glds16_untracked(src, &tile[b][p * 1024]);
         }
     };
-    stage(0, 0);
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const int b = kt & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // this wave's pieces of tile kt have landed ...
-        __syncthreads();                                                    // ... and everybody's; everybody is also done reading buffer b ^ 1
-        if (kt + 1 < ntiles) stage(kt + 1, b ^ 1);
+    for (int s = 0; s < AHEAD && s < ntiles; ++s) stage(s, s);
+    for (int kt = 0, b = 0; kt < ntiles; ++kt, b = (b + 1 == NS ? 0 : b + 1)) {
+        // this wave's pieces of tile kt have landed (the AHEAD - 1 younger tiles stay in flight; the last tiles of the range: everything) ...
+        if (kt + AHEAD - 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... and, behind the barrier, everybody's; everybody is also done with tile kt - 1, whose buffer the next stage overwrites.  A RAW barrier:
+        // __syncthreads() may come with a vmcnt(0) of its own
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + AHEAD < ntiles) stage(kt + AHEAD, b == 0 ? NS - 1 : b - 1);
         const frag_ab *fr = reinterpret_cast<const frag_ab *>(&tile[b][0]) + lane;
         const int kb = kt * 32 + qd * 8;
 #pragma unroll
@@ -462,10 +482,12 @@ hipError_t attention_prefill_launch(const unsigned short *q, KvGeom kv, int laye
     const int nkv = kv.num_kv_heads, hd = kv.head_dim, G = num_heads / nkv;
     if (n <= 0 || nkv * G != num_heads) return hipErrorInvalidValue;
     const float scale = 1.0f / sqrtf((float)hd);
+    static const int kStages = getenv("VLO_ATTN_STAGES") ? atoi(getenv("VLO_ATTN_STAGES")) : 4;      // tile buffers in the ring (2: one tile in flight)
 #define VLO_ATTN_PF(HD_, G_)                                                                                                          \
     do {                                                                                                                              \
         constexpr int QB_ = 256 / G_;                                                                                                 \
-        hipLaunchKernelGGL((attn_prefill_kernel<HD_, G_>), dim3((n + QB_ - 1) / QB_, nkv), dim3(512), 0, st, q, kv, layer, num_heads, pos0, n, scale, out); \
+        if (kStages == 2) hipLaunchKernelGGL((attn_prefill_kernel<HD_, G_, 2>), dim3((n + QB_ - 1) / QB_, nkv), dim3(512), 0, st, q, kv, layer, num_heads, pos0, n, scale, out); \
+        else hipLaunchKernelGGL((attn_prefill_kernel<HD_, G_, 4>), dim3((n + QB_ - 1) / QB_, nkv), dim3(512), 0, st, q, kv, layer, num_heads, pos0, n, scale, out); \
         return hipGetLastError();                                                                                                     \
     } while (0)
     if (hd == 128 && G == 4) VLO_ATTN_PF(128, 4);

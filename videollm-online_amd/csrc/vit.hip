@@ -494,10 +494,12 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
                                scale * 1.4426950408889634f, v->attn_vrs);
         else if (v->hdk == 64)
             hipLaunchKernelGGL((vit_attn_kernel<64>), dim3((S + 63) / 64, v->nh, B), dim3(256), kAttnLds, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
-        else if (B * v->nh * ((S + 255) / 256) >= tiles_min && tiles_min > 0)
+        else if (B * v->nh * ((S + 255) / 256) >= tiles_min && tiles_min > 0) {
             // padded heads, batched frames: 256-query workgroups over LDS-staged key tiles (vit_attn.inc::vit_attn_tiles_kernel)
-            hipLaunchKernelGGL((vit_attn_tiles_kernel<96, 80>), dim3((S + 255) / 256, v->nh, B), dim3(512), 0, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
-        else {
+            static const int kStages = getenv("VLO_ATTN_STAGES") ? atoi(getenv("VLO_ATTN_STAGES")) : 4;        // tile buffers in the ring (2: one tile in flight)
+            if (kStages == 2) hipLaunchKernelGGL((vit_attn_tiles_kernel<96, 80, 2>), dim3((S + 255) / 256, v->nh, B), dim3(512), 0, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
+            else hipLaunchKernelGGL((vit_attn_tiles_kernel<96, 80, 4>), dim3((S + 255) / 256, v->nh, B), dim3(512), 0, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
+        } else {
             static const int qs = getenv("VLO_VIT_ATTN_QS") ? atoi(getenv("VLO_VIT_ATTN_QS")) : 4;     // 16-query sub-tiles per block for the padded-head kernel
             if (qs == 2)
                 hipLaunchKernelGGL((vit_attn_kernel<96, 80, 2>), dim3((S + 31) / 32, v->nh, B), dim3(256), attn_lds(80, 2), st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
