@@ -717,6 +717,7 @@ def test_prefill_path_gemms_in_emulation(E, shape):
         s = eng.new_session()
         g = torch.Generator().manual_seed(4)
         rc = gc = None
+        first = None
         for i, n in enumerate((300, 11, 1)):
             x = (torch.randn(n, spec.hidden_size, generator=g) * 0.7).bfloat16()
             rl, rc = ref.forward(x, rc)
@@ -724,9 +725,17 @@ def test_prefill_path_gemms_in_emulation(E, shape):
             last, allr = eng.llm_step(s, x)
             assert eng.session_len(s) == len(rc) and torch.equal(last, allr[-1])
             _three_way("prefill path", i, allr, rl, gl)
+            first = first or (x, allr.clone())
+        # the attention kernel's wave-uniform shortcuts (no causal select on fully visible tiles, no accumulator rescale when no maximum moved) are
+        # bit-identical to the long way
+        os.environ["VLO_ATTN_NOSKIP"] = "1"
+        s2 = eng.new_session()
+        _, again = eng.llm_step(s2, first[0])
+        assert torch.equal(again, first[1])
         eng.close()
     finally:
         os.environ.pop("VLO_EMUL_GLDS", None)
+        os.environ.pop("VLO_ATTN_NOSKIP", None)
 
 
 VIT_TILES_CHILD = r"""

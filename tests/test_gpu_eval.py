@@ -113,6 +113,23 @@ def test_session_fork_and_crop():
     assert len(a) == 0
 
 
+def test_prefill_attention_shortcuts_are_bit_identical(monkeypatch):
+    """attn_prefill_kernel skips the causal select on tiles that are fully visible to a wave and the accumulator rescale on tiles that moved
+    no running maximum (wave-uniform decisions); VLO_ATTN_NOSKIP=1 takes the long way.  Same logits, bit for bit, over 6 slabs of key tiles."""
+    spec = O.LLM_SPECS["toy128"]
+    w = O.init_llm_weights(spec, seed=3)
+    eng = _engine(spec, w, kv_pool_tokens=4096)
+    x = (torch.randn(1500, spec.hidden_size, generator=torch.Generator().manual_seed(5)) * 0.05).bfloat16().cuda()
+    a = eng.new_session()
+    _, short = eng.llm_step(a, x, want_last=False, want_all=True)
+    monkeypatch.setenv("VLO_ATTN_NOSKIP", "1")
+    b = eng.new_session()
+    _, long = eng.llm_step(b, x, want_last=False, want_all=True)
+    assert torch.equal(short, long)
+    assert torch.equal(a.read_kv(1, 0, 0, 0, 1500), b.read_kv(1, 0, 0, 0, 1500))
+    eng.close()
+
+
 def test_full_logits_forward_matches_oracle():
     """model(input_ids=, frames=) returns every row (the evaluation path), 3-way checked against fp32 gold."""
     from videollm_online_amd.modeling_live import LiveModel

@@ -316,6 +316,14 @@ static hipError_t attn_combine_launch(const float *part_o, const float *part_ml,
     return hipGetLastError();
 }
 
+// max over lanes l, l ^ 16, l ^ 32, l ^ 48 (the four lanes that hold one score column of a 16 x 16 MFMA tile) by two row swaps
+VLO_DEV float quad_lanes_maxf(float x) {
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 // ------------------------------------------------------------------------------------
 // Prefill attention (blocks of hundreds to thousands of new tokens, engine.hip::run_prefill): flash-style.  One workgroup = one kv head x
 // QB = 256 / G consecutive queries: its 256 (query, head) columns are 16 column tiles, two per wave (8 waves), and ALL waves walk the SAME
@@ -330,11 +338,15 @@ static hipError_t attn_combine_launch(const float *part_o, const float *part_ml,
 //   * the loads are issued in inline asm (invisible to hipcc, which would drain them before every LDS read) into a ring of NS tile buffers and
 //     retired by ONE COUNTED s_waitcnt vmcnt + a raw s_barrier per tile: NS - 1 tiles are in flight while one is multiplied (one 16-KiB tile per CU
 //     in flight — NS = 2 — leaves the kernel waiting for L2 latency: a tile's MFMAs take ~0.5 us, its round trip ~2).
+//   * the softmax arithmetic is what the kernel is bound by (PMC: VALU in 33 % of the wave cycles, MFMA busy 22 %), so two wave-uniform
+//     shortcuts drop work whose result is known, BIT-IDENTICALLY: a tile every key of which is visible to every query of the wave skips the
+//     causal select; a tile that raised no lane's running maximum skips the rescale of the 32 accumulator registers (alpha == 1 exactly).
+//     `noskip` (VLO_ATTN_NOSKIP=1, tests) takes the long way everywhere.
 // grid = (ceil(n / QB), nkv); 512 threads.  Rounding points as the other attention kernels (P -> bf16 before P.V, bf16 output).
 // ------------------------------------------------------------------------------------
 template <int HD, int G, int NS>
 __global__ __launch_bounds__(512) void attn_prefill_kernel(const bf16_t *__restrict__ q, KvGeom kv, int layer, int nh, int64_t pos0, int n, float scale,
-                                                           bf16_t *__restrict__ out) {
+                                                           bf16_t *__restrict__ out, int noskip) {
     constexpr int NKK = HD / 32, NDT = HD / 16, QB = 256 / G, NCT = 2;
     constexpr int PK = 2 * NKK, PV = NDT, PIECES = PK + PV;             // 1-KiB pieces of one key tile: K (t, kk) then V^T (dt)
     static_assert(PIECES % 8 == 0, "eight waves share the staging");
@@ -431,19 +443,27 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const bf16_t *__restr
                 s1 = mfma_bf16(fr[(1 * NKK + kk) * 64], qf[ct][kk], s1);
             }
             float v[8];
+            if (!noskip && !__any(kt * 32 + 31 > qpos[ct])) {                 // every key of the tile is visible to every query of the wave
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = (kb + r <= qpos[ct]) ? s0[r] * scale : -INFINITY;
-                v[4 + r] = (kb + 4 + r <= qpos[ct]) ? s1[r] * scale : -INFINITY;
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = s0[r] * scale;
+                    v[4 + r] = s1[r] * scale;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = (kb + r <= qpos[ct]) ? s0[r] * scale : -INFINITY;
+                    v[4 + r] = (kb + 4 + r <= qpos[ct]) ? s1[r] * scale : -INFINITY;
+                }
             }
             float tmax = v[0];
 #pragma unroll
             for (int j = 1; j < 8; ++j) tmax = fmaxf(tmax, v[j]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            tmax = quad_lanes_maxf(tmax);
             const float m_new = fmaxf(mrun[ct], tmax);
             const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
             const float alpha = __expf(mrun[ct] - m_safe);
+            const bool rescale = noskip || __any(m_new != mrun[ct]);         // wave-uniform; nobody's maximum moved: alpha == 1 (or 0 on all-zero rows)
             mrun[ct] = m_new;
             float psum = 0.f;
             float pr[8];
@@ -454,12 +474,14 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const bf16_t *__restr
             }
             const frag_ab pb = __builtin_bit_cast(frag_ab, make_uint4(pack2bf(pr[0], pr[1]), pack2bf(pr[2], pr[3]), pack2bf(pr[4], pr[5]), pack2bf(pr[6], pr[7])));
             lrun[ct] = lrun[ct] * alpha + psum;
+            if (rescale) {
 #pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                f32x4 o = O[ct][dt];
-                o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
-                O[ct][dt] = mfma_bf16(fr[(PK + dt) * 64], pb, o);
+                for (int dt = 0; dt < NDT; ++dt) {
+                    O[ct][dt][0] *= alpha; O[ct][dt][1] *= alpha; O[ct][dt][2] *= alpha; O[ct][dt][3] *= alpha;
+                }
             }
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) O[ct][dt] = mfma_bf16(fr[(PK + dt) * 64], pb, O[ct][dt]);
         }
     }
 #pragma unroll
@@ -483,11 +505,13 @@ hipError_t attention_prefill_launch(const unsigned short *q, KvGeom kv, int laye
     if (n <= 0 || nkv * G != num_heads) return hipErrorInvalidValue;
     const float scale = 1.0f / sqrtf((float)hd);
     static const int kStages = getenv("VLO_ATTN_STAGES") ? atoi(getenv("VLO_ATTN_STAGES")) : 4;      // tile buffers in the ring (2: one tile in flight)
+    const char *ns = getenv("VLO_ATTN_NOSKIP");                            // read per call: the tests flip it between two passes over the same input
+    const int noskip = ns && atoi(ns) != 0;
 #define VLO_ATTN_PF(HD_, G_)                                                                                                          \
     do {                                                                                                                              \
         constexpr int QB_ = 256 / G_;                                                                                                 \
-        if (kStages == 2) hipLaunchKernelGGL((attn_prefill_kernel<HD_, G_, 2>), dim3((n + QB_ - 1) / QB_, nkv), dim3(512), 0, st, q, kv, layer, num_heads, pos0, n, scale, out); \
-        else hipLaunchKernelGGL((attn_prefill_kernel<HD_, G_, 4>), dim3((n + QB_ - 1) / QB_, nkv), dim3(512), 0, st, q, kv, layer, num_heads, pos0, n, scale, out); \
+        if (kStages == 2) hipLaunchKernelGGL((attn_prefill_kernel<HD_, G_, 2>), dim3((n + QB_ - 1) / QB_, nkv), dim3(512), 0, st, q, kv, layer, num_heads, pos0, n, scale, out, noskip); \
+        else hipLaunchKernelGGL((attn_prefill_kernel<HD_, G_, 4>), dim3((n + QB_ - 1) / QB_, nkv), dim3(512), 0, st, q, kv, layer, num_heads, pos0, n, scale, out, noskip); \
         return hipGetLastError();                                                                                                     \
     } while (0)
     if (hd == 128 && G == 4) VLO_ATTN_PF(128, 4);
