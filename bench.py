@@ -75,6 +75,25 @@ def reduce_elapsed_max(dist, elapsed, device="cuda"):
     return float(t.item())
 
 
+def rocprof_cross_check(bytes_per_launch, profiles_dir=None):
+    """The dominant kernel's kernel-only average from the builder's committed `rocprofv3 --kernel-trace --stats` run of the bench command
+    (the newest profiles/rN_kernel_stats_bench200*.csv; Llama-3-8B, bf16: gemv16_kernel<16, 8, XSRC_NORM, EPI_SWIGLU, bf16>), as extra keys
+    of the `roofline` object: a STORED cross-check beside the live HIP-event figure, labelled as such.  {} when there is no such file."""
+    import csv
+    import glob
+    try:
+        d = profiles_dir or os.path.join(ROOT, "profiles")
+        path = sorted(glob.glob(os.path.join(d, "r[0-9]*_kernel_stats_bench200*.csv")),
+                      key=lambda q: (int(os.path.basename(q)[1:].split("_")[0]), q))[-1]
+        row = next(r for r in csv.DictReader(open(path)) if r["kernel"].startswith("void gemv16_kernel<16, 8, 1, 3, 0"))
+        us = float(row["avg_us"])
+        return {"rocprof_avg_launch_us": us, "frac_rocprof": round(bytes_per_launch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                "rocprof_source": f"profiles/{os.path.basename(path)} ({row['calls']} launches; stored result of a rocprofv3 --kernel-trace --stats run, "
+                                  "NOT measured in this run)"}
+    except Exception:
+        return {}
+
+
 def aggregate_fps(frames_per_rank, world, elapsed_max):
     """whole-job frames/s: every rank streams ``frames_per_rank`` frames (weak scaling)."""
     return frames_per_rank * world / elapsed_max
@@ -520,21 +539,7 @@ def main():
                 traffic_source = "profiles/pmc_gemv_gate_up.json (stored result of a rocprofv3 --pmc run, NOT measured in this run)"
             except Exception:
                 traffic = None
-        # the same kernel's kernel-only average from the builder's committed `rocprofv3 --kernel-trace --stats` run of this command
-        # (the newest profiles/rN_kernel_stats_bench200*.csv): a stored cross-check beside the live figure, labelled as such
-        rocprof = {}
-        if args.model == "llama-3-8b" and args.weight_dtype == "bf16":
-            try:
-                import csv, glob
-                path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_kernel_stats_bench200*.csv")),
-                              key=lambda q: (int(os.path.basename(q)[1:].split("_")[0]), q))[-1]
-                row = next(r for r in csv.DictReader(open(path)) if r["kernel"].startswith("void gemv16_kernel<16, 8, 1, 3, 0"))
-                us = float(row["avg_us"])
-                rocprof = {"rocprof_avg_launch_us": us, "frac_rocprof": round(bytes_per_launch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                           "rocprof_source": f"profiles/{os.path.basename(path)} ({row['calls']} launches; stored result of a rocprofv3 --kernel-trace --stats run, "
-                                             "NOT measured in this run)"}
-            except Exception:
-                rocprof = {}
+        rocprof = rocprof_cross_check(bytes_per_launch) if args.model == "llama-3-8b" and args.weight_dtype == "bf16" else {}
         minutes = total / args.fps / 60.0
         out = {
             "metric": ("streaming FPS + p50 per-frame latency, Llama-3-8B+SigLIP-L, 10 min @ 2 FPS, 1/2/4/8 GPU"

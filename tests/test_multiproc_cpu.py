@@ -205,3 +205,20 @@ def test_bench_world_size_mismatch_fails_loudly():
     r = _run_bench(["--gpus", "8", "--steps", "2"], dict(VLO_BENCH_BACKEND="gloo", VLO_BENCH_DRY_RUN="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_roofline_rocprof_cross_check_reads_the_newest_committed_summary(tmp_path):
+    """bench.py's `roofline.frac_rocprof` is the kernel-only average of the gate/up GEMV from the newest committed
+    profiles/rN_kernel_stats_bench200*.csv (a stored figure, labelled as such) — newest by round number, not by string order."""
+    import bench
+    hdr = "kernel,calls,total_ms,avg_us,min_us,max_us,pct\n"
+    (tmp_path / "round1_kernel_stats_bench200.csv").write_text(hdr + '"void gemv16_kernel<16, 8, 1, 3, 0>(GemvArgs)",10,1.0,99.0,1,1,1\n')
+    (tmp_path / "r3_kernel_stats_bench200.csv").write_text(hdr + '"void gemv16_kernel<16, 8, 1, 3, 0>(GemvArgs)",10,1.0,50.0,1,1,1\n')
+    (tmp_path / "r12_kernel_stats_bench200.csv").write_text(
+        hdr + '"void gemv16_kernel<14, 8, 0, 0, 0, 1>(GemvArgs)",5,1.0,20.0,1,1,1\n"void gemv16_kernel<16, 8, 1, 3, 0, 1>(GemvArgs)",7,1.0,40.0,1,1,1\n')
+    got = bench.rocprof_cross_check(8000.0 * 40.0 * 1e3, profiles_dir=str(tmp_path))        # bytes that stream in 40 us at the 8 TB/s peak
+    assert got["rocprof_avg_launch_us"] == 40.0 and got["frac_rocprof"] == 1.0 and "r12_kernel_stats_bench200.csv (7 launches" in got["rocprof_source"]
+    assert "NOT measured in this run" in got["rocprof_source"]
+    assert bench.rocprof_cross_check(1.0, profiles_dir=str(tmp_path / "nothing_here")) == {}
+    real = bench.rocprof_cross_check(235286528.0)                                            # the file this repo ships
+    assert real and 0.5 < real["frac_rocprof"] < 1.0
