@@ -62,8 +62,6 @@ struct vlo_engine {
     std::vector<int> free_pages;
     std::mutex pool_mu;
 
-    void *pf_wexp = nullptr;                     // prefill path of an fp8 engine: bf16 expansion of ONE projection's image (the largest), reused per GEMM
-    size_t pf_wexp_bytes = 0;
 
     VitState *vit = nullptr;
     void *ingest = nullptr;                      // ingest.hip: cached tap tables + scratch of vlo_frame_ingest
@@ -99,7 +97,11 @@ struct vlo_session {
     // workspaces of the prefill path (blocks of up to VLO_PREFILL_TOKENS tokens as real GEMMs, prefill.h; allocated on first use):
     // residual stream, normed rows / attention output (the GEMMs' X operand: 256 spare rows), qkv projection, q after RoPE, MLP act
     unsigned short *ph = nullptr, *px = nullptr, *pqkv = nullptr, *pq = nullptr, *pact = nullptr;
-    float *ppart_o = nullptr, *ppart_ml = nullptr;   // attention partials of a whole prefill block: VLO_PREFILL_TOKENS / 16 sub-chunk states
+    float *ppart_o = nullptr, *ppart_ml = nullptr;   // attention partials of a whole prefill block (VLO_PREFILL_TOKENS / 16 sub-chunk states): only for the fallback kernel
+    // prefill path of an fp8 engine: bf16 expansion of ONE projection's image (the largest), rewritten before each GEMM.  Per SESSION: sessions
+    // step on streams of their own, a scratch shared through the engine would be overwritten under another session's GEMM
+    void *pf_wexp = nullptr;
+    size_t pf_wexp_bytes = 0;
 };
 
 int dev_alloc(void **p, size_t bytes);

@@ -761,15 +761,6 @@ static int ensure_prefill_ws(vlo_session *s) {
     struct { unsigned short **p; size_t elems; } want[] = {{&s->ph, R * H}, {&s->px, RX * std::max(H, qd)}, {&s->pqkv, R * (qd + 2 * kvd)},
                                                             {&s->pq, R * qd}, {&s->pact, RX * I}};
     HIP_TRY(hipSetDevice(e->device));
-    if (!s->ppart_o) {
-        void *po = nullptr, *pm = nullptr;
-        int rc = dev_alloc(&po, (size_t)(VLO_PREFILL_TOKENS / 16) * e->nh_l * 16 * e->head_dim * 4);
-        if (rc) return rc;
-        s->owned.push_back(po);
-        if ((rc = dev_alloc(&pm, (size_t)(VLO_PREFILL_TOKENS / 16) * e->nh_l * 16 * 2 * 4))) return rc;
-        s->owned.push_back(pm);
-        s->ppart_o = (float *)po; s->ppart_ml = (float *)pm;
-    }
     for (auto &w : want) {
         if (*w.p) continue;
         void *p = nullptr;
@@ -779,6 +770,21 @@ static int ensure_prefill_ws(vlo_session *s) {
         HIP_TRY(hipMemset(p, 0, w.elems * 2));  // the spare rows are read (and dropped) by the GEMMs: keep them finite
         *w.p = (unsigned short *)p;
     }
+    return VLO_OK;
+}
+
+// partial states for the fallback attention kernel (shapes attn_prefill_kernel is not instantiated for, VLO_PREFILL_FLASH=0): 67 MB at the 8B shape,
+// so only sessions that take the fallback pay for them
+static int ensure_prefill_partials(vlo_session *s) {
+    if (s->ppart_ml) return VLO_OK;
+    vlo_engine *e = s->e;
+    void *po = nullptr, *pm = nullptr;
+    int rc = dev_alloc(&po, (size_t)(VLO_PREFILL_TOKENS / 16) * e->nh_l * 16 * e->head_dim * 4);
+    if (rc) return rc;
+    s->owned.push_back(po);
+    if ((rc = dev_alloc(&pm, (size_t)(VLO_PREFILL_TOKENS / 16) * e->nh_l * 16 * 2 * 4))) return rc;
+    s->owned.push_back(pm);
+    s->ppart_o = (float *)po; s->ppart_ml = (float *)pm;
     return VLO_OK;
 }
 
@@ -800,17 +806,21 @@ static int run_prefill(vlo_session *s, const unsigned short *src, int m, bool wa
     // per weight against hundreds of tokens of MFMA work per weight — and its per-channel scales go to the GEMM's epilogue
     auto gemm = [&](const unsigned short *X, const PackedLinear &pl, int N, int K, unsigned short *out, int ldo, int kind) -> int {
         if (!pl.wq) { HIP_TRY(llm_gemm_launch(X, pl.Wp, m, N, K, out, ldo, kind, st)); return VLO_OK; }
-        const size_t need = (size_t)pl.NT * 16 * K * 2;
-        if (e->pf_wexp_bytes < need) {
-            HIP_TRY(hipStreamSynchronize(st));                       // (grows once: the largest projection)
+        // sized for the largest projection of a layer at the first use (not grown projection by projection); the lm_head image may grow it once more
+        const LayerWeights &L0 = e->layers[0];
+        const size_t img = (size_t)pl.NT * 16 * K * 2;
+        auto bytes = [](const PackedLinear &q) { return (size_t)q.NT * 16 * q.K * 2; };
+        const size_t need = std::max({img, bytes(L0.qkv), bytes(L0.o), bytes(L0.gate_up), bytes(L0.down)});
+        if (s->pf_wexp_bytes < need) {
+            HIP_TRY(hipStreamSynchronize(st));                       // (grows at most a few times: up to the largest projection)
             void *p = nullptr;
             int rc2 = dev_alloc(&p, need);
             if (rc2) return rc2;
-            e->owned.push_back(p);
-            e->pf_wexp = p; e->pf_wexp_bytes = need;
+            s->owned.push_back(p);
+            s->pf_wexp = p; s->pf_wexp_bytes = need;
         }
-        HIP_TRY(expand_fp8_image_launch(pl.Wp, e->pf_wexp, pl.NT, K, st));
-        HIP_TRY(llm_gemm_launch(X, e->pf_wexp, m, N, K, out, ldo, kind, st, pl.wscale));
+        HIP_TRY(expand_fp8_image_launch(pl.Wp, s->pf_wexp, pl.NT, K, st));
+        HIP_TRY(llm_gemm_launch(X, s->pf_wexp, m, N, K, out, ldo, kind, st, pl.wscale));
         return VLO_OK;
     };
     for (int l = 0; l < c.num_layers; ++l) {
@@ -822,7 +832,10 @@ static int run_prefill(vlo_session *s, const unsigned short *src, int m, bool wa
         // one split each); the output lands in px (the o-proj's X operand)
         static const bool flash = getenv("VLO_PREFILL_FLASH") ? atoi(getenv("VLO_PREFILL_FLASH")) != 0 : true;
         hipError_t ae = flash ? attention_prefill_launch(s->pq, kv, l, nh, s->len, m, s->px, st) : hipErrorNotSupported;
-        if (ae == hipErrorNotSupported) ae = attention_launch(s->pq, kv, l, nh, s->len, m, s->ppart_o, s->ppart_ml, s->px, st, -1, VLO_PREFILL_TOKENS / 16);
+        if (ae == hipErrorNotSupported) {
+            if ((rc = ensure_prefill_partials(s))) return rc;
+            ae = attention_launch(s->pq, kv, l, nh, s->len, m, s->ppart_o, s->ppart_ml, s->px, st, -1, VLO_PREFILL_TOKENS / 16);
+        }
         HIP_TRY(ae);
         if ((rc = gemm(s->px, L.o, H, qd, s->ph, H, LLM_GEMM_RESID))) return rc;
         HIP_TRY(add_rmsnorm_launch(s->ph, nullptr, 0, H, (const unsigned short *)L.ln_post, s->px, H, H, c.rms_eps, m, st));
