@@ -713,7 +713,7 @@ def test_prefill_path_gemms_in_emulation(E, shape):
     ref, gold = O.LlamaOracle(spec, w, torch.bfloat16), O.LlamaOracle(spec, w, torch.float32)
     os.environ["VLO_EMUL_GLDS"] = "late"
     try:
-        eng = E.EmulEngine(spec, kv_pool_tokens=1024).load_weights(w, O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+        eng = E.EmulEngine(spec, kv_pool_tokens=2048).load_weights(w, O.rope_inv_freq(spec.head_dim, spec.rope_theta))     # three sessions of <= 312 tokens
         s = eng.new_session()
         g = torch.Generator().manual_seed(4)
         rc = gc = None
@@ -732,10 +732,17 @@ def test_prefill_path_gemms_in_emulation(E, shape):
         s2 = eng.new_session()
         _, again = eng.llm_step(s2, first[0])
         assert torch.equal(again, first[1])
+        # ... and so is the experimental one-column-tile kernel (128 columns per workgroup, four waves per SIMD; opt-in)
+        os.environ.pop("VLO_ATTN_NOSKIP")
+        os.environ["VLO_ATTN_NCT"] = "1"
+        s3 = eng.new_session()
+        _, again = eng.llm_step(s3, first[0])
+        assert torch.equal(again, first[1])
         eng.close()
     finally:
         os.environ.pop("VLO_EMUL_GLDS", None)
         os.environ.pop("VLO_ATTN_NOSKIP", None)
+        os.environ.pop("VLO_ATTN_NCT", None)
 
 
 VIT_TILES_CHILD = r"""

@@ -347,157 +347,21 @@ VLO_DEV float quad_lanes_maxf(float x) {
 template <int HD, int G, int NS>
 __global__ __launch_bounds__(512) void attn_prefill_kernel(const bf16_t *__restrict__ q, KvGeom kv, int layer, int nh, int64_t pos0, int n, float scale,
                                                            bf16_t *__restrict__ out, int noskip) {
-    constexpr int NKK = HD / 32, NDT = HD / 16, QB = 256 / G, NCT = 2;
-    constexpr int PK = 2 * NKK, PV = NDT, PIECES = PK + PV;             // 1-KiB pieces of one key tile: K (t, kk) then V^T (dt)
-    static_assert(PIECES % 8 == 0, "eight waves share the staging");
-    constexpr int PPW = PIECES / 8;
-    constexpr int AHEAD = NS - 1;                                         // tiles issued ahead of the one being multiplied
-    __shared__ __attribute__((aligned(16))) char tile[NS][PIECES * 1024];
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int col = lane & 15, qd = lane >> 4;
-    const int kvh = blockIdx.y;
-    const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;                  // the longest key ranges start first
-    const int q0 = qb * QB;
-    // this wave's two column tiles: column cc = 32 w + 16 ct + col -> query q0 + cc / G, head kvh G + cc % G
-    int qi[NCT], hh[NCT], qpos[NCT];
-    frag_ab qf[NCT][NKK];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-        const int cc = w * 32 + ct * 16 + col;
-        qi[ct] = q0 + cc / G;
-        hh[ct] = kvh * G + cc % G;
-        qpos[ct] = (int)pos0 + min(qi[ct], n - 1);
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) {
-            frag_ab z = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (qi[ct] < n) z = *reinterpret_cast<const frag_ab *>(q + (size_t)qi[ct] * nh * HD + (size_t)hh[ct] * HD + kk * 32 + qd * 8);
-            qf[ct][kk] = z;
-        }
-    }
-    f32x4 O[NCT][NDT];
-    float mrun[NCT], lrun[NCT];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-        mrun[ct] = -INFINITY;
-        lrun[ct] = 0.f;
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) O[ct][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    const bf16_t *kbase = kv.k_pool + (size_t)layer * kv.layer_stride;
-    const bf16_t *vbase = kv.vt_pool + (size_t)layer * kv.layer_stride;
-    // keys this workgroup needs: [0, pos0 + last query of the block]
-    const int L = (int)pos0 + min(q0 + QB, n);
-    const int ntiles = (L + 31) >> 5;
-    // stage key tile kt into buffer b: this wave's PPW pieces.  Piece p < PK: K (t = p / NKK, kk = p % NKK): lane (c = qd, r = col) fetches
-    // bytes [(4 kk + c) 16, + 16) of key row (r >> 2) * 8 + (r & 3) + 4 t; piece PK + dt: V^T rows 16 dt + r, keys 8 c .. 8 c + 7.
-    // The page ids travel in a register, one per lane for 64 consecutive pages (16 384 keys), and reach the staging code by a shuffle: a
-    // page-table read inside the loop is a VECTOR load for hipcc (the kernel stores to global memory, so nothing is provably scalar), and the
-    // s_waitcnt vmcnt(0) it puts in front of the value's first use would drain the whole ring of direct-to-LDS tiles on every iteration.  The
-    // refill every 512 tiles waits for its load INSIDE its branch (the empty asm consumes the value), so that no wait is left at the join.
-    const int npages = (L + VLO_PAGE_TOKENS - 1) / VLO_PAGE_TOKENS;
-    int ptv = lane < npages ? kv.page_table[lane] : 0, ptchunk = 0;
-    asm volatile("" : "+v"(ptv));
-    auto stage = [&](int kt, int b) {
-        const int kt0 = kt * 32;
-        const int pg = kt0 / VLO_PAGE_TOKENS, tok0 = kt0 % VLO_PAGE_TOKENS;       // a 32-key tile never straddles a 256-token page
-        if ((pg >> 6) != ptchunk) {
-            ptchunk = pg >> 6;
-            ptv = ptchunk * 64 + lane < npages ? kv.page_table[ptchunk * 64 + lane] : 0;
-            asm volatile("" : "+v"(ptv));
-        }
-        const int page = __builtin_amdgcn_readfirstlane(__shfl(ptv, pg & 63, 64));
-        const bf16_t *kp = kbase + (size_t)page * kv.page_elems + ((size_t)kvh * VLO_PAGE_TOKENS + tok0) * HD;
-        const bf16_t *vp = vbase + (size_t)page * kv.page_elems + ((size_t)kvh * HD) * VLO_PAGE_TOKENS + tok0;
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int p = w * PPW + i;                                      // wave-uniform
-            const bf16_t *src;
-            if (p < PK) {
-                const int t = p / NKK, kk = p - t * NKK;
-                src = kp + (size_t)((col >> 2) * 8 + (col & 3) + 4 * t) * HD + (kk * 4 + qd) * 8;
-            } else {
-                src = vp + (size_t)((p - PK) * 16 + col) * VLO_PAGE_TOKENS + qd * 8;
-            }
-            glds16_untracked(src, &tile[b][p * 1024]);
-        }
-    };
-    for (int s = 0; s < AHEAD && s < ntiles; ++s) stage(s, s);
-    for (int kt = 0, b = 0; kt < ntiles; ++kt, b = (b + 1 == NS ? 0 : b + 1)) {
-        // this wave's pieces of tile kt have landed (the AHEAD - 1 younger tiles stay in flight; the last tiles of the range: everything) ...
-        if (kt + AHEAD - 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * PPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // ... and, behind the barrier, everybody's; everybody is also done with tile kt - 1, whose buffer the next stage overwrites.  A RAW barrier:
-        // __syncthreads() may come with a vmcnt(0) of its own
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + AHEAD < ntiles) stage(kt + AHEAD, b == 0 ? NS - 1 : b - 1);
-        const frag_ab *fr = reinterpret_cast<const frag_ab *>(&tile[b][0]) + lane;
-        const int kb = kt * 32 + qd * 8;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-                s0 = mfma_bf16(fr[(0 * NKK + kk) * 64], qf[ct][kk], s0);
-                s1 = mfma_bf16(fr[(1 * NKK + kk) * 64], qf[ct][kk], s1);
-            }
-            float v[8];
-            if (!noskip && !__any(kt * 32 + 31 > qpos[ct])) {                 // every key of the tile is visible to every query of the wave
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = s0[r] * scale;
-                    v[4 + r] = s1[r] * scale;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = (kb + r <= qpos[ct]) ? s0[r] * scale : -INFINITY;
-                    v[4 + r] = (kb + 4 + r <= qpos[ct]) ? s1[r] * scale : -INFINITY;
-                }
-            }
-            float tmax = v[0];
-#pragma unroll
-            for (int j = 1; j < 8; ++j) tmax = fmaxf(tmax, v[j]);
-            tmax = quad_lanes_maxf(tmax);
-            const float m_new = fmaxf(mrun[ct], tmax);
-            const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __expf(mrun[ct] - m_safe);
-            const bool rescale = noskip || __any(m_new != mrun[ct]);         // wave-uniform; nobody's maximum moved: alpha == 1 (or 0 on all-zero rows)
-            mrun[ct] = m_new;
-            float psum = 0.f;
-            float pr[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                pr[j] = __expf(v[j] - m_safe);
-                psum += pr[j];
-            }
-            const frag_ab pb = __builtin_bit_cast(frag_ab, make_uint4(pack2bf(pr[0], pr[1]), pack2bf(pr[2], pr[3]), pack2bf(pr[4], pr[5]), pack2bf(pr[6], pr[7])));
-            lrun[ct] = lrun[ct] * alpha + psum;
-            if (rescale) {
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-                    O[ct][dt][0] *= alpha; O[ct][dt][1] *= alpha; O[ct][dt][2] *= alpha; O[ct][dt][3] *= alpha;
-                }
-            }
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) O[ct][dt] = mfma_bf16(fr[(PK + dt) * 64], pb, O[ct][dt]);
-        }
-    }
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-        float l = lrun[ct];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        if (qi[ct] >= n) continue;
-        bf16_t *orow = out + (size_t)qi[ct] * nh * HD + (size_t)hh[ct] * HD;
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            const f32x4 o = O[ct][dt];
-            bf16_t o4[4] = {f2bf(o[0] / l), f2bf(o[1] / l), f2bf(o[2] / l), f2bf(o[3] / l)};
-            *reinterpret_cast<ushort4 *>(orow + dt * 16 + qd * 4) = *reinterpret_cast<const ushort4 *>(o4);
-        }
-    }
+#define VLO_PF_NCT 2
+#include "attn_prefill_body.inc"
+#undef VLO_PF_NCT
+}
+
+// EXPERIMENTAL, opt-in (VLO_ATTN_NCT=1), NOT yet run on hardware: the same body with ONE column tile per wave — 128 columns per workgroup, a register
+// budget of 128 (four waves per SIMD instead of two) at twice the LDS read traffic per FLOP.  DESIGN.md section 8.4: the shipping kernel is a
+// per-wave latency chain that two waves per SIMD cannot hide; this is the variant to measure first.  Bit-identical to the shipping kernel by
+// construction (a column's arithmetic does not depend on its neighbours; the wave-uniform shortcuts are exact), checked in the emulation.
+template <int HD, int G, int NS>
+__global__ __launch_bounds__(512, 4) void attn_prefill_1ct_kernel(const bf16_t *__restrict__ q, KvGeom kv, int layer, int nh, int64_t pos0, int n, float scale,
+                                                                  bf16_t *__restrict__ out, int noskip) {
+#define VLO_PF_NCT 1
+#include "attn_prefill_body.inc"
+#undef VLO_PF_NCT
 }
 
 hipError_t attention_prefill_launch(const unsigned short *q, KvGeom kv, int layer, int num_heads, int64_t pos0, int n, unsigned short *out, hipStream_t st) {
@@ -505,11 +369,17 @@ hipError_t attention_prefill_launch(const unsigned short *q, KvGeom kv, int laye
     if (n <= 0 || nkv * G != num_heads) return hipErrorInvalidValue;
     const float scale = 1.0f / sqrtf((float)hd);
     static const int kStages = getenv("VLO_ATTN_STAGES") ? atoi(getenv("VLO_ATTN_STAGES")) : 4;      // tile buffers in the ring (2: one tile in flight)
+    const char *nct = getenv("VLO_ATTN_NCT");                              // 1: the experimental one-column-tile kernel (read per call, as noskip)
+    const int kNct = nct ? atoi(nct) : 2;
     const char *ns = getenv("VLO_ATTN_NOSKIP");                            // read per call: the tests flip it between two passes over the same input
     const int noskip = ns && atoi(ns) != 0;
 #define VLO_ATTN_PF(HD_, G_)                                                                                                          \
     do {                                                                                                                              \
         constexpr int QB_ = 256 / G_;                                                                                                 \
+        if (kNct == 1) {                                                                                                              \
+            hipLaunchKernelGGL((attn_prefill_1ct_kernel<HD_, G_, 4>), dim3((n + QB_ / 2 - 1) / (QB_ / 2), nkv), dim3(512), 0, st, q, kv, layer, num_heads, pos0, n, scale, out, noskip); \
+            return hipGetLastError();                                                                                                 \
+        }                                                                                                                             \
         if (kStages == 2) hipLaunchKernelGGL((attn_prefill_kernel<HD_, G_, 2>), dim3((n + QB_ - 1) / QB_, nkv), dim3(512), 0, st, q, kv, layer, num_heads, pos0, n, scale, out, noskip); \
         else hipLaunchKernelGGL((attn_prefill_kernel<HD_, G_, 4>), dim3((n + QB_ - 1) / QB_, nkv), dim3(512), 0, st, q, kv, layer, num_heads, pos0, n, scale, out, noskip); \
         return hipGetLastError();                                                                                                     \
