@@ -305,7 +305,7 @@ def main():
     ap.add_argument("--prefetch-frames", type=int, default=56,
                     help="frames encoded ahead per batched ViT call while the Llama steps run (the reference batches pending frames the same way, "
                          "demo/inference.py:105-106).  56 frames = 32256 token rows = 126 row tiles of 256: every GEMM of the tower is a whole "
-                         "number of 256-CU rounds within 2 % (504 / 1512 / 2016 tiles); 28 frames give 252 / 756 / 1008")
+                         "number of 256-CU rounds within 2 %% (504 / 1512 / 2016 tiles); 28 frames give 252 / 756 / 1008")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-feed", action="store_true", help="skip the two no-look-ahead re-runs of the timed frames (`live_feed`)")
     ap.add_argument("--cpu-sample-frames", type=int, default=20)

@@ -222,3 +222,12 @@ def test_roofline_rocprof_cross_check_reads_the_newest_committed_summary(tmp_pat
     assert bench.rocprof_cross_check(1.0, profiles_dir=str(tmp_path / "nothing_here")) == {}
     real = bench.rocprof_cross_check(235286528.0)                                            # the file this repo ships
     assert real and 0.5 < real["frac_rocprof"] < 1.0
+
+
+def test_bench_help_renders():
+    """argparse formats every help string with %: an unescaped per-cent sign in one of them made `bench.py --help` raise (found in round 4)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "--prefetch-frames" in r.stdout, r.stderr[-2000:]
