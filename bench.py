@@ -488,10 +488,12 @@ def main():
             li.prefetch, li.prefetch_frames = pf, pfn
             el, cs, _, st_n = run(preroll, total)
             el = reduce_elapsed_max(dist, el, device="cuda" if backend == "nccl" else "cpu")
-            if args.mode != "free":       # a fixed schedule: exactly the same Llama steps as the timed region
-                assert len(li.past_key_values) == final_len and st_n == llm_steps, (len(li.past_key_values), final_len, st_n, llm_steps)
             live_feed[name] = {"frames_per_s": round(aggregate_fps(K, world, el), 3), "p50_frame_latency_ms": round(statistics.median(cs) * 1e3, 4),
                                "p95_frame_latency_ms": round(sorted(cs)[int(0.95 * (len(cs) - 1))] * 1e3, 4)}
+            # a fixed schedule replays exactly the Llama steps of the timed region; a secondary figure must never cost the line above, so a
+            # mismatch is reported inside the object instead of raised
+            if args.mode != "free" and not (len(li.past_key_values) == final_len and st_n == llm_steps):
+                live_feed[name]["mismatch"] = f"KV {len(li.past_key_values)} vs {final_len} tokens, {st_n} vs {llm_steps} Llama steps"
             log(f"live_feed {name}: {K / el:.1f} frames/s, p50 {statistics.median(cs) * 1e3:.2f} ms")
         li.prefetch, li.prefetch_frames = saved
         live_feed["note"] = (f"the same {K} frames from the same context ({kv_start} cached tokens, KV cropped back) with the encoder on the critical path: "
