@@ -44,3 +44,13 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_terminal_summary(terminalreporter):
+    """The margin under the 3-way logit band (tests/parity_util.BAND), visible in every gate log: the worst recorded ratios."""
+    from tests import parity_util as P
+    if not P.RATIOS:
+        return
+    worst = sorted(P.RATIOS, key=lambda t: -t[0])[:6]
+    terminalreporter.write_line(f"[parity band] {len(P.RATIOS)} three-way checks, band {P.BAND}: worst (err - slack) / reference-err = "
+                                + ", ".join(f"{t[0]:.3f} ({t[4]})" for t in worst))

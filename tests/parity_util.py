@@ -32,3 +32,17 @@ def fmt(rep: dict) -> str:
     return (f"bit-equal {rep['bit_equal']:.1%}  <=1ulp {rep['within_1ulp']:.1%}  <=2ulp {rep['within_2ulp']:.1%}  "
             f"max {rep['max_ulps_scale']:.2f} ulps@scale ({rep['max_abs']:.4g} abs, scale {rep['scale']:.3g})  "
             f"max local {rep['max_ulps_local']:.1f} ulps")
+
+
+# ---- the 3-way logit band, one definition -------------------------------------------------------------------------------------
+# err(engine, fp32 gold) <= BAND * err(reference-precision path, fp32 gold) + slack.  Round 4's verdict measured every ratio at
+# 0.86 - 1.19 and asked for the 25 % of unused slack in the old 1.5 to go; every check is recorded and the worst ratios of a run
+# are printed in the pytest summary (tests/conftest.py), so the margin under the band is visible in every gate log.
+BAND = 1.25
+RATIOS = []
+
+
+def within_band(e, r, slack=0.0, tag=""):
+    """True iff e <= BAND * r + slack; records (e - slack) / r for the run summary."""
+    RATIOS.append((max(e - slack, 0.0) / r if r > 0 else (0.0 if e <= slack else float("inf")), e, r, slack, tag))
+    return e <= BAND * r + slack

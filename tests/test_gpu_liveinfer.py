@@ -3,6 +3,8 @@ free-running sampler semantics on a toy model, same frames / ids / query."""
 import pytest
 import torch
 
+from tests.parity_util import within_band
+
 from oracle import vlo_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -158,7 +160,7 @@ def test_cfg1_true_shapes_60_frame_stream():
         e = (le - lg[-1]).abs().max().item()
         r = (lr[-1].float() - lg[-1]).abs().max().item()
         s = lg[-1].abs().max().item()
-        assert e <= 1.5 * r + 1e-3 * s + 0.02, (len(rc), e, r, s)
+        assert within_band(e, r, 1e-3 * s + 0.02, "test_gpu_liveinfer.py:161"), (len(rc), e, r, s)
         worst = max(worst, (e, r))
         margin, _ = O.top2_margin(lg[-1])
         if margin >= NEAR_TIE:

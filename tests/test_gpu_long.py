@@ -8,8 +8,9 @@ restatement of demo/inference.py:40-123 teacher-forced with the engine's own tok
 and every greedy token must be the reference-bf16 path's, except at a near-tie of the reference's own logits where the engine
 may pick another of the tied candidates (rule in Follower._judge; DESIGN.md §2 states it and its history).
 
-OPT-IN (VLO_LONG_TESTS=1, ~23 minutes on an MI355X box, most of it the oracle following two 1 200-frame traces; numbers kept in
-profiles/r*_parity_measurements.txt):
+OPT-IN (VLO_LONG_TESTS=1; numbers kept in profiles/r*_parity_measurements.txt).  The follower of the 1 200-frame traces is the
+oracle's code executed by torch on the GPU (VLO_FOLLOWER_DEVICE=cuda, the default for these cases: a few minutes in all);
+VLO_FOLLOWER_DEVICE=cpu follows on the host cores as the 150-frame slice does (~23 minutes on an MI355X box):
 * the same trace over all 1 200 frames (KV to > 13 k tokens);
 * config 3's context: all-row logits 3-way at 66 000 cached tokens (narrow 3-layer model with the 8B head geometry);
 * tensor-parallel logical ranks T = 8 at 13 k cached tokens.
@@ -22,7 +23,7 @@ import pytest
 import torch
 
 from oracle import vlo_oracle as O
-from tests.parity_util import fmt, ulp_report
+from tests.parity_util import fmt, ulp_report, within_band
 from videollm_online_amd.trace import FRAME, RESPONSE, FrameEvent, ResponseEvent      # the ONE event schema
 
 pytestmark = pytest.mark.gpu
@@ -44,12 +45,13 @@ class Follower(O.LiveInferOracle):
         self.emb = engine_embeds
         self.stats = collections.Counter()
         self.flip_margins = []
+        self.dev = llm.W["model.embed_tokens.weight"].device     # cpu (default suite) or cuda (the 1 200-frame runs: VLO_FOLLOWER_DEVICE)
 
     def input_video_stream(self, video_time):
         frame_idx = int(video_time * self.frame_fps)
         if frame_idx > self.last_frame_idx:
             for r in range(self.last_frame_idx + 1, frame_idx + 1):
-                self.frame_embeds_queue.append((r / self.frame_fps, self.emb[r]))
+                self.frame_embeds_queue.append((r / self.frame_fps, self.emb[r].to(self.dev)))
         self.last_frame_idx = frame_idx
         self.video_time = video_time
 
@@ -82,7 +84,7 @@ class Follower(O.LiveInferOracle):
             elif self.last_ids == [self.tok.eos_token_id]:
                 self.last_ids = self.last_ids + list(self.tok.stream_prompt_ids)
             H = self.llm.spec.hidden_size
-            inputs = torch.cat([self.llm.embed(torch.tensor(self.last_ids, dtype=torch.long)).view(-1, H), frame_embeds.view(-1, H)], dim=0)
+            inputs = torch.cat([self.llm.embed(torch.tensor(self.last_ids, dtype=torch.long, device=self.dev)).view(-1, H), frame_embeds.view(-1, H)], dim=0)
             logits, self.past_key_values = self.llm.forward(inputs, self.past_key_values)
             self._frames_done += 1
             if self.query_queue and video_time >= self.query_queue[0][0]:
@@ -102,7 +104,7 @@ class Follower(O.LiveInferOracle):
         assert ev.kind == RESPONSE and ev.video_time == video_time and ev.query == query, (ev[:3], video_time, query)
         self.last_ids = list(self.tok.query_ids[query]) if query is not None else list(self.tok.stream_generation_ids)
         forced = self.schedule(self._frames_done - 1) if self.schedule is not None else None
-        x = self.llm.embed(torch.tensor(self.last_ids))
+        x = self.llm.embed(torch.tensor(self.last_ids, device=self.dev))
         eos, V = self.tok.eos_token_id, self.llm.spec.vocab_size
         for i, t in enumerate(ev.output_ids):
             logits, self.past_key_values = self.llm.forward(x, self.past_key_values)
@@ -115,7 +117,7 @@ class Follower(O.LiveInferOracle):
             if not (forced is not None and i == len(ev.output_ids) - 1):
                 self._judge("greedy", mine, t, logits[-1])
             if i < len(ev.output_ids) - 1:
-                x = self.llm.embed(torch.tensor([t]))
+                x = self.llm.embed(torch.tensor([t], device=self.dev))
         if forced is None:
             assert ev.output_ids[-1] == eos or len(ev.output_ids) == self.max_new
         self.last_ids = list(ev.output_ids[-1:])
@@ -131,10 +133,11 @@ def test_liveinfer_150_frame_slice_is_the_reference_trace(mode):
 @long_only
 @pytest.mark.parametrize("mode", ["scheduled", "free"])
 def test_liveinfer_1200_frame_stream_is_the_reference_trace(mode):
-    _trace_vs_reference(mode, int(os.environ.get("VLO_LONG_FRAMES", "1200")), prefetch_frames=int(os.environ.get("VLO_LONG_PREFETCH", "56")))
+    _trace_vs_reference(mode, int(os.environ.get("VLO_LONG_FRAMES", "1200")), prefetch_frames=int(os.environ.get("VLO_LONG_PREFETCH", "56")),
+                        follower_device=os.environ.get("VLO_FOLLOWER_DEVICE", "cuda"))
 
 
-def _trace_vs_reference(mode, T, prefetch_frames):
+def _trace_vs_reference(mode, T, prefetch_frames, follower_device="cpu"):
     from videollm_online_amd.engine import Engine, EngineConfig
     from videollm_online_amd.inference import LiveInfer, StreamTokens
     from videollm_online_amd.modeling_live import LiveModel
@@ -183,7 +186,10 @@ def _trace_vs_reference(mode, T, prefetch_frames):
     assert kv_end == sum(n for _, n in li.step_log)
     emb_cpu = {k: v.cpu() for k, v in embeds.items()}
     assert sorted(emb_cpu) == list(range(T))
-    f = Follower(O.LlamaOracle(spec, w, torch.bfloat16), toks, vspec.frame_num_tokens, trace, emb_cpu, schedule=sched, max_new=max_new)
+    # the follower is the oracle's code either on the CPU (default suite) or executed by torch on the GPU (_gpu_oracles' argument: the
+    # same operations and rounding points, another bf16 summation order — what turns ~20 minutes of following 1 200 frames into ~2)
+    fw = w if follower_device == "cpu" else {k: v.to(follower_device) for k, v in w.items()}
+    f = Follower(O.LlamaOracle(spec, fw, torch.bfloat16), toks, vspec.frame_num_tokens, trace, emb_cpu, schedule=sched, max_new=max_new)
     f.load_video(torch.empty(T, 0))
     f.input_query_stream(query, video_time=0.0)
     for i in range(T):
@@ -246,7 +252,7 @@ def test_config3_context_66k_logits_parity():
         e, r, scale = _three_way(allr, rl, gl)
         rep = ulp_report(allr, rl)
         print(f"[toy128 3 layers] Lc={Lc} {kind}: engine err {e:.4g} ref-bf16(gpu torch) err {r:.4g} scale {scale:.3g} | engine vs ref-bf16: {fmt(rep)}")
-        assert e <= 1.5 * r + 1e-3 * scale, f"Lc={Lc} {kind}: engine err {e} vs reference-bf16 err {r}"
+        assert within_band(e, r, 1e-3 * scale, "test_gpu_long.py:249"), f"Lc={Lc} {kind}: engine err {e} vs reference-bf16 err {r}"
         assert rep["max_ulps_scale"] <= MAX_ULPS_AT_SCALE, fmt(rep)
         Lc += x.shape[0]
     assert len(sess) == len(rc) == Lc
@@ -300,7 +306,7 @@ def test_tensor_parallel_8_logical_ranks_at_13k_context():
             torch.cuda.synchronize()
             e, r, scale = _three_way(last.cpu(), rl[-1].cpu(), gl[-1].cpu())
             print(f"[TP=8 logical, {allreduce}] Lc={Lc} {kind}: engine err {e:.4g} ref-bf16(gpu torch) err {r:.4g} scale {scale:.3g}")
-            assert e <= 1.5 * r + 1e-3 * scale, (allreduce, kind, e, r)
+            assert within_band(e, r, 1e-3 * scale, "test_gpu_long.py:303"), (allreduce, kind, e, r)
             rc, gc = rc_n, gc_n
             Lc += x.shape[0]
         sess.close()

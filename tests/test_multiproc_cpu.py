@@ -4,6 +4,8 @@ import socket
 import sys
 
 import torch
+
+from tests.parity_util import within_band
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -173,7 +175,7 @@ def test_tp_data_path_two_processes_rccl_standin():
         assert np.array_equal(a, b), f"step {i}: the two ranks hold different logits"
         e = np.abs(a - gl.numpy()).max()
         r = (rl.float() - gl).abs().max().item()
-        assert e <= 1.5 * r + 1e-3 * gl.abs().max().item(), f"step {i}: engine err {e} vs reference-bf16 err {r}"
+        assert within_band(e, r, 1e-3 * gl.abs().max().item(), "test_multiproc_cpu.py:176"), f"step {i}: engine err {e} vs reference-bf16 err {r}"
     assert res[0][2] >= 0.0 and res[1][2] >= 0.0
     # frame-parallel encode + all-gather == every rank encoding every frame (north_star's frame-embedding broadcast)
     assert all(v[0] for v in vit.values()), f"frame-parallel and replicated vision embeddings differ: {vit}"
