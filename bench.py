@@ -107,7 +107,7 @@ def make_schedule(mode):
     return None
 
 
-def cpu_baseline(model_name, frames_u8_cpu, toks, mode, sample_frames, budget_s=25.0, windows=()):
+def cpu_baseline(model_name, frames_u8_cpu, toks, mode, sample_frames, budget_s=25.0, windows=(), window_13k_frames=0):
     """The CPU oracle (a port of the reference's CPU/sdpa path: bf16 Llama, fp32 SigLIP) on the first
     ``sample_frames`` frames of the same stream.  Timing-equivalent weights: one random layer aliased
     across all layers (values do not affect CPU time, and 15 GB of distinct random numbers would take
@@ -152,24 +152,43 @@ def cpu_baseline(model_name, frames_u8_cpu, toks, mode, sample_frames, budget_s=
                            toks.interval_id, dict(toks.query_ids))
     sched = make_schedule(mode)                 # the GPU line's schedule: 16-token responses
     win = []
-    for Lc in windows:
-        # BASELINE.md section 4: 10-frame windows deep in the stream, the KV cache pre-filled with random keys / values (their values
-        # do not affect CPU time); the window's last frame is answered as the schedule says.  Reported as windows, never extrapolated.
-        lw = O.LiveInferOracle(llm, vw, vspec, otoks, frame_fps=2, schedule=sched, max_new=16)
-        lw.load_video(frames_u8_cpu[:10])
+    window_13k = None
+    kv_blk = None
+
+    def prefilled(Lc):
+        # a KV cache of Lc tokens: ONE random block aliased across layers and between K and V (values do not affect CPU time; the
+        # oracle's cache grows by torch.cat, never in place, so the shared source stays intact)
+        nonlocal kv_blk
+        if kv_blk is None or kv_blk.shape[1] < Lc:
+            kv_blk = torch.randn(spec.num_kv_heads, Lc, hd, generator=g).to(bf)
         cache = llm.new_cache()
         for i in range(spec.num_layers):
-            cache.k[i] = torch.randn(spec.num_kv_heads, Lc, hd, generator=g).to(bf)
-            cache.v[i] = torch.randn(spec.num_kv_heads, Lc, hd, generator=g).to(bf)
-        lw.past_key_values, lw.last_ids = cache, [toks.interval_id]
+            cache.k[i] = kv_blk[:, :Lc]
+            cache.v[i] = kv_blk[:, :Lc]
+        return cache
+
+    def window(Lc, nframes):
+        lw = O.LiveInferOracle(llm, vw, vspec, otoks, frame_fps=2, schedule=sched, max_new=16)
+        lw.load_video(frames_u8_cpu[:nframes])
+        lw.past_key_values, lw.last_ids = prefilled(Lc), [toks.interval_id]
         t0 = time.time()
-        for i in range(10):
+        for i in range(nframes):
             lw.input_video_stream(i / 2)
             lw()
         dt = time.time() - t0
-        win.append({"kv_tokens_at_start": Lc, "kv_tokens_at_end": len(lw.past_key_values), "frames": 10, "frames_per_s": round(10 / dt, 4)})
-        log(f"cpu_baseline window at Lc={Lc}: {10 / dt:.3f} frames/s")
-        del lw, cache
+        log(f"cpu_baseline window at Lc={Lc}: {nframes} frames, {nframes / dt:.3f} frames/s")
+        return {"kv_tokens_at_start": Lc, "kv_tokens_at_end": len(lw.past_key_values), "frames": nframes, "frames_per_s": round(nframes / dt, 4)}
+
+    if window_13k_frames > 0:
+        # the context the GPU line is timed at (configs[1]'s last frames): `window_13k_frames` un-answered frame steps (encode + the
+        # 11-token Llama step over ~13.2 k cached tokens) inside the baseline's time budget — the figure to read next to `value`
+        window_13k = window(13245, window_13k_frames)
+        window_13k["note"] = ("frame steps only (SigLIP-L encode + an 11-token Llama step; no response falls inside the window) at the cache length the "
+                              "GPU line's timed frames start from; KV pre-filled with random values")
+    for Lc in windows:
+        # BASELINE.md section 4: 10-frame windows deep in the stream, the KV cache pre-filled with random keys / values (their values
+        # do not affect CPU time); the window's last frame is answered as the schedule says.  Reported as windows, never extrapolated.
+        win.append(window(Lc, 10))
     li = O.LiveInferOracle(llm, vw, vspec, otoks, frame_fps=2, schedule=sched, max_new=16)
     li.load_video(frames_u8_cpu)
     li.input_query_stream("Please narrate the video in real time.", video_time=0.0)
@@ -185,6 +204,7 @@ def cpu_baseline(model_name, frames_u8_cpu, toks, mode, sample_frames, budget_s=
     dt = time.time() - t0
     sample_frames = done
     return {"value": round(sample_frames / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            **({"window_13k": window_13k} if window_13k else {}),
             **({"windows": win, "windows_note": "10-frame windows of the same stream with the KV cache pre-filled (random) to the given length; "
                                                 "each window's last frame is answered with a 16-token response"} if win else {}),
             "port_vs_reference": "profiles/r3_port_vs_reference_cpu.txt: the port runs at 0.85-1.07x the time of the reference's own classes "
@@ -309,6 +329,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-feed", action="store_true", help="skip the two no-look-ahead re-runs of the timed frames (`live_feed`)")
     ap.add_argument("--cpu-sample-frames", type=int, default=20)
+    ap.add_argument("--cpu-budget-s", type=float, default=12.0, help="time budget of the CPU baseline's from-the-start sample (its frame loop stops once it is spent)")
+    ap.add_argument("--cpu-window-13k-frames", type=int, default=3, help="`cpu_baseline.window_13k`: this many un-answered frame steps of the CPU path at 13 245 "
+                    "cached tokens (the context the GPU line is timed at), ~4.5 s per frame on 16 cores; 0 = skip")
     ap.add_argument("--cpu-windows", default="", help="comma-separated cache lengths (e.g. 1024,4096,13312): the CPU baseline additionally times "
                                                       "10-frame windows with the KV cache pre-filled to these lengths (BASELINE.md section 4); "
                                                       "~15-40 s of CPU time each at the 8B size, off by default")
@@ -563,7 +586,11 @@ def main():
                                    + (f"ONE stream, Llama TP={world} ({'RCCL' if args.tp_allreduce == 'rccl' else 'one-shot p2p'} all-reduce x2/layer), ViT "
                                       f"{'frame-parallel + all-gather of the frame embeddings' if args.tp_vit == 'frame-parallel' else 'replicated'}, "
                                       if tp else f"TP=1, one stream per GPU ({world} replica(s)), ") + f"mode={args.mode} "
-                                   f"(16-token response every 10th frame + t=0 query), random-init weights at true shapes",
+                                   f"(16-token response every 10th frame + t=0 query), random-init weights at true shapes"
+                                   + (f"; `value` / p50 use {args.prefetch_frames} frames of look-ahead per encoder call — a LIVE camera feed gets "
+                                      f"{live_feed['no_lookahead']['frames_per_s']} frames/s, p50 {live_feed['no_lookahead']['p50_frame_latency_ms']} ms (no look-ahead) or "
+                                      f"{live_feed['one_frame_lookahead']['frames_per_s']} frames/s, p50 {live_feed['one_frame_lookahead']['p50_frame_latency_ms']} ms "
+                                      f"(one frame of look-ahead): see `live_feed`" if live_feed and "no_lookahead" in live_feed and "one_frame_lookahead" in live_feed else ""),
                        "frames": K, "stream_frames": total, "preroll_frames": preroll, "kv_tokens_at_start": kv_start,
                        "final_kv_tokens": final_len, "llm_steps": llm_steps, "prefetch_encode": not args.no_prefetch, "prefetch_frames": args.prefetch_frames,
                        "parallelism": f"tp{world}" if tp else f"replicas{world}",
@@ -630,7 +657,8 @@ def main():
             log("cpu_baseline: building CPU oracle")
             try:
                 out["cpu_baseline"] = cpu_baseline(args.model, frames[:max(args.cpu_sample_frames, 10)].cpu(), toks, args.mode,
-                                                   args.cpu_sample_frames, windows=[int(v) for v in args.cpu_windows.split(",") if v])
+                                                   args.cpu_sample_frames, budget_s=args.cpu_budget_s, windows=[int(v) for v in args.cpu_windows.split(",") if v],
+                                                   window_13k_frames=args.cpu_window_13k_frames if args.model == "llama-3-8b" else 0)
             except Exception as ex:     # never lose the GPU line to a host-side problem
                 out["cpu_baseline"] = {"value": None, "error": repr(ex)}
         print(json.dumps(out), flush=True)

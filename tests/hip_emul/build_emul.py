@@ -52,8 +52,7 @@ def build(force=False, sanitize=None):
         # bytes from its own gsrc to lds_dst + 16 l
         src = re.sub(r'asm volatile\("s_mov_b32 %0, m0[^;]*;', "emul_glds(gsrc, (char *)lds_dst + (threadIdx.x & 63) * 16, 16); (void)keep; (void)dst;", src)
         src = re.sub(r'asm volatile\(""\s*:::\s*"memory"\);', ";", src)                  # compiler-only memory barrier
-        src = re.sub(r'asm(?: volatile)?\(""\s*:\s*"\+[vs]"\(\w+\)\);', ";", src)   # optimisation barrier on a VGPR / SGPR value
-        src = re.sub(r'asm\("s_cmp_gt_i32 %1, 0[^;]*;', "r = remaining > 0 ? 1 : 0;", src)            # common.cuh::vlo_exists01
+        src = re.sub(r'asm(?: volatile)?\(""\s*:\s*"\+v"\(\w+\)\);', ";", src)      # optimisation barrier on a VGPR value
         src = re.sub(r'asm\("s_nop 7\\n\\ts_nop 3\\n\\tv_max3_f32[^;]*;', "r = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), fmaxf(fmaxf(a4, a5), fmaxf(a6, a7)));", src)
         src = re.sub(r'asm\("v_max_f32 %0, %1, %2"\s*:\s*"=v"\((\w+)\)\s*:\s*"v"\((\w+)\),\s*"v"\((\w+)\)\);', r"\1 = fmaxf(\2, \3);", src)
         return src

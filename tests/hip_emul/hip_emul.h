@@ -208,21 +208,6 @@ static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __A
 #define __builtin_amdgcn_s_sleep(x) sched_yield()
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)
-typedef unsigned emul_u32x2b __attribute__((ext_vector_type(2)));
-// buffer resources (raw, stride 0): base pointer + byte offsets
-struct __amdgpu_buffer_rsrc_t { const char *base; unsigned bytes; };
-typedef unsigned emul_u32x4 __attribute__((ext_vector_type(4)));
-static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void *p, short /*stride*/, int num_records, int /*flags*/) { return {(const char *)p, (unsigned)num_records}; }
-static inline emul_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int /*aux*/) {
-    emul_u32x4 v = {0u, 0u, 0u, 0u};
-    if ((unsigned long long)voff + soff + 16 <= r.bytes) memcpy(&v, r.base + voff + soff, 16);      // out of range: zeros, no access
-    return v;
-}
-static inline emul_u32x2b __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int /*aux*/) {
-    emul_u32x2b v = {0u, 0u};
-    if ((unsigned long long)voff + soff + 8 <= r.bytes) memcpy(&v, r.base + voff + soff, 8);
-    return v;
-}
 #define __builtin_amdgcn_s_barrier() emul_raw_barrier()
 // a wave is in lockstep on the hardware (the builtin emits no instruction); here its 64 lanes are OS threads: rendezvous
 #define __builtin_amdgcn_wave_barrier() pthread_barrier_wait(&emul_ctx->waves[threadIdx.x >> 6].bar)

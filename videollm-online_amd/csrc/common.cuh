@@ -42,30 +42,6 @@ VLO_DEV f32x4 mfma_f16(frag_ab a, frag_ab b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(frag_h, a), __builtin_bit_cast(frag_h, b), c, 0, 0, 0);
 }
 
-// 16-byte load through a buffer resource: address = wave-uniform 48-bit base (4 SGPRs) + a 32-bit per-lane byte offset (ONE VGPR) + a uniform
-// byte offset (SGPR / immediate).  Where a kernel streams many fragments off one base (the KV pages of the step attention) this keeps the address
-// arithmetic on the scalar unit and the per-load 64-bit VGPR address pairs out of the register file.
-typedef __amdgpu_buffer_rsrc_t vlo_rsrc_t;
-// `bytes` = 0 makes every load through the resource out of range: it returns zeros WITHOUT touching memory — a software-pipelined loop can keep
-// its prefetch loads unconditional (hipcc counts its vmcnt waits exactly only when no load sits behind a branch) and still fetch nothing past the end.
-// The 0 / 1 is made by two SCALAR instructions in inline asm: written as C (`remaining > 0 ? 1 : 0`, min / max, a sign-bit shift) hipcc canonicalises it
-// to an i1 select and may lower that to a vector v_cndmask — the whole resource then lives in VGPRs and every load through it becomes a waterfall loop
-// (tools/check_attn_isa.py checks for `s_cbranch_execnz` inside the key loops).
-VLO_DEV int vlo_exists01(int remaining) {
-    int r;
-    asm("s_cmp_gt_i32 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(remaining) : "scc");
-    return r;
-}
-VLO_DEV vlo_rsrc_t make_rsrc(const void *base, int exists01 = 1) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, -exists01, 0x00020000);   // records 0xffffffff: unbounded; 0: every load out of range
-}
-VLO_DEV frag_ab buf_load_frag(vlo_rsrc_t r, unsigned lane_off, unsigned uniform_off) {
-    return __builtin_bit_cast(frag_ab, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, uniform_off, 0));
-}
-VLO_DEV uint2 buf_load_u2(vlo_rsrc_t r, unsigned lane_off, unsigned uniform_off) {
-    return __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(r, lane_off, uniform_off, 0));
-}
-
 VLO_DEV float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -77,241 +77,8 @@ __global__ __launch_bounds__(512) void attn_chunk_kernel(const bf16_t *__restric
 //   * Q fragments live in LDS (shared by the 8 waves), not in registers: the accumulators of 3 column tiles are 96 registers;
 //   * the 8 partial states merge pairwise through LDS in three halving rounds; wave 0 writes the block's partial for the valid columns only.
 // ------------------------------------------------------------------------------------
-// Loop structure (round 5; round 4's loop read kv.page_table with a VECTOR load inside the key loop: `global_load_dword` -> `s_waitcnt vmcnt(0)` in
-// front of the V^T loads and again in front of the next block's K loads drained every load of the wave twice per 32-key block — nothing in flight
-// across iterations, 4.0 / 3.1 TB/s at 15 k tokens):
-//   * the wave index goes through readfirstlane, so a block's key range, its page index and the page id are wave-UNIFORM: the page-table reads are
-//     scalar loads (`s_load_dword`, lgkmcnt — they never touch vmcnt), fetched TWO blocks ahead of their use;
-//   * a wave's successive 32-key blocks are KS * 32 = one page apart: the in-page offsets are loop constants, a block's address is page id * page size
-//     + constant;
-//   * K of block b + 1 — and, where the accumulators leave room (DEEP), V^T of block b + 1 — are issued BEFORE block b is multiplied: the waits in the
-//     loop are counted (`s_waitcnt vmcnt(N)`, N > 0: tools/check_attn_isa.py asserts that), 16 - 32 KiB per wave in flight while it computes;
-//   * the wave's first K / V^T blocks are issued before the Q fragments are staged (one round trip at the start, not two);
-//   * a block every key of which is visible to every query (all but the last of a step) skips the causal compare / select (bit-identical).
 template <int HD, int NCT>
 __global__ __launch_bounds__(512) void attn_cols_kernel(const bf16_t *__restrict__ q, KvGeom kv, int layer, int nh, int G, int64_t pos0, int n,
-                                                        int chunk, float scale, float *__restrict__ part_o, float *__restrict__ part_ml) {
-    constexpr int NKK = HD / 32, NDT = HD / 16, KS = 8;
-    constexpr bool DEEP = NCT * NDT <= 8 || HD == 64;                      // V^T double-buffered too: (HD 128, NCT 1) and every HD 64 variant
-    constexpr int NQL = (NCT * NKK + KS - 1) / KS;                         // Q fragments a wave stages
-    static_assert(KS * 32 == VLO_PAGE_TOKENS, "a wave's successive key blocks are one page apart");
-    extern __shared__ __attribute__((aligned(16))) float4 lds_o[];         // the block's one dynamic LDS array (shared name with attn_chunk_kernel)
-    uint4 *qs = reinterpret_cast<uint4 *>(lds_o);                          // [NCT][NKK][64]   Q fragments (MFMA B operand)
-    float4 *lds_po = lds_o + NCT * NKK * 64;                               // [4][NCT][NDT][64] partial O of the merge rounds
-    float *lds_ml = reinterpret_cast<float *>(lds_po + 4 * NCT * NDT * 64); // [4][NCT][16][2]
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int split = blockIdx.x, kvh = blockIdx.y;
-    const int col = lane & 15, qd = lane >> 4;
-    const int L = (int)(pos0 + n);
-    const int c0 = split * chunk, c1 = min(L, c0 + chunk);
-    const int kfirst = c0 + w * 32;
-    const int nb = kfirst < c1 ? (c1 - kfirst + KS * 32 - 1) / (KS * 32) : 0;   // 32-key blocks this wave walks
-
-    // Straight-line prologue (no conditional loads: hipcc then counts its own waits exactly): the Q fragment loads go out first, then the page ids
-    // (scalar), then the wave's first K / V^T blocks.  A block that does not exist (beyond the wave's last; all of them for a wave without keys: the
-    // ragged last split, contexts under 256 tokens) is "loaded" through a zero-length buffer resource — zeros, no memory access.  Columns past the
-    // step's n tokens load the last token's q (any finite value does: a column's arithmetic never leaves its column, and those columns are not written).
-    uint4 qz[NQL];
-#pragma unroll
-    for (int j = 0; j < NQL; ++j) {
-        const int i = min(w + j * KS, NCT * NKK - 1);
-        const int ct = i / NKK, kk = i - ct * NKK;
-        const int cc = ct * 16 + col, qi = cc / G, h = cc - qi * G;
-        qz[j] = *reinterpret_cast<const uint4 *>(q + (size_t)min(qi, n - 1) * nh * HD + (size_t)(kvh * G + h) * HD + kk * 32 + qd * 8);
-    }
-    f32x4 O[NCT][NDT];
-    float mrun[NCT], lrun[NCT];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-        mrun[ct] = -INFINITY;
-        lrun[ct] = 0.f;
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) O[ct][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    const int krow = (col >> 2) * 8 + (col & 3);                           // S row `col` of tile t is key krow + 4 t of the block
-    const int kf0 = nb > 0 ? kfirst : c0;                                  // (a wave without keys reads a valid page-table entry and nothing else)
-    const int *pt = kv.page_table + kf0 / VLO_PAGE_TOKENS;                 // wave-uniform: page ids of blocks 0, 1, ... are pt[0], pt[1], ...
-    const int tok0 = kf0 % VLO_PAGE_TOKENS;
-    // addresses = a buffer resource per page (wave-uniform base in SGPRs: pool + layer + page + kv head + in-page offset) + ONE 32-bit per-lane byte
-    // offset + immediates / a scalar offset per V^T row tile: no per-load 64-bit VGPR address pairs
-    const char *kbase = reinterpret_cast<const char *>(kv.k_pool + (size_t)layer * kv.layer_stride + ((size_t)kvh * VLO_PAGE_TOKENS + tok0) * HD);
-    const char *vbase = reinterpret_cast<const char *>(kv.vt_pool + (size_t)layer * kv.layer_stride + (size_t)kvh * HD * VLO_PAGE_TOKENS + tok0);
-    const unsigned klane = (unsigned)(krow * HD + qd * 8) * 2u, vlane = (unsigned)(col * VLO_PAGE_TOKENS + qd * 8) * 2u;
-    const size_t page_bytes = (size_t)kv.page_elems * 2;
-    auto load_k = [&](int page, int exists01, frag_ab (&dst)[2][NKK]) {
-        const vlo_rsrc_t r = make_rsrc(kbase + (size_t)page * page_bytes, exists01);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) dst[t][kk] = buf_load_frag(r, klane, (unsigned)(4 * t * HD + kk * 32) * 2u);
-    };
-    auto load_v = [&](int page, int exists01, frag_ab (&dst)[NDT]) {
-        const vlo_rsrc_t r = make_rsrc(vbase + (size_t)page * page_bytes, exists01);
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) dst[dt] = buf_load_frag(r, vlane, (unsigned)(dt * 16 * VLO_PAGE_TOKENS * 2));
-    };
-    frag_ab kA[2][NKK], kB[2][NKK], vA[NDT], vB[NDT];                      // two register sets; vB: DEEP only (dead otherwise)
-    int pc = pt[0], p1 = pt[nb > 1 ? 1 : 0], p2 = pt[nb > 2 ? 2 : 0];      // pages of blocks b, b + 1, b + 2 (scalar loads)
-    load_k(pc, vlo_exists01(nb), kA);
-    if constexpr (DEEP) load_v(pc, vlo_exists01(nb), vA);
-    // every wave writes its NQL fragments, the surplus ones (fragment index >= NCT * NKK: a clamped duplicate) into the head of the merge area behind the
-    // Q area, which nothing reads before the merge rounds rewrite it: no branch around the write, so the Q loads cannot be sunk behind the K / V^T loads
-    static_assert(NQL * KS * 64 <= NCT * NKK * 64 + 4 * NCT * NDT * 64, "surplus Q fragments fit the merge area");
-#pragma unroll
-    for (int j = 0; j < NQL; ++j) qs[(w + j * KS) * 64 + lane] = qz[j];
-    __syncthreads();                                                        // Q fragments staged
-    int qoff = 0;                                                           // opaque zero: the Q fragments are re-read from LDS every block, never hoisted into
-                                                                            // registers (an asm memory clobber would do that too — and turn the page-table reads of the loop into vector loads)
-    auto multiply_block = [&](int kt0, frag_ab (&kf)[2][NKK], frag_ab (&vf)[NDT]) {
-        asm("" : "+v"(qoff));                                              // (not volatile: a volatile asm counts as a memory write and the page-table reads of the loop stop being scalar loads)
-        const bool all_visible = kt0 + 32 <= (int)pos0 + 1;                 // every key of the block <= pos0 <= every query's position (wave-uniform)
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-                const frag_ab qf = __builtin_bit_cast(frag_ab, qs[(ct * NKK + kk) * 64 + lane + qoff]);
-                s0 = mfma_bf16(kf[0][kk], qf, s0);
-                s1 = mfma_bf16(kf[1][kk], qf, s1);
-            }
-            float v[8];
-            if (all_visible) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = s0[r] * scale;
-                    v[4 + r] = s1[r] * scale;
-                }
-            } else {                                                       // the step's last blocks only: the column's query position is divided out here,
-                int colm = lane;                                           // behind an opaque move, instead of living in a register per tile across the loop
-                asm("" : "+v"(colm));
-                const int qp = (int)pos0 + min((ct * 16 + (colm & 15)) / G, n - 1), kb = kt0 + (colm >> 4) * 8;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = (kb + r <= qp) ? s0[r] * scale : -INFINITY;
-                    v[4 + r] = (kb + 4 + r <= qp) ? s1[r] * scale : -INFINITY;
-                }
-            }
-            float tmax = v[0];
-#pragma unroll
-            for (int j = 1; j < 8; ++j) tmax = fmaxf(tmax, v[j]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(mrun[ct], tmax);
-            const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __expf(mrun[ct] - m_safe);
-            mrun[ct] = m_new;
-            float psum = 0.f;
-            float p[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                p[j] = __expf(v[j] - m_safe);
-                psum += p[j];
-            }
-            const uint4 pk = make_uint4(pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7]));
-            const frag_ab pb = __builtin_bit_cast(frag_ab, pk);
-            lrun[ct] = lrun[ct] * alpha + psum;
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                f32x4 o = O[ct][dt];
-                o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
-                O[ct][dt] = mfma_bf16(vf[dt], pb, o);
-            }
-            if constexpr (!DEEP && NCT >= 3) __builtin_amdgcn_sched_barrier(0);   // three column tiles at HD 128: one tile's temporaries at a time (no spills)
-        }
-    };
-    // Two blocks per trip, ping-pong between the register sets (no copies): set B <- block b + 1, multiply A (block b), set A <- block b + 2,
-    // multiply B.  EVERY load of the loop is unconditional — a load behind a branch makes hipcc's wait for everything issued before it a vmcnt(0) —
-    // and a block past the wave's last comes through the zero-length resource.  Not DEEP (two / three column tiles at HD 128 fill the register file):
-    // one V^T set, loaded at the top of its block, behind it the next block's K.
-    // (sched_barrier: hipcc's scheduler otherwise hoists a block's loads above the previous block's multiply — both copies of a register set live)
-#define VLO_FENCE() __builtin_amdgcn_sched_barrier(0)
-    for (int b = 0; b < nb; b += 2) {
-        const int has1 = vlo_exists01(nb - b - 1), has2 = vlo_exists01(nb - b - 2);
-        if constexpr (!DEEP) load_v(pc, 1, vA);
-        load_k(p1, has1, kB);
-        if constexpr (DEEP) load_v(p1, has1, vB);
-        VLO_FENCE();
-        multiply_block(kfirst + b * (KS * 32), kA, vA);
-        VLO_FENCE();
-        if constexpr (!DEEP) load_v(p1, has1, vA);
-        load_k(p2, has2, kA);
-        if constexpr (DEEP) load_v(p2, has2, vA);
-        VLO_FENCE();
-        if (has1) multiply_block(kfirst + (b + 1) * (KS * 32), kB, DEEP ? vB : vA);
-        VLO_FENCE();
-        pc = p2;
-        p1 = pt[min(b + 3, max(nb - 1, 0))];                               // scalar loads, consumed in the next trip
-        p2 = pt[min(b + 4, max(nb - 1, 0))];
-    }
-#undef VLO_FENCE
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-        lrun[ct] += __shfl_xor(lrun[ct], 16, 64);
-        lrun[ct] += __shfl_xor(lrun[ct], 32, 64);
-    }
-    // ---- pairwise merge of the 8 partial states: wave w + half hands its state to wave w
-    for (int half = KS / 2; half >= 1; half >>= 1) {
-        if (w >= half && w < 2 * half) {
-            const int slot = w - half;
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                if (qd == 0) {
-                    lds_ml[((slot * NCT + ct) * 16 + col) * 2] = mrun[ct];
-                    lds_ml[((slot * NCT + ct) * 16 + col) * 2 + 1] = lrun[ct];
-                }
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-                    const f32x4 o = O[ct][dt];
-                    lds_po[((size_t)(slot * NCT + ct) * NDT + dt) * 64 + lane] = make_float4(o[0], o[1], o[2], o[3]);
-                }
-            }
-        }
-        __syncthreads();
-        if (w < half) {
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                const float mo = lds_ml[((w * NCT + ct) * 16 + col) * 2], lo = lds_ml[((w * NCT + ct) * 16 + col) * 2 + 1];
-                const float M = fmaxf(mrun[ct], mo);
-                const float Ms = (M == -INFINITY) ? 0.f : M;
-                const float wa = __expf(mrun[ct] - Ms), wb = __expf(mo - Ms);          // -inf -> 0
-                lrun[ct] = lrun[ct] * wa + lo * wb;
-                mrun[ct] = M;
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-                    const float4 o = lds_po[((size_t)(w * NCT + ct) * NDT + dt) * 64 + lane];
-                    O[ct][dt][0] = O[ct][dt][0] * wa + o.x * wb;
-                    O[ct][dt][1] = O[ct][dt][1] * wa + o.y * wb;
-                    O[ct][dt][2] = O[ct][dt][2] * wa + o.z * wb;
-                    O[ct][dt][3] = O[ct][dt][3] * wa + o.w * wb;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (w != 0) return;
-    int col_w = lane & 15, qd_w = lane >> 4;                              // re-derived behind an opaque move: the (token, head) of a column is divided out
-    asm("" : "+v"(col_w));                                                // again here instead of living in registers across the key loop
-    asm("" : "+v"(qd_w));
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-        const int cc = ct * 16 + col_w, qi = cc / G, h = cc - qi * G;
-        if (qi >= n) continue;
-        const size_t row = ((size_t)split * nh + kvh * G + h) * 16 + qi;
-        if (qd_w == 0) {
-            part_ml[row * 2] = mrun[ct];
-            part_ml[row * 2 + 1] = lrun[ct];
-        }
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            const f32x4 o = O[ct][dt];
-            *reinterpret_cast<float4 *>(part_o + row * HD + dt * 16 + qd_w * 4) = make_float4(o[0], o[1], o[2], o[3]);
-        }
-    }
-}
-
-// round 4's loop, kept for ONE hardware A/B (VLO_ATTN_V1=1); removed once the numbers are in profiles/
-template <int HD, int NCT>
-__global__ __launch_bounds__(512) void attn_cols_v1_kernel(const bf16_t *__restrict__ q, KvGeom kv, int layer, int nh, int G, int64_t pos0, int n,
                                                         int chunk, float scale, float *__restrict__ part_o, float *__restrict__ part_ml) {
     constexpr int NKK = HD / 32, NDT = HD / 16, KS = 8;
     extern __shared__ __attribute__((aligned(16))) float4 lds_o[];         // the block's one dynamic LDS array (shared name with attn_chunk_kernel)
@@ -692,21 +459,11 @@ hipError_t attention_launch(const unsigned short *q, KvGeom kv, int layer, int n
         (void)hipFuncSetAttribute((const void *)attn_cols_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)attn_cols_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)attn_cols_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)attn_cols_v1_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)attn_cols_v1_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)attn_cols_v1_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)attn_cols_v1_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)attn_cols_v1_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)attn_cols_v1_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
         attr_done = true;
     }
-    static const int cols_v1 = getenv("VLO_ATTN_V1") ? atoi(getenv("VLO_ATTN_V1")) : 0;
-#define VLO_ATTN_COLS(HD_, NCT_)                                                                                                                  \
-    do {                                                                                                                                          \
-        if (cols_v1) hipLaunchKernelGGL((attn_cols_v1_kernel<HD_, NCT_>), grid, dim3(512), lds, st, q, kv, layer, num_heads, G, pos0, n, chunk, scale, part_o, part_ml); \
-        else hipLaunchKernelGGL((attn_cols_kernel<HD_, NCT_>), grid, dim3(512), lds, st, q, kv, layer, num_heads, G, pos0, n, chunk, scale, part_o, part_ml); \
-    } while (0)
+#define VLO_ATTN_COLS(HD_, NCT_) \
+    hipLaunchKernelGGL((attn_cols_kernel<HD_, NCT_>), grid, dim3(512), lds, st, q, kv, layer, num_heads, G, pos0, n, chunk, scale, part_o, part_ml)
     if (ag.nct) {
         if (hd == 128 && ag.nct == 1) VLO_ATTN_COLS(128, 1);
         else if (hd == 128 && ag.nct == 2) VLO_ATTN_COLS(128, 2);
