@@ -734,17 +734,49 @@ def test_prefill_path_gemms_in_emulation(E, shape):
         s2 = eng.new_session()
         _, again = eng.llm_step(s2, first[0])
         assert torch.equal(again, first[1])
-        # ... and so is the experimental one-column-tile kernel (128 columns per workgroup, four waves per SIMD; opt-in)
-        os.environ.pop("VLO_ATTN_NOSKIP")
-        os.environ["VLO_ATTN_NCT"] = "1"
-        s3 = eng.new_session()
-        _, again = eng.llm_step(s3, first[0])
-        assert torch.equal(again, first[1])
         eng.close()
     finally:
         os.environ.pop("VLO_EMUL_GLDS", None)
         os.environ.pop("VLO_ATTN_NOSKIP", None)
-        os.environ.pop("VLO_ATTN_NCT", None)
+
+
+@pytest.mark.parametrize("p2p", [False, True] if FULL else [False], ids=["sum-kernel", "p2p-group"] if FULL else ["sum-kernel"])
+def test_tensor_parallel_prefill_path_in_emulation(E, p2p):
+    """csrc/tp.hip::tp_prefill with T = 2 logical ranks: inputs of >= 256 tokens run the ranks' SHARDS of the projections as GEMMs over the packed
+    images (column-sharded q|k|v and gate|up, row-sharded o / down as fp32 partial matrices through the EP_LLM_F32 epilogue), RoPE + KV append and
+    the prefill attention on each rank's own kv heads, the [m][H] fp32 all-reduce as the sum kernel, `h += bf16(sum); x = RMSNorm(h) w` as the row
+    kernel, the vocabulary shards 16 rows at a time through the GEMV + the logits gather.  300 tokens (a 256-row tile + a partial one), then a frame
+    step and a decode step of the 16-row TP pipeline on the cache the prefill wrote; all rows' logits 3-way against the oracle.  A group whose
+    16-row exchanges are the p2p mailboxes takes the same prefill path (its matrix-sized all-reduce is the sum kernel: all ranks are local)."""
+    spec = O.LlmSpec(256, 256, 1, 4, 2, 256, 10000.0, 1e-5, vision_hidden_size=128)     # per rank: 2 heads of 64 on 1 kv head, 128 MLP columns, 128 logits
+    w = O.init_llm_weights(spec, seed=9)
+    ref, gold = O.LlamaOracle(spec, w, torch.bfloat16), O.LlamaOracle(spec, w, torch.float32)
+    os.environ["VLO_EMUL_GLDS"] = "late"
+    try:
+        grp = E.EmulTpGroup(spec, 2, w, O.rope_inv_freq(spec.head_dim, spec.rope_theta), p2p=p2p, kv_pool_tokens=2048)      # three sessions of <= 312 tokens
+        s = grp.new_session()
+        g = torch.Generator().manual_seed(4)
+        rc = gc = None
+        for i, n in enumerate((300, 11, 1)):
+            x = (torch.randn(n, spec.hidden_size, generator=g) * 0.7).bfloat16()
+            rl, rc = ref.forward(x, rc)
+            gl, gc = gold.forward(x, gc)
+            last, allr = grp.llm_step(s, x)
+            assert grp.session_len(s) == len(rc) and torch.equal(last, allr[-1])
+            _three_way(f"tp2 prefill {'p2p' if p2p else 'sum'}", i, allr, rl, gl)
+        if FULL:        # only the last row wanted: the same logits as the all-rows call's last row (VLO_EMUL_FULL=1: two more 300-token passes)
+            s2 = grp.new_session()
+            g = torch.Generator().manual_seed(4)
+            x = (torch.randn(300, spec.hidden_size, generator=g) * 0.7).bfloat16()
+            last2, _ = grp.llm_step(s2, x, want_all=False)
+            s3 = grp.new_session()
+            last3, all3 = grp.llm_step(s3, x)
+            assert torch.equal(last2, last3) and torch.equal(last3, all3[-1])
+        if p2p:
+            assert grp.p2p_status()["timed_out"] == 0
+        grp.close()
+    finally:
+        os.environ.pop("VLO_EMUL_GLDS", None)
 
 
 VIT_TILES_CHILD = r"""

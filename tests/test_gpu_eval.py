@@ -132,23 +132,6 @@ def test_prefill_attention_shortcuts_are_bit_identical(monkeypatch):
     eng.close()
 
 
-@pytest.mark.skipif(os.environ.get("VLO_EXPERIMENTAL") != "1", reason="opt-in: the one-column-tile prefill attention kernel has not run on hardware yet (VLO_EXPERIMENTAL=1)")
-def test_prefill_attention_one_column_tile_variant_is_bit_identical(monkeypatch):
-    """VLO_ATTN_NCT=1: attn_prefill_1ct_kernel (128 columns per workgroup, register budget 128) against the shipping kernel — a column's arithmetic does
-    not depend on its neighbours, so the logits must be equal bit for bit (the CPU emulation agrees: test_prefill_path_gemms_in_emulation)."""
-    spec = O.LLM_SPECS["toy128"]
-    w = O.init_llm_weights(spec, seed=3)
-    eng = _engine(spec, w, kv_pool_tokens=4096)
-    x = (torch.randn(1500, spec.hidden_size, generator=torch.Generator().manual_seed(5)) * 0.05).bfloat16().cuda()
-    a = eng.new_session()
-    _, two = eng.llm_step(a, x, want_last=False, want_all=True)
-    monkeypatch.setenv("VLO_ATTN_NCT", "1")
-    b = eng.new_session()
-    _, one = eng.llm_step(b, x, want_last=False, want_all=True)
-    assert torch.equal(two, one)
-    eng.close()
-
-
 def test_full_logits_forward_matches_oracle():
     """model(input_ids=, frames=) returns every row (the evaluation path), 3-way checked against fp32 gold."""
     from videollm_online_amd.modeling_live import LiveModel

@@ -102,6 +102,7 @@ struct vlo_session {
     // step on streams of their own, a scratch shared through the engine would be overwritten under another session's GEMM
     void *pf_wexp = nullptr;
     size_t pf_wexp_bytes = 0;
+    float *ppartial = nullptr;                   // TP prefill: this rank's o-proj / down-proj partial sums fp32 [VLO_PREFILL_TOKENS][H] awaiting the all-reduce
 };
 
 int dev_alloc(void **p, size_t bytes);
@@ -110,6 +111,9 @@ struct KvGeom;
 int ensure_pages(vlo_session *s, int64_t new_len, hipStream_t st);
 GemvArgs gemv_args(const PackedLinear &pl, const unsigned short *x, int ldx, int n_rows);
 KvGeom kv_geom(const vlo_session *s);
+int ensure_prefill_ws(vlo_session *s);                        // prefill-path workspaces of a session (sized for the engine's shard)
+bool prefill_ok(const vlo_engine *e);                         // do this engine's (shard) shapes take the prefill GEMMs
+int prefill_gemm(vlo_session *s, const unsigned short *X, const PackedLinear &pl, int m, int N, int K, void *out, int ldo, int kind, hipStream_t st);
 void ingest_create(vlo_engine *e);
 void ingest_destroy(vlo_engine *e);
 int connector_run(vlo_engine *e, int slot, const void *feats_dev, int rows, void *out_dev, hipStream_t st);   // slot 0 / 1: scratch set

@@ -753,7 +753,7 @@ static int run_block(vlo_session *s, const unsigned short *src, int m, bool want
 }
 
 // ---- prefill path: up to VLO_PREFILL_TOKENS new tokens per weight pass, the projections as MFMA-bound GEMMs (prefill.h) ------------------
-static int ensure_prefill_ws(vlo_session *s) {
+int ensure_prefill_ws(vlo_session *s) {
     if (s->pact) return VLO_OK;                 // the LAST buffer allocated below: set only when all of them exist
     vlo_engine *e = s->e;
     const size_t H = e->cfg.hidden_size, I = e->I_l, qd = (size_t)e->nh_l * e->head_dim, kvd = (size_t)e->nkv_l * e->head_dim;
@@ -788,6 +788,30 @@ static int ensure_prefill_partials(vlo_session *s) {
     return VLO_OK;
 }
 
+// One projection of a prefill block: out = X W^T through the GEMM of prefill.h (kind = LLM_GEMM_*).  fp8 engines: the projection's e4m3 image is
+// expanded to bf16 (exactly) into the session's scratch right before its GEMM — 3 bytes of extra traffic per weight against hundreds of tokens of
+// MFMA work per weight — and its per-channel scales go to the GEMM's epilogue.  Shared with tp.hip (a rank's shard of a tensor-parallel prefill).
+int prefill_gemm(vlo_session *s, const unsigned short *X, const PackedLinear &pl, int m, int N, int K, void *out, int ldo, int kind, hipStream_t st) {
+    vlo_engine *e = s->e;
+    if (!pl.wq) { HIP_TRY(llm_gemm_launch(X, pl.Wp, m, N, K, out, ldo, kind, st)); return VLO_OK; }
+    // sized for the largest projection of a layer at the first use (not grown projection by projection); the lm_head image may grow it once more
+    const LayerWeights &L0 = e->layers[0];
+    const size_t img = (size_t)pl.NT * 16 * K * 2;
+    auto bytes = [](const PackedLinear &q) { return (size_t)q.NT * 16 * q.K * 2; };
+    const size_t need = std::max({img, bytes(L0.qkv), bytes(L0.o), bytes(L0.gate_up), bytes(L0.down)});
+    if (s->pf_wexp_bytes < need) {
+        HIP_TRY(hipStreamSynchronize(st));                       // (grows at most a few times: up to the largest projection)
+        void *p = nullptr;
+        int rc2 = dev_alloc(&p, need);
+        if (rc2) return rc2;
+        s->owned.push_back(p);
+        s->pf_wexp = p; s->pf_wexp_bytes = need;
+    }
+    HIP_TRY(expand_fp8_image_launch(pl.Wp, s->pf_wexp, pl.NT, K, st));
+    HIP_TRY(llm_gemm_launch(X, s->pf_wexp, m, N, K, out, ldo, kind, st, pl.wscale));
+    return VLO_OK;
+}
+
 // one block of VLO_PREFILL_MIN <= m <= VLO_PREFILL_TOKENS new tokens.  Per decoder layer: RMSNorm rows -> qkv GEMM -> RoPE + KV append ->
 // attention in one launch (the block path's kernel, grid.z = 16-query sub-chunks: the whole block's keys are already appended) ->
 // o GEMM [residual add] -> RMSNorm rows -> gate/up GEMM [SwiGLU] -> down GEMM [residual add].  Rounding points as run_chunk / run_block
@@ -802,26 +826,8 @@ static int run_prefill(vlo_session *s, const unsigned short *src, int m, bool wa
     if ((rc = ensure_pages(s, s->len + m, st))) return rc;
     const KvGeom kv = kv_geom(s);
     HIP_TRY(copy_rows_launch(src, s->ph, m, H, st));
-    // fp8 engines: a projection's e4m3 image is expanded to bf16 (exactly) into one scratch right before its GEMM — 3 bytes of extra traffic
-    // per weight against hundreds of tokens of MFMA work per weight — and its per-channel scales go to the GEMM's epilogue
     auto gemm = [&](const unsigned short *X, const PackedLinear &pl, int N, int K, unsigned short *out, int ldo, int kind) -> int {
-        if (!pl.wq) { HIP_TRY(llm_gemm_launch(X, pl.Wp, m, N, K, out, ldo, kind, st)); return VLO_OK; }
-        // sized for the largest projection of a layer at the first use (not grown projection by projection); the lm_head image may grow it once more
-        const LayerWeights &L0 = e->layers[0];
-        const size_t img = (size_t)pl.NT * 16 * K * 2;
-        auto bytes = [](const PackedLinear &q) { return (size_t)q.NT * 16 * q.K * 2; };
-        const size_t need = std::max({img, bytes(L0.qkv), bytes(L0.o), bytes(L0.gate_up), bytes(L0.down)});
-        if (s->pf_wexp_bytes < need) {
-            HIP_TRY(hipStreamSynchronize(st));                       // (grows at most a few times: up to the largest projection)
-            void *p = nullptr;
-            int rc2 = dev_alloc(&p, need);
-            if (rc2) return rc2;
-            s->owned.push_back(p);
-            s->pf_wexp = p; s->pf_wexp_bytes = need;
-        }
-        HIP_TRY(expand_fp8_image_launch(pl.Wp, s->pf_wexp, pl.NT, K, st));
-        HIP_TRY(llm_gemm_launch(X, s->pf_wexp, m, N, K, out, ldo, kind, st, pl.wscale));
-        return VLO_OK;
+        return prefill_gemm(s, X, pl, m, N, K, out, ldo, kind, st);
     };
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerWeights &L = e->layers[l];
@@ -867,13 +873,13 @@ static int run_prefill(vlo_session *s, const unsigned short *src, int m, bool wa
     return VLO_OK;
 }
 
-// shapes the prefill GEMMs take (bf16 image, or the fp8 image expanded per GEMM): every projection width a multiple of 256, every K of 128
-static bool prefill_ok(const vlo_engine *e) {
+// shapes the prefill GEMMs take (bf16 image, or the fp8 image expanded per GEMM): every projection width a multiple of 256, every K of 128 —
+// of THIS rank's shard under tensor parallelism (tp.hip::tp_prefill: column-sharded q|k|v and gate|up, row-sharded o and down)
+bool prefill_ok(const vlo_engine *e) {
     static const bool on = getenv("VLO_PREFILL") ? atoi(getenv("VLO_PREFILL")) != 0 : true;
     const vlo_config &c = e->cfg;
-    const int hd = e->head_dim, qd = c.num_heads * hd, Nqkv = qd + 2 * c.num_kv_heads * hd;
-    return on && e->tp_size == 1 && !(Nqkv & 255) && !(c.hidden_size & 255) && !((2 * c.intermediate_size) & 255) &&
-           !(c.intermediate_size & 127) && !(qd & 127) && (hd == 64 || hd == 128);
+    const int hd = e->head_dim, qd = e->nh_l * hd, Nqkv = qd + 2 * e->nkv_l * hd;
+    return on && !(Nqkv & 255) && !(c.hidden_size & 255) && !((2 * e->I_l) & 255) && !(e->I_l & 127) && !(qd & 127) && (hd == 64 || hd == 128);
 }
 
 int vlo_llm_step(vlo_session *s, const void *embeds_dev, int n, void *last_logits_dev, void *all_logits_dev, void *stream) {

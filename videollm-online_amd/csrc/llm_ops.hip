@@ -326,9 +326,9 @@ VLO_DEV float quad_lanes_maxf(float x) {
 
 // ------------------------------------------------------------------------------------
 // Prefill attention (blocks of hundreds to thousands of new tokens, engine.hip::run_prefill): flash-style.  One workgroup = one kv head x
-// QB = 256 / G consecutive queries: its 256 (query, head) columns are 16 column tiles, two per wave (8 waves), and ALL waves walk the SAME
+// QB = 128 / G consecutive queries: its 128 (query, head) columns are 8 column tiles, one per wave (8 waves), and ALL waves walk the SAME
 // 32-key tiles, which are staged once per workgroup in LDS (K 32 x HD, V^T HD x 32: 16 KiB at HD = 128, double-buffered) by direct-to-LDS
-// loads — a K / V^T byte leaves L2 once per 256 columns instead of once per 16-query sub-chunk (the decode-shaped kernel above re-reads
+// loads — a K / V^T byte leaves L2 once per 128 columns instead of once per 16-query sub-chunk (the decode-shaped kernel above re-reads
 // the whole prefix for every sub-chunk: 232 TFLOP/s at 13 k tokens).  No split-KV, no merge kernel: a workgroup sees every key its
 // queries may attend to and writes normalised bf16 rows.
 //   * LDS layout = the MFMA A-operand fragments themselves: piece (1 KiB) = [16-byte chunk c][row r] so lane l = 16 c + r reads slot l
@@ -344,21 +344,13 @@ VLO_DEV float quad_lanes_maxf(float x) {
 //     change in time (13 312 tokens: 255.3 vs 255.8 ms) — VALU throughput is not what bounds this kernel.
 // grid = (ceil(n / QB), nkv); 512 threads.  Rounding points as the other attention kernels (P -> bf16 before P.V, bf16 output).
 // ------------------------------------------------------------------------------------
+// ONE column tile per wave: 128 (query, head) columns per workgroup, a register budget of 128 — four waves per SIMD.  (Round 4 shipped two column tiles
+// per wave, 256 columns per workgroup at 208 - 214 VGPRs / two waves per SIMD: half the LDS read traffic per FLOP, but a per-wave latency chain that two
+// waves per SIMD cannot hide.  Measured on the MI355X, bit-identical outputs: 13 312 tokens 242.2 -> 232.4 ms, 2 048 tokens 33.7 -> 33.9 ms;
+// profiles/r5_prefill_attention_one_column_tile.txt.  The two-tile kernel is gone.)
 template <int HD, int G, int NS>
-__global__ __launch_bounds__(512) void attn_prefill_kernel(const bf16_t *__restrict__ q, KvGeom kv, int layer, int nh, int64_t pos0, int n, float scale,
-                                                           bf16_t *__restrict__ out, int noskip) {
-#define VLO_PF_NCT 2
-#include "attn_prefill_body.inc"
-#undef VLO_PF_NCT
-}
-
-// EXPERIMENTAL, opt-in (VLO_ATTN_NCT=1), NOT yet run on hardware: the same body with ONE column tile per wave — 128 columns per workgroup, a register
-// budget of 128 (four waves per SIMD instead of two) at twice the LDS read traffic per FLOP.  DESIGN.md section 8.4: the shipping kernel is a
-// per-wave latency chain that two waves per SIMD cannot hide; this is the variant to measure first.  Bit-identical to the shipping kernel by
-// construction (a column's arithmetic does not depend on its neighbours; the wave-uniform shortcuts are exact), checked in the emulation.
-template <int HD, int G, int NS>
-__global__ __launch_bounds__(512, 4) void attn_prefill_1ct_kernel(const bf16_t *__restrict__ q, KvGeom kv, int layer, int nh, int64_t pos0, int n, float scale,
-                                                                  bf16_t *__restrict__ out, int noskip) {
+__global__ __launch_bounds__(512, 4) void attn_prefill_kernel(const bf16_t *__restrict__ q, KvGeom kv, int layer, int nh, int64_t pos0, int n, float scale,
+                                                              bf16_t *__restrict__ out, int noskip) {
 #define VLO_PF_NCT 1
 #include "attn_prefill_body.inc"
 #undef VLO_PF_NCT
@@ -369,17 +361,11 @@ hipError_t attention_prefill_launch(const unsigned short *q, KvGeom kv, int laye
     if (n <= 0 || nkv * G != num_heads) return hipErrorInvalidValue;
     const float scale = 1.0f / sqrtf((float)hd);
     static const int kStages = getenv("VLO_ATTN_STAGES") ? atoi(getenv("VLO_ATTN_STAGES")) : 4;      // tile buffers in the ring (2: one tile in flight)
-    const char *nct = getenv("VLO_ATTN_NCT");                              // 1: the experimental one-column-tile kernel (read per call, as noskip)
-    const int kNct = nct ? atoi(nct) : 2;
     const char *ns = getenv("VLO_ATTN_NOSKIP");                            // read per call: the tests flip it between two passes over the same input
     const int noskip = ns && atoi(ns) != 0;
 #define VLO_ATTN_PF(HD_, G_)                                                                                                          \
     do {                                                                                                                              \
-        constexpr int QB_ = 256 / G_;                                                                                                 \
-        if (kNct == 1) {                                                                                                              \
-            hipLaunchKernelGGL((attn_prefill_1ct_kernel<HD_, G_, 4>), dim3((n + QB_ / 2 - 1) / (QB_ / 2), nkv), dim3(512), 0, st, q, kv, layer, num_heads, pos0, n, scale, out, noskip); \
-            return hipGetLastError();                                                                                                 \
-        }                                                                                                                             \
+        constexpr int QB_ = 128 / G_;                                                                                                 \
         if (kStages == 2) hipLaunchKernelGGL((attn_prefill_kernel<HD_, G_, 2>), dim3((n + QB_ - 1) / QB_, nkv), dim3(512), 0, st, q, kv, layer, num_heads, pos0, n, scale, out, noskip); \
         else hipLaunchKernelGGL((attn_prefill_kernel<HD_, G_, 4>), dim3((n + QB_ - 1) / QB_, nkv), dim3(512), 0, st, q, kv, layer, num_heads, pos0, n, scale, out, noskip); \
         return hipGetLastError();                                                                                                     \

@@ -18,17 +18,19 @@ hipError_t gemm64_launch(GemvArgs a, const Gemm64Plan &p, int epi, hipStream_t s
 // The projections run as real GEMMs (MFMA-bound: hundreds of tokens per weight byte instead of 64): the ViT's ping-pong kernel
 // (vit_gemm.inc: 256 x 256 tiles, direct-to-LDS double buffering, persistent XCD-aware tile walk) instantiated for bf16 operands with
 // the weight operand read from the SAME packed fragment image the GEMV streams (a per-lane source address of the direct-to-LDS load)
-// and the Llama epilogues with the GEMV path's rounding points.  bf16 images only (fp8 engines keep the 64-token block path).
+// and the Llama epilogues with the GEMV path's rounding points.  fp8 engines: each projection's e4m3 image is expanded (exactly) to bf16 into
+// a per-session scratch right before its GEMM (expand_fp8_image_launch), its per-channel scales multiply the sums in the epilogue.
 #define VLO_PREFILL_TOKENS 4096   // rows of the prefill workspace; x must stay readable 256 rows past M (the kernel reads whole tiles)
 #define VLO_PREFILL_MIN 256       // shorter inputs take the 64-token block path
-enum { LLM_GEMM_BF16 = 0, LLM_GEMM_SWIGLU = 1, LLM_GEMM_RESID = 2 };
+enum { LLM_GEMM_BF16 = 0, LLM_GEMM_SWIGLU = 1, LLM_GEMM_RESID = 2, LLM_GEMM_F32 = 3 };
 // X bf16 [M][K] row-major; Wp = packed image of W [N][K]; N % 256 == 0, K % 128 == 0.
 //   LLM_GEMM_BF16:   out bf16 [M][ldo] = bf16(X W^T)
 //   LLM_GEMM_SWIGLU: Wp = the gate/up image (N = 2 I): out bf16 [M][ldo = I] = bf16(silu(bf16 g) * bf16 u)
 //   LLM_GEMM_RESID:  out = the residual stream bf16 [M][N]: out = bf16(out + bf16(X W^T))
+//   LLM_GEMM_F32:    out = FLOAT [M][ldo] = X W^T (raw sums): a tensor-parallel rank's partial o-proj / down-proj, all-reduced by the caller
 // wscale: null (bf16 image) or the fp32 per-output-channel scales of an fp8 engine, packed row order; Wp is then the bf16 EXPANSION of the
 // fp8 image (expand_fp8_image_launch below), the scales multiply the fp32 sums in the epilogue as they do in the GEMV
-hipError_t llm_gemm_launch(const unsigned short *X, const void *Wp, int M, int N, int K, unsigned short *out, int ldo, int kind, hipStream_t st,
+hipError_t llm_gemm_launch(const unsigned short *X, const void *Wp, int M, int N, int K, void *out, int ldo, int kind, hipStream_t st,
                            const float *wscale = nullptr);
 // fp8 e4m3 image Wp8[tile][kf2][lane] (gemv.hip) -> bf16 image Wp[tile][kf][lane], exact (every e4m3 value is a bf16 value); NT tiles of K
 hipError_t expand_fp8_image_launch(const void *Wp8, void *Wp_bf16, int NT, int K, hipStream_t st);

@@ -312,11 +312,11 @@ hipError_t expand_fp8_image_launch(const void *Wp8, void *Wp_bf16, int NT, int K
     return hipGetLastError();
 }
 
-hipError_t llm_gemm_launch(const unsigned short *X, const void *Wp, int M, int N, int K, unsigned short *out, int ldo, int kind, hipStream_t st,
+hipError_t llm_gemm_launch(const unsigned short *X, const void *Wp, int M, int N, int K, void *out, int ldo, int kind, hipStream_t st,
                            const float *wscale) {
     if (!X || !Wp || !out || M <= 0 || (N & 255) || (K & 127) || K < 128) return hipErrorInvalidValue;
     GemmArgs a{};
-    a.X = (const f16_t *)X; a.W = (const f16_t *)Wp; a.M = M; a.N = N; a.K = K; a.ldx = K; a.ldo = ldo; a.outb = out; a.xpad = 1;
+    a.X = (const f16_t *)X; a.W = (const f16_t *)Wp; a.M = M; a.N = N; a.K = K; a.ldx = K; a.ldo = ldo; a.outb = (unsigned short *)out; a.out32 = (float *)out; a.xpad = 1;
     a.bias = wscale;
     const int tx = N / 256;
     // tile height: 256 rows once such tiles fill the chip, else 128 (twice the tiles, half the work each)
@@ -337,6 +337,7 @@ hipError_t llm_gemm_launch(const unsigned short *X, const void *Wp, int M, int N
     if (kind == LLM_GEMM_BF16) VLO_LLM_GO(EP_LLM_BF16);
     if (kind == LLM_GEMM_SWIGLU) VLO_LLM_GO(EP_LLM_SWIGLU);
     if (kind == LLM_GEMM_RESID) VLO_LLM_GO(EP_LLM_RESID);
+    if (kind == LLM_GEMM_F32) VLO_LLM_GO(EP_LLM_F32);
 #undef VLO_LLM_GO
     return hipErrorInvalidValue;
 }

@@ -32,6 +32,7 @@
 #include "engine.h"
 #include "gemv.h"
 #include "llm_ops.h"
+#include "prefill.h"
 #include "tp_p2p.cuh"
 
 #define TP_TRY(expr)                                                                                        \
@@ -676,6 +677,109 @@ static int tp_chunk(vlo_tp_session *t, const unsigned short *src, int m, bool wa
     return VLO_OK;
 }
 
+// ---- one block of VLO_PREFILL_MIN <= m <= VLO_PREFILL_TOKENS new tokens on every local rank, lock-step: the projections as GEMMs ----------
+// engine.hip::run_prefill under HF's tensor-parallel plan: column-sharded q|k|v and gate|up (this rank's heads / MLP columns), RoPE + KV append and
+// the flash-style prefill attention on the rank's own kv heads, row-sharded o / down as fp32 PARTIAL matrices [m][H] (EP_LLM_F32) that are
+// all-reduced in fp32 and then folded into the residual stream by the row kernel (h += bf16(sum); x = RMSNorm(h) w) — the rounding points of the
+// 16-row TP step and of the one-GPU prefill.  The exchange here is bandwidth-sized (m x H x 4 bytes: 64 MiB at 4 096 tokens of the 8B model), so
+// it goes through RCCL (one process per GPU) or the sum kernel (all ranks in this process); the latency-sized p2p mailboxes are not used for it.
+static bool tp_prefill_ok(const vlo_tp_session *t) {
+    const vlo_tp_group *g = t->g;
+    if (!(g->comm || (int)g->eng.size() == g->tp_size)) return false;       // mailbox-only groups keep the 16-row step
+    for (const vlo_engine *e : g->eng)
+        if (!prefill_ok(e)) return false;
+    return true;
+}
+static int tp_prefill_exchange(vlo_tp_session *t, int m, const void *(*norm_w)(const vlo_engine *, int), int layer, hipStream_t st) {
+    vlo_tp_group *g = t->g;
+    const vlo_config &c = g->eng[0]->cfg;
+    const int H = c.hidden_size;
+    const size_t count = (size_t)m * H;
+    if (g->comm) {
+        float *b = t->ss[0]->ppartial;
+        const int nrc = g_rccl.AllReduce(b, b, count, kNcclFloat32, kNcclSum, g->comm, st);
+        if (nrc != 0) return vlo_fail(VLO_E_HIP, rccl_err("ncclAllReduce", nrc));
+    } else {
+        PtrList L;
+        L.n = (int)t->ss.size();
+        for (int r = 0; r < L.n; ++r) L.p[r] = t->ss[r]->ppartial;
+        hipLaunchKernelGGL(tp_sum_kernel, dim3(1024), dim3(256), 0, st, L, count);
+        TP_TRY(hipGetLastError());
+    }
+    for (vlo_session *s : t->ss)
+        TP_TRY(add_rmsnorm_launch(s->ph, s->ppartial, 1, H, (const unsigned short *)norm_w(s->e, layer), s->px, H, H, c.rms_eps, m, st));
+    return VLO_OK;
+}
+static int tp_prefill(vlo_tp_session *t, const unsigned short *src, int m, bool want_last, unsigned short *all_logits, hipStream_t st) {
+    vlo_tp_group *g = t->g;
+    const int R = (int)t->ss.size();
+    const vlo_config &c = g->eng[0]->cfg;
+    const int H = c.hidden_size, V = c.vocab_size, hd = g->eng[0]->head_dim;
+    int rc;
+    for (int r = 0; r < R; ++r) {
+        vlo_session *s = t->ss[r];
+        if ((rc = ensure_prefill_ws(s))) return rc;
+        if (!s->ppartial) {
+            void *p = nullptr;
+            if ((rc = dev_alloc(&p, (size_t)VLO_PREFILL_TOKENS * H * 4))) return rc;
+            s->owned.push_back(p);
+            s->ppartial = (float *)p;
+        }
+        if ((rc = ensure_pages(s, s->len + m, st))) return rc;
+        TP_TRY(copy_rows_launch(src, s->ph, m, H, st));
+    }
+    for (int l = 0; l < c.num_layers; ++l) {
+        for (int r = 0; r < R; ++r) {           // attention half
+            vlo_session *s = t->ss[r];
+            vlo_engine *e = s->e;
+            const LayerWeights &L = e->layers[l];
+            const KvGeom kv = kv_geom(s);
+            const int qd = e->nh_l * hd, Nqkv = qd + 2 * e->nkv_l * hd;
+            if (l == 0) TP_TRY(add_rmsnorm_launch(s->ph, nullptr, 0, H, (const unsigned short *)L.ln_in, s->px, H, H, c.rms_eps, m, st));
+            if ((rc = prefill_gemm(s, s->px, L.qkv, m, Nqkv, H, s->pqkv, Nqkv, LLM_GEMM_BF16, st))) return rc;
+            TP_TRY(rope_kv_append_launch(s->pqkv, m, e->nh_l, (const unsigned short *)e->cos_tab, (const unsigned short *)e->sin_tab, kv, l, s->len, s->pq, st));
+            TP_TRY(attention_prefill_launch(s->pq, kv, l, e->nh_l, s->len, m, s->px, st));       // (prefill_ok: head dim 64 / 128; GQA groups the kernel is built for)
+            if ((rc = prefill_gemm(s, s->px, L.o, m, H, qd, s->ppartial, H, LLM_GEMM_F32, st))) return rc;
+        }
+        if ((rc = tp_prefill_exchange(t, m, norm_post, l, st))) return rc;      // exchange 1: h += sum(o partials); x = post-attention norm
+        for (int r = 0; r < R; ++r) {           // MLP half
+            vlo_session *s = t->ss[r];
+            vlo_engine *e = s->e;
+            const LayerWeights &L = e->layers[l];
+            if ((rc = prefill_gemm(s, s->px, L.gate_up, m, 2 * e->I_l, H, s->pact, e->I_l, LLM_GEMM_SWIGLU, st))) return rc;
+            if ((rc = prefill_gemm(s, s->pact, L.down, m, H, e->I_l, s->ppartial, H, LLM_GEMM_F32, st))) return rc;
+        }
+        // exchange 2: h += sum(down partials); x = the next layer's input norm — after the last layer the final norm, and only when logits are wanted
+        if (l + 1 < c.num_layers) {
+            if ((rc = tp_prefill_exchange(t, m, norm_in, l + 1, st))) return rc;
+        } else if (want_last || all_logits) {
+            if ((rc = tp_prefill_exchange(t, m, norm_final, 0, st))) return rc;
+        }
+    }
+    if (want_last || all_logits) {
+        // logits: the vocabulary shards of 16 rows at a time through the GEMV + the logits all-gather of the 16-row step (V / T is not a whole number
+        // of 256-column GEMM tiles for Llama-3's vocabulary at T = 8); every row, or the last one only
+        for (int r0 = all_logits ? 0 : m - 1; r0 < m; r0 += 16) {
+            const int nr = std::min(16, m - r0);
+            for (int r = 0; r < R; ++r) {
+                vlo_session *s = t->ss[r];
+                vlo_engine *e = s->e;
+                GemvArgs a = gemv_args(e->lm_head, s->px + (size_t)r0 * H, H, nr);
+                a.out_bf16 = s->logits_local; a.ldo = e->V_l;
+                TP_TRY(gemv_launch(a, e->lm_head.plan, XSRC_PLAIN, EPI_BF16, st));
+            }
+            if ((rc = tp_gather_logits(t, nr, st))) return rc;
+            if (all_logits) TP_TRY(hipMemcpyAsync(all_logits + (size_t)r0 * V, t->ss[0]->logits, (size_t)nr * V * 2, hipMemcpyDeviceToDevice, st));
+            for (int r = 0; r < R; ++r) {
+                t->ss[r]->last_logits = t->ss[r]->logits + (size_t)(nr - 1) * V;
+                t->ss[r]->has_logits = true;
+            }
+        }
+    }
+    for (int r = 0; r < R; ++r) t->ss[r]->len += m;
+    return VLO_OK;
+}
+
 int vlo_tp_llm_step(vlo_tp_session *t, const void *embeds_dev, int n, void *last_logits_dev, void *all_logits_dev, void *stream) {
     if (!t || !embeds_dev || n <= 0) return vlo_fail(VLO_E_INVALID, "bad tp_llm_step arguments");
     vlo_engine *e0 = t->g->eng[0];
@@ -691,13 +795,25 @@ int vlo_tp_llm_step(vlo_tp_session *t, const void *embeds_dev, int n, void *last
     hipStream_t st = (hipStream_t)stream;
     const int H = e0->cfg.hidden_size, V = e0->cfg.vocab_size;
     int rc;
-    for (int c0 = 0; c0 < n; c0 += 16) {
-        const int m = std::min(16, n - c0);
+    static const bool block_path = getenv("VLO_BLOCK_PATH") ? atoi(getenv("VLO_BLOCK_PATH")) != 0 : true;     // (0: 16-row steps everywhere, as vlo_llm_step)
+    const bool prefill = block_path && tp_prefill_ok(t);
+    for (int c0 = 0; c0 < n;) {
+        const int left = n - c0;
+        if (prefill && left >= VLO_PREFILL_MIN) {
+            // long inputs (teacher-forced evaluation, a long first prompt): blocks of up to VLO_PREFILL_TOKENS tokens, projections as GEMMs
+            const int m = std::min(VLO_PREFILL_TOKENS, left);
+            if ((rc = tp_prefill(t, (const unsigned short *)embeds_dev + (size_t)c0 * H, m, c0 + m == n,
+                                 all_logits_dev ? (unsigned short *)all_logits_dev + (size_t)c0 * V : nullptr, st))) return rc;
+            c0 += m;
+            continue;
+        }
+        const int m = std::min(16, left);
         const bool last = (c0 + m == n);
         if ((rc = tp_chunk(t, (const unsigned short *)embeds_dev + (size_t)c0 * H, m, last, all_logits_dev != nullptr, st))) return rc;
         if (all_logits_dev)
             TP_TRY(hipMemcpyAsync((unsigned short *)all_logits_dev + (size_t)c0 * V, t->ss[0]->logits, (size_t)m * V * 2,
                                   hipMemcpyDeviceToDevice, st));
+        c0 += m;
     }
     if (last_logits_dev) TP_TRY(hipMemcpyAsync(last_logits_dev, t->ss[0]->last_logits, (size_t)V * 2, hipMemcpyDeviceToDevice, st));
     return VLO_OK;
