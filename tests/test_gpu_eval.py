@@ -92,6 +92,14 @@ def test_session_fork_and_crop():
         b.close()
         c.close()
     k5 = a.read_kv(1, 0, 0, 0, 700).clone()
+    # a FORK on a page / tile boundary continued through the same path (444 tokens: the prefill GEMMs again, the same attention tiles) is the
+    # uninterrupted run bit for bit, and its KV pages are copies of the source's (a wrong page copy at the boundary would show in both)
+    f = a.fork(256)
+    assert torch.equal(f.read_kv(1, 0, 0, 0, 256), k5[:256])          # read_kv: [tokens][head_dim]
+    _, again_f = eng.llm_step(f, x[256:], want_last=False, want_all=True)
+    assert len(f) == 700 and torch.equal(again_f, full[256:])
+    assert torch.equal(f.read_kv(1, 0, 0, 0, 700), k5) and torch.equal(f.read_kv(1, 1, 1, 0, 700), a.read_kv(1, 1, 1, 0, 700))
+    f.close()
     a.crop(256)
     assert len(a) == 256
     _, again = eng.llm_step(a, x[256:], want_last=False, want_all=True)    # 444 tokens: the prefill path again, the same 64-query sub-blocks

@@ -125,3 +125,48 @@ def test_tp_session_fork_crop_and_stream_evaluate(golden_dir):
         np.testing.assert_allclose(out[1:], ref_bf16[1:], rtol=0, atol=1e-6, err_msg=f"case {c}")
         assert abs(out[0] - fp32[0]) <= 1.5 * abs(ref_bf16[0] - fp32[0]) + 0.01 * fp32[0], (c, out[0], ref_bf16[0], fp32[0])
         grp.close()
+
+
+@pytest.mark.parametrize("T", [2, 8])
+def test_tp_prefill_path_matches_oracle_and_the_16_row_steps(T, monkeypatch):
+    """csrc/tp.hip::tp_prefill (inputs of >= 256 tokens: every rank's SHARD of the projections as GEMMs, fp32 partial matrices all-reduced, the
+    prefill attention on the rank's own kv heads) with T logical ranks at the Llama-3-8B widths, two distinct layers: a 700-token input (a full
+    tile, a partial tile and more than one 256-row GEMM tile) 3-way against the oracle on its last rows' logits, then a frame step and a decode
+    step of the 16-row TP pipeline on the cache the prefill wrote.  The oracle's code runs on the GPU for the fp32 / bf16 reference passes
+    (tests/test_gpu_long.py::_gpu_oracles' argument)."""
+    from tests.test_gpu_long import _gpu_oracles
+    spec = O.LLM_SPECS["llama-3-8b-2l"]
+    w = O.init_llm_weights(spec, seed=6)
+    toks = O.default_tokens(spec, seed=7, n_start=35)
+    ref, gold = _gpu_oracles(spec, w)
+    grp = _group(spec, w, T)
+    sess = grp.new_session()
+    g = torch.Generator().manual_seed(21)
+    H = spec.hidden_size
+    rc = gc = None
+    x700 = None
+    full = None
+    for i, n in enumerate((700, 11, 1)):
+        x = ((torch.randn(n, H, generator=g) * 0.7).bfloat16() if n != 1 else ref.embed(torch.tensor([17]).cuda()).cpu()).cuda()
+        rl, rc = ref.forward(x, rc, logits_from=max(0, n - 16))
+        gl, gc = gold.forward(x, gc, logits_from=max(0, n - 16))
+        last, allr = grp.llm_step(sess, x, want_last=True, want_all=True)
+        torch.cuda.synchronize()
+        assert sess.get_seq_length() == len(rc) and torch.equal(last, allr[-1])
+        if i == 0:
+            x700, full = x, allr.clone()
+        tail = allr[max(0, n - 16):].float().cpu()
+        e = (tail - gl.cpu()).abs().max().item()
+        r = (rl.float().cpu() - gl.cpu()).abs().max().item()
+        scale = gl.abs().max().item()
+        print(f"[tp{T} prefill] step {i} (n={n}): engine err {e:.4g} ref-bf16(gpu torch) err {r:.4g} scale {scale:.3g}")
+        assert within_band(e, r, 1e-3 * scale, "test_gpu_tp.py:prefill"), f"step {i}: {e} vs {r}"
+    # a fork at a 256-token boundary continued with the remaining 444 tokens (again through the prefill path) reproduces the uninterrupted run's
+    # logits BIT FOR BIT: rows are independent in every GEMM, K is summed in the same order, a query walks the same key tiles
+    child = sess.fork(256)
+    _, again = grp.llm_step(child, x700[256:], want_last=True, want_all=True)
+    torch.cuda.synchronize()
+    assert child.get_seq_length() == 700 and torch.equal(again, full[256:])
+    child.close()
+    sess.close()
+    grp.close()

@@ -34,6 +34,13 @@ struct LayerWeights {
 
 struct VitState;
 
+struct PrefillWs {
+    unsigned short *ph = nullptr, *px = nullptr, *pqkv = nullptr, *pq = nullptr, *pact = nullptr;
+    void *wexp = nullptr;
+    size_t wexp_bytes = 0;
+    float *partial = nullptr;
+};
+
 struct vlo_engine {
     vlo_config cfg{};
     int device = 0;
@@ -65,6 +72,12 @@ struct vlo_engine {
 
     VitState *vit = nullptr;
     void *ingest = nullptr;                      // ingest.hip: cached tap tables + scratch of vlo_frame_ingest
+
+    // prefill-path workspaces (~275 MB at the 8B shape, + the fp8 expansion scratch) are POOLED per engine: a session takes a set at its first
+    // prefill block and hands it back when it is destroyed — stream_evaluate forks a session per turn, serving holds many sessions; each set is
+    // allocated (hipMalloc + a blocking memset) once and owned by exactly one session at a time (sessions step on streams of their own).
+    // Guarded by pool_mu; freed with the engine.
+    std::vector<PrefillWs> prefill_free;
 
     // live timing of the dominant kernel (vlo_profile_*)
     int prof_stride = 0;

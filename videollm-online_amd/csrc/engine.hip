@@ -121,6 +121,8 @@ void vlo_engine_destroy(vlo_engine *e) {
     hipSetDevice(e->device);
     for (auto &kv : e->raw) hipFree(kv.second.ptr);
     for (void *p : e->owned) hipFree(p);
+    for (const PrefillWs &w : e->prefill_free)
+        for (void *p : {(void *)w.ph, (void *)w.px, (void *)w.pqkv, (void *)w.pq, (void *)w.pact, w.wexp, (void *)w.partial}) if (p) hipFree(p);
     for (auto &pr : e->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     vit_destroy(e);
     ingest_destroy(e);
@@ -469,10 +471,12 @@ int vlo_session_reset(vlo_session *s) {
 }
 int64_t vlo_session_len(const vlo_session *s) { return s ? s->len : -1; }
 
+static void release_prefill_ws(vlo_session *s);      // (defined with the prefill path below)
 void vlo_session_destroy(vlo_session *s) {
     if (!s) return;
     hipSetDevice(s->e->device);
     hipDeviceSynchronize();
+    release_prefill_ws(s);
     vlo_session_reset(s);
     for (void *p : s->owned) hipFree(p);
     if (s->host_tok) hipHostFree(s->host_tok);
@@ -754,8 +758,19 @@ static int run_block(vlo_session *s, const unsigned short *src, int m, bool want
 
 // ---- prefill path: up to VLO_PREFILL_TOKENS new tokens per weight pass, the projections as MFMA-bound GEMMs (prefill.h) ------------------
 int ensure_prefill_ws(vlo_session *s) {
-    if (s->pact) return VLO_OK;                 // the LAST buffer allocated below: set only when all of them exist
+    if (s->pact) return VLO_OK;                 // the LAST buffer taken below: set only when all of them exist
     vlo_engine *e = s->e;
+    {
+        std::lock_guard<std::mutex> g(e->pool_mu);
+        if (!e->prefill_free.empty()) {         // a set another session handed back (engine.h: pooled per engine)
+            const PrefillWs w = e->prefill_free.back();
+            e->prefill_free.pop_back();
+            s->ph = w.ph; s->px = w.px; s->pqkv = w.pqkv; s->pq = w.pq;
+            s->pf_wexp = w.wexp; s->pf_wexp_bytes = w.wexp_bytes; s->ppartial = w.partial;
+            s->pact = w.pact;
+            return VLO_OK;
+        }
+    }
     const size_t H = e->cfg.hidden_size, I = e->I_l, qd = (size_t)e->nh_l * e->head_dim, kvd = (size_t)e->nkv_l * e->head_dim;
     const size_t R = VLO_PREFILL_TOKENS, RX = R + 256;        // X operands: the GEMM reads whole 256-row tiles
     struct { unsigned short **p; size_t elems; } want[] = {{&s->ph, R * H}, {&s->px, RX * std::max(H, qd)}, {&s->pqkv, R * (qd + 2 * kvd)},
@@ -765,12 +780,28 @@ int ensure_prefill_ws(vlo_session *s) {
         if (*w.p) continue;
         void *p = nullptr;
         int rc = dev_alloc(&p, w.elems * 2);
-        if (rc) return rc;
-        s->owned.push_back(p);
+        if (rc) return rc;                      // (a partly built set goes back to the pool with the session and is completed by its next user)
         HIP_TRY(hipMemset(p, 0, w.elems * 2));  // the spare rows are read (and dropped) by the GEMMs: keep them finite
         *w.p = (unsigned short *)p;
     }
     return VLO_OK;
+}
+
+// a destroyed session's prefill set goes back to its engine's pool (the device is idle: vlo_session_destroy synchronises first)
+static void release_prefill_ws(vlo_session *s) {
+    if (!s->ph && !s->px && !s->pqkv && !s->pq && !s->pact && !s->pf_wexp && !s->ppartial) return;
+    vlo_engine *e = s->e;
+    if (!s->pact) {                             // an allocation failed half way: nothing reusable
+        for (void *p : {(void *)s->ph, (void *)s->px, (void *)s->pqkv, (void *)s->pq, s->pf_wexp, (void *)s->ppartial}) if (p) hipFree(p);
+    } else {
+        PrefillWs w;
+        w.ph = s->ph; w.px = s->px; w.pqkv = s->pqkv; w.pq = s->pq; w.pact = s->pact;
+        w.wexp = s->pf_wexp; w.wexp_bytes = s->pf_wexp_bytes; w.partial = s->ppartial;
+        std::lock_guard<std::mutex> g(e->pool_mu);
+        e->prefill_free.push_back(w);
+    }
+    s->ph = s->px = s->pqkv = s->pq = s->pact = nullptr;
+    s->pf_wexp = nullptr; s->pf_wexp_bytes = 0; s->ppartial = nullptr;
 }
 
 // partial states for the fallback attention kernel (shapes attn_prefill_kernel is not instantiated for, VLO_PREFILL_FLASH=0): 67 MB at the 8B shape,
@@ -800,11 +831,11 @@ int prefill_gemm(vlo_session *s, const unsigned short *X, const PackedLinear &pl
     auto bytes = [](const PackedLinear &q) { return (size_t)q.NT * 16 * q.K * 2; };
     const size_t need = std::max({img, bytes(L0.qkv), bytes(L0.o), bytes(L0.gate_up), bytes(L0.down)});
     if (s->pf_wexp_bytes < need) {
-        HIP_TRY(hipStreamSynchronize(st));                       // (grows at most a few times: up to the largest projection)
+        HIP_TRY(hipStreamSynchronize(st));                       // (grows at most twice per pooled set: the largest layer projection, then the lm_head image)
         void *p = nullptr;
         int rc2 = dev_alloc(&p, need);
         if (rc2) return rc2;
-        s->owned.push_back(p);
+        if (s->pf_wexp) hipFree(s->pf_wexp);                     // the superseded scratch: nothing reads it after the synchronise above
         s->pf_wexp = p; s->pf_wexp_bytes = need;
     }
     HIP_TRY(expand_fp8_image_launch(pl.Wp, s->pf_wexp, pl.NT, K, st));

@@ -299,7 +299,8 @@ int vlo_tp_session_fork(vlo_tp_session *src, int64_t n_tokens, vlo_tp_session **
     t->g = src->g;
     for (vlo_session *s : src->ss) {
         vlo_session *d = nullptr;
-        TP_TRY(hipSetDevice(s->e->device));
+        const hipError_t de = hipSetDevice(s->e->device);          // (not TP_TRY: every error path below destroys the half-built session and its shards)
+        if (de != hipSuccess) { vlo_tp_session_destroy(t); return vlo_fail(VLO_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(de)); }
         const int rc = session_fork_shard(s, n_tokens, &d, stream);
         if (rc) { vlo_tp_session_destroy(t); return rc; }
         t->ss.push_back(d);
@@ -722,8 +723,7 @@ static int tp_prefill(vlo_tp_session *t, const unsigned short *src, int m, bool 
         if (!s->ppartial) {
             void *p = nullptr;
             if ((rc = dev_alloc(&p, (size_t)VLO_PREFILL_TOKENS * H * 4))) return rc;
-            s->owned.push_back(p);
-            s->ppartial = (float *)p;
+            s->ppartial = (float *)p;                 // part of the session's pooled prefill set from here on (engine.h)
         }
         if ((rc = ensure_pages(s, s->len + m, st))) return rc;
         TP_TRY(copy_rows_launch(src, s->ph, m, H, st));
@@ -884,7 +884,10 @@ int vlo_tp_greedy_generate(vlo_tp_session *t, const void *embeds_dev, int m, int
         if (!forced) {          // every rank reads the same token (the logits are gathered on every rank)
             TP_TRY(hipMemcpyAsync(s->host_tok, out_ids_dev + i, 8, hipMemcpyDeviceToHost, st));
             TP_TRY(hipStreamSynchronize(st));
-            if (*s->host_tok == eos_token_id) { s->has_logits = false; break; }   // same post-EOS state as vlo_greedy_generate
+            if (*s->host_tok == eos_token_id) {                                  // same post-EOS state as vlo_greedy_generate, on EVERY local shard
+                for (vlo_session *sh : t->ss) sh->has_logits = false;
+                break;
+            }
         }
         if (last) break;
         TP_TRY(embed_gather_launch((const unsigned short *)e->embed, out_ids_dev + i, 1, e->cfg.hidden_size, V, s->emb1, st));
