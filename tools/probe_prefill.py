@@ -17,9 +17,15 @@ def main():
     ap.add_argument("--model", default="llama-3-8b")
     ap.add_argument("--tokens", type=int, default=2048)
     ap.add_argument("--weight-dtype", default="bf16", choices=["bf16", "fp8"])
+    ap.add_argument("--tp", type=int, default=1, help="T logical tensor-parallel ranks on this one GPU (csrc/tp.hip::tp_prefill): the ranks' shards run one "
+                    "after the other, so time / T is what ONE rank of a T-GPU group spends on its GEMMs + attention (its all-reduce over xGMI not included)")
     args = ap.parse_args()
     cfg = EngineConfig(**SHAPES[args.model], kv_pool_tokens=max(16384, 2 * args.tokens), weight_dtype=args.weight_dtype)
-    eng = Engine(cfg)
+    if args.tp > 1:
+        from videollm_online_amd.engine import TpGroup
+        eng = TpGroup(cfg, args.tp)
+    else:
+        eng = Engine(cfg)
     random_llm_weights_to_engine(eng, cfg)
     eng.finalize()
     H = cfg.hidden_size
@@ -40,7 +46,8 @@ def main():
             eng.llm_step(sess, x)
         torch.cuda.synchronize()
         dt = time.time() - t0
-        print(f"[{mode}, {args.weight_dtype} weights] {args.tokens} tokens, all-row logits+stats={want_all}: {dt*1e3:.1f} ms = {args.tokens/dt:.0f} tok/s "
+        tp = f", TP={args.tp} logical ranks (per-rank share of the time: {dt * 1e3 / args.tp:.1f} ms)" if args.tp > 1 else ""
+        print(f"[{mode}, {args.weight_dtype} weights{tp}] {args.tokens} tokens, all-row logits+stats={want_all}: {dt*1e3:.1f} ms = {args.tokens/dt:.0f} tok/s "
               f"({dt*1e3/args.tokens*64:.2f} ms per 64 tokens)")
         sess.close()
 
