@@ -505,7 +505,7 @@ def test_frame_ingest_kernels_match_the_oracle(E, H, W, R, layout, a):
     eng.close()
 
 
-@pytest.mark.parametrize("n,N,K", [(11, 64, 512), (3, 48, 1024), (16, 32, 2048),
+@pytest.mark.parametrize("n,N,K", [(11, 64, 512), (3, 48, 1024), (16, 32, 2048), (7, 64, 1792),      # K = 1792: 4 waves x 14 fragments (the 8B down-proj shard at TP = 8)
                                    (5, 8336, 512)])      # 521 tiles: two groups per block (both register sets re-loaded), last group has one tile
 def test_fp8_weight_image_gemv(E, n, N, K):
     """The fp8 e4m3 weight image (two MFMA fragments per 16-byte lane load, e4m3 -> bf16 expansion in registers, per-output-channel

@@ -157,6 +157,33 @@ def test_fp8_70b_width_tp8_logical_ranks():
     grp.close()
 
 
+def test_fp8_8b_width_tp8_logical_ranks():
+    """The 8B layer shape sharded 8 ways with fp8 weights: the down-proj shard is K = 1792 — 56 fragments, which no 8-wave plan divides: it streams on
+    4 waves x 14 fragments (csrc/gemv.hip, the one 4-wave fp8 instantiation; before round 5 an fp8 8B engine could not shard beyond TP = 4) — o-proj
+    K = 512, qkv / gate-up K = 4096; logical ranks on one GPU, 3-way against the dequantised-weight oracle."""
+    from videollm_online_amd.engine import TpGroup
+    spec = O.LLM_SPECS["llama-3-8b-2l"]
+    w = O.init_llm_weights(spec, seed=6)
+    toks = O.default_tokens(spec, seed=7, n_start=35)
+    eng_w, ora_w, keep = _quantized(w)
+    ref, gold = _oracles(spec, ora_w, keep)
+    grp = TpGroup(_cfg(spec), 8)
+    grp.load_weights(eng_w)
+    grp.load_weight("rope.inv_freq", O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+    grp.finalize()
+    sess = grp.new_session()
+    rc = gc = None
+    for i, x in enumerate(_steps(spec, ref, toks, 6)[:4]):
+        rl, rc = ref.forward(x, rc)
+        gl, gc = gold.forward(x, gc)
+        last, allr = grp.llm_step(sess, x.cuda(), want_last=True, want_all=True)
+        torch.cuda.synchronize()
+        assert sess.get_seq_length() == len(rc)
+        _check("fp8 8b-2l tp8", i, allr.cpu(), rl, gl)
+    sess.close()
+    grp.close()
+
+
 def test_fp8_block_path_teacher_forced_rows():
     """A 150-token teacher-forced input on an fp8 engine: blocks of 64 + 64 + 22 tokens through gemm64_kernel<KF, EPI, WQ = 1>
     (csrc/prefill.hip: the fp8 image streamed once per 64 tokens), every row's logits against the reference arithmetic on the

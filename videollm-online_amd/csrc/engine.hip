@@ -220,7 +220,7 @@ static int make_linear(vlo_engine *e, PackedLinear *pl, int N, int K, bool allow
     pl->NT = (N + 15) / 16;
     pl->wq = fp8 ? 1 : 0;
     if (gemv_plan(K, allow_ksplit, &pl->plan)) return fail(VLO_E_UNSUPPORTED, "no GEMV plan for K=" + std::to_string(K));
-    if (fp8 && ((pl->plan.KF & 1) || pl->plan.NW != 8 || (K & 63)))
+    if (fp8 && ((pl->plan.KF & 1) || !(pl->plan.NW == 8 || (pl->plan.NW == 4 && pl->plan.KF == 14)) || (K & 63)))      // (4 x 14: K = 1792, gemv.hip)
         return fail(VLO_E_UNSUPPORTED, "fp8 weight image needs an even fragment count per wave (K=" + std::to_string(K) + ")");
     if (gemm64_plan(K, &pl->plan64, fp8))
         return fail(VLO_E_UNSUPPORTED, "no block-GEMM plan for K=" + std::to_string(K));
@@ -1263,7 +1263,7 @@ int vlo_test_gemv_fp8(const void *x_dev, const void *Wq_dev, const float *scale_
     GemvPlan plan;
     const bool whole_k = getenv("VLO_TEST_GEMV_WHOLE_K") && atoi(getenv("VLO_TEST_GEMV_WHOLE_K"));
     if (gemv_plan(K, !whole_k, &plan)) return fail(VLO_E_UNSUPPORTED, "no GEMV plan for K");
-    if ((plan.KF & 1) || plan.NW != 8 || (K & 63)) return fail(VLO_E_UNSUPPORTED, "fp8 weight image needs an even fragment count per wave for this K");
+    if ((plan.KF & 1) || !(plan.NW == 8 || (plan.NW == 4 && plan.KF == 14)) || (K & 63)) return fail(VLO_E_UNSUPPORTED, "fp8 weight image needs an even fragment count per wave for this K");
     const int NT = (N + 15) / 16;
     ScratchBufs sc;
     void *Wp = nullptr, *xp = nullptr;

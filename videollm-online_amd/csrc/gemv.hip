@@ -208,7 +208,7 @@ static hipError_t launch_variant(const GemvArgs &a, int xsrc, int epi, dim3 grid
         constexpr bool kHasBatch = (KF == 16 && NW == 8);                                         \
         const bool batch = kHasBatch && kBatch && a.KC > 1 && (EP) != EPI_BF16_GELU_ERF; \
         if (a.wq) {                                                                               \
-            if constexpr ((KF & 1) == 0 && NW == 8) {                                             \
+            if constexpr ((KF & 1) == 0 && (NW == 8 || (NW == 4 && KF == 14))) {    /* 4 x 14: K = 1792, the 8B down-proj shard at TP = 8 */ \
                 if constexpr (kHasBatch && (EP) != EPI_BF16_GELU_ERF) { \
                     if (batch) { hipLaunchKernelGGL((gemv16_kernel<KF, NW, XS, EP, 1, 4>), grid, block, lds, st, a); return hipGetLastError(); } \
                 }                                                                                 \
