@@ -172,6 +172,8 @@ int gemv_plan(int K, bool allow_ksplit, GemvPlan *p) {
 // rotary epilogue).  e.g. gate/up: 1792 tiles = 7.0 per CU as singles, 896 pairs = 3.5 -> 4 per CU (87.5 %).
 static bool single_tile_groups(const GemvArgs &a, const GemvPlan &p, int epi) {
     if (epi == EPI_ROPE) return false;
+    static const int force = env_int("VLO_GEMV_SINGLE", -1);     // experiments: 1 = single tiles wherever the epilogue allows, 0 = pairs everywhere
+    if (force >= 0) return force != 0;
     const int slots = 256 / p.ksplit > 0 ? 256 / p.ksplit : 1;
     auto eff = [&](int items) {
         const int rounds = (items + slots - 1) / slots;
