@@ -181,6 +181,73 @@ def test_tp_data_path_two_processes_rccl_standin():
     assert all(v[0] for v in vit.values()), f"frame-parallel and replicated vision embeddings differ: {vit}"
 
 
+_PREFILL_SPEC = (256, 256, 1, 4, 2, 256, 10000.0, 1e-5)      # per rank at T = 2: 2 heads of 64 on 1 kv head, 128 MLP columns, 128 logits: every shard GEMM a whole number of tiles
+
+
+def _tp_prefill_rccl_worker(rank, world, port, q):
+    """csrc/tp.hip::tp_prefill in the one-process-per-rank mode on the CPU: the matrix all-reduce of the fp32 partial sums is ncclAllReduce
+    (shared-memory stand-in), the logits shards travel through ncclAllGather."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from tests.hip_emul import build_emul
+    os.environ["VLO_RCCL_LIBRARY"] = build_emul.build_rccl_shim()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import vlo_oracle as O
+    from tests.hip_emul import emul_engine as E
+    spec = O.LlmSpec(*_PREFILL_SPEC, vision_hidden_size=128)
+    w = O.init_llm_weights(spec, seed=9)
+    uid = [E.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    r = E.EmulTpRankRccl(spec, world, rank, w, O.rope_inv_freq(spec.head_dim, spec.rope_theta), bytes(uid[0]), kv_pool_tokens=1024)
+    g = torch.Generator().manual_seed(4)
+    outs = []
+    for n in (300, 11):                                      # 300 tokens: the prefill path; then a 16-row TP step on the cache it wrote
+        x = (torch.randn(n, spec.hidden_size, generator=g) * 0.7).bfloat16()
+        outs.append(r.llm_step(x)[1].float().numpy())
+    q.put((rank, outs, r.comm_info()))
+    dist.barrier()
+    r.close()
+    dist.destroy_process_group()
+
+
+def test_tp_prefill_path_two_processes_rccl_standin():
+    """The tensor-parallel PREFILL path across two processes (round 5): every rank runs its shard of a 300-token input as GEMMs, the [300][H] fp32
+    partial matrices of o-proj / down-proj go through ncclAllReduce (here: the shared-memory stand-in behind the real entry points), both ranks
+    end with the same logits, 3-way against the oracle; a 16-row TP step then runs on the cache the prefill wrote."""
+    import numpy as np
+    from oracle import vlo_oracle as O
+    from tests.hip_emul import build_emul
+    if build_emul.clang() is None:
+        import pytest
+        pytest.skip("no host clang for the CPU emulation")
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_tp_prefill_rccl_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = {}
+    for _ in range(world):
+        rank, outs, info = q.get(timeout=1500)
+        res[rank] = (outs, info)
+    [p.join(120) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    assert res[0][1] == (2, 0) and res[1][1] == (2, 1)
+    spec = O.LlmSpec(*_PREFILL_SPEC, vision_hidden_size=128)
+    w = O.init_llm_weights(spec, seed=9)
+    ref, gold = O.LlamaOracle(spec, w, torch.bfloat16), O.LlamaOracle(spec, w, torch.float32)
+    g = torch.Generator().manual_seed(4)
+    rc = gc = None
+    for i, n in enumerate((300, 11)):
+        x = (torch.randn(n, spec.hidden_size, generator=g) * 0.7).bfloat16()
+        rl, rc = ref.forward(x, rc)
+        gl, gc = gold.forward(x, gc)
+        a, b = res[0][0][i], res[1][0][i]
+        assert np.array_equal(a, b), f"step {i}: the two ranks hold different logits"
+        e = np.abs(a - gl.numpy()).max()
+        r = (rl.float() - gl).abs().max().item()
+        assert within_band(e, r, 1e-3 * gl.abs().max().item(), "test_multiproc_cpu.py:tp_prefill"), f"step {i}: engine err {e} vs reference-bf16 err {r}"
+
+
 def _run_bench(argv, env_extra, timeout=300):
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
