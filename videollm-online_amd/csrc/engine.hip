@@ -780,7 +780,7 @@ int ensure_prefill_ws(vlo_session *s) {
         if (*w.p) continue;
         void *p = nullptr;
         int rc = dev_alloc(&p, w.elems * 2);
-        if (rc) return rc;                      // (a partly built set goes back to the pool with the session and is completed by its next user)
+        if (rc) return rc;                      // (a partly built set is freed with the session: release_prefill_ws)
         HIP_TRY(hipMemset(p, 0, w.elems * 2));  // the spare rows are read (and dropped) by the GEMMs: keep them finite
         *w.p = (unsigned short *)p;
     }
