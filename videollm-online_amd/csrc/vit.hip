@@ -25,77 +25,10 @@
 
 #include "vit_gemm.inc"
 
-// ------------------------------------------------------------------------------------
-// LayerNorm (fp32 in, fp32 stats) -> fp16 (matmul operand) and optionally fp32
-// ------------------------------------------------------------------------------------
-// one WAVE per token row (4 rows per block): the row lives in registers (D / 64 floats per lane, coalesced float4 loads), mean and
-// variance are two wave reductions — no LDS, no block barrier; D <= 2048, D % 4 == 0
-#define LN_MAXC 8
-// RED: the residual GEMM before this LayerNorm ran split-K (vit_gemm.inc::gemm_launch_slab): the row first becomes
-// x + fp16(slab[0] + ... + slab[ks-1] + bias) — the epilogue the un-split GEMM applies itself (EP_RESID) — and is written back.
-template <bool RED>
-__global__ __launch_bounds__(256) void vit_layernorm_kernel(float *__restrict__ x, const float *__restrict__ w,
-                                                            const float *__restrict__ b, f16_t *__restrict__ out16,
-                                                            float *__restrict__ out32, int M, int D, float eps,
-                                                            const float *__restrict__ slab, int ks, size_t slab_stride,
-                                                            const float *__restrict__ gbias) {
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    float *xr = x + (size_t)row * D;
-    float4 v[LN_MAXC];
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
-        const int i = (c * 64 + lane) * 4;
-        v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < D) {
-            v[c] = *reinterpret_cast<const float4 *>(xr + i);
-            if (RED) {
-                float4 t = *reinterpret_cast<const float4 *>(slab + (size_t)row * D + i);
-#pragma unroll
-                for (int z = 1; z < 4; ++z) {                 // ks <= 4; unrolled so that the slab loads go out together
-                    if (z < ks) {
-                        const float4 u = *reinterpret_cast<const float4 *>(slab + (size_t)z * slab_stride + (size_t)row * D + i);
-                        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-                    }
-                }
-                const float4 gb = *reinterpret_cast<const float4 *>(gbias + i);
-                v[c].x += rh(t.x + gb.x); v[c].y += rh(t.y + gb.y); v[c].z += rh(t.z + gb.z); v[c].w += rh(t.w + gb.w);
-                *reinterpret_cast<float4 *>(xr + i) = v[c];
-            }
-            s += v[c].x + v[c].y + v[c].z + v[c].w;
-        }
-    }
-    const float mean = wave_sum(s) / (float)D;
-    float q = 0.f;
-#pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
-        const int i = (c * 64 + lane) * 4;
-        if (i < D) {
-            const float d0 = v[c].x - mean, d1 = v[c].y - mean, d2 = v[c].z - mean, d3 = v[c].w - mean;
-            q += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-        }
-    }
-    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
-#pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
-        const int i = (c * 64 + lane) * 4;
-        if (i < D) {
-            const float4 wv = *reinterpret_cast<const float4 *>(w + i);
-            const float4 bv = *reinterpret_cast<const float4 *>(b + i);
-            const float o0 = (v[c].x - mean) * rs * wv.x + bv.x, o1 = (v[c].y - mean) * rs * wv.y + bv.y;
-            const float o2 = (v[c].z - mean) * rs * wv.z + bv.z, o3 = (v[c].w - mean) * rs * wv.w + bv.w;
-            if (out16) {
-                ushort4 o;
-                o.x = f2h(o0); o.y = f2h(o1); o.z = f2h(o2); o.w = f2h(o3);
-                *reinterpret_cast<ushort4 *>(out16 + (size_t)row * D + i) = o;
-            }
-            if (out32) *reinterpret_cast<float4 *>(out32 + (size_t)row * D + i) = make_float4(o0, o1, o2, o3);
-        }
-    }
-}
+#include "vit_ln.inc"
 
 #include "vit_attn.inc"
+#include "vit_tall.inc"
 
 // MAP head attention: one probe query per head over S keys.  grid = (heads, B), 256 threads.
 // kv: fp16 [B*S][2D] (K | V row-major), qp: fp16 [D] (probe @ Wq + bq, precomputed at load)
@@ -448,7 +381,13 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
     float *const w_slab = v->slab + r0 * D;
     const size_t slab_stride = (size_t)v->slab_rows * D;
     const bool slab_ok = r0 + (size_t)M <= (size_t)v->slab_rows;
-    const int ks_out = slab_ok ? vit_resid_ksplit(M, D, D) : 1, ks_fc2 = slab_ok ? vit_resid_ksplit(M, D, I) : 1;
+    // one frame (two): every GEMM on the tall tiles, one workgroup per CU (vit_tall.inc); fc2 (K = 4 x hidden) as 4 K slices into the slabs
+    static const int tall_max_rows = getenv("VLO_VIT_TALL_MAX_ROWS") ? atoi(getenv("VLO_VIT_TALL_MAX_ROWS")) : 1152;
+    static const int tall_ks_out = getenv("VLO_VIT_TALL_KS_OUT") ? atoi(getenv("VLO_VIT_TALL_KS_OUT")) : 1;
+    static const int tall_ks_fc2 = getenv("VLO_VIT_TALL_KS_FC2") ? atoi(getenv("VLO_VIT_TALL_KS_FC2")) : 4;
+    const bool tall = M <= tall_max_rows && slab_ok && D % 64 == 0 && I % 64 == 0 && D >= 5 * GEMM_BK * tall_ks_out && I >= 5 * GEMM_BK * tall_ks_fc2 &&
+                      D % (GEMM_BK * tall_ks_out) == 0 && I % (GEMM_BK * tall_ks_fc2) == 0;
+    const int ks_out = tall ? tall_ks_out : (slab_ok ? vit_resid_ksplit(M, D, D) : 1), ks_fc2 = tall ? tall_ks_fc2 : (slab_ok ? vit_resid_ksplit(M, D, I) : 1);
     int pend_ks = 0;                          // K slices waiting in the slab for the next LayerNorm (0 = none)
     const float *pend_bias = nullptr;
     auto layernorm = [&](const float *g, const float *b, f16_t *o16, float *o32) {
@@ -466,10 +405,10 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
         if (ks > 1) {
             a.out32 = w_slab; a.ldo = v->slab_rows;
             pend_ks = ks; pend_bias = bias;
-            return gemm_launch_slab(a, ks, st);
+            return tall ? gemm_launch_tall<EP_SLAB>(a, ks, st) : gemm_launch_slab(a, ks, st);
         }
         a.out32 = w_h;
-        return gemm_launch<EP_RESID>(a, st);
+        return tall ? gemm_launch_tall<EP_RESID>(a, 1, st) : gemm_launch<EP_RESID>(a, st);
     };
     {   // patch embed + pos  -> residual stream h (fp32)
         GemmArgs a{};
@@ -484,7 +423,7 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
             GemmArgs a{};
             a.xpad = 1; a.X = w_x16; a.W = Ly.wqkv; a.bias = Ly.bqkv; a.out16 = w_qk16; a.outVT = w_vT;
             a.M = M; a.N = 3 * D; a.K = D; a.ldx = D; a.ldo = 2 * v->nh * v->hdk; a.S = S; a.Sp = v->Sp; a.D = D; a.hd = v->hd; a.hdk = v->hdk; a.hdv = v->hdv;
-            VIT_TRY(gemm_launch<EP_QKV>(a, st));
+            VIT_TRY(tall ? gemm_launch_tall<EP_QKV>(a, 1, st) : gemm_launch<EP_QKV>(a, st));
         }
         // batched frames: one workgroup per (frame, head) with K and V^T resident in LDS; few frames: 64-query tiles, keys split over 4 waves
         static const int head_min = getenv("VLO_VIT_ATTN_HEAD_MIN") ? atoi(getenv("VLO_VIT_ATTN_HEAD_MIN")) : 96;     // workgroups; 0 = never
@@ -512,7 +451,7 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
             GemmArgs a{};
             a.xpad = 1; a.X = w_x16; a.W = Ly.w1; a.bias = Ly.b1; a.out16 = w_mid16;
             a.M = M; a.N = I; a.K = D; a.ldx = D; a.ldo = I;
-            VIT_TRY(gemm_launch<EP_F16_GELU>(a, st));
+            VIT_TRY(tall ? gemm_launch_tall<EP_F16_GELU>(a, 1, st) : gemm_launch<EP_F16_GELU>(a, st));
         }
         VIT_TRY(resid_gemm(w_mid16, Ly.w2, Ly.b2, I, ks_fc2));
     }
