@@ -51,6 +51,8 @@ def build(force=False, sanitize=None):
         # csrc/gemv_engine.inc::eng_glds16 — one direct-to-LDS piece issued in inline asm (invisible to hipcc's vmcnt bookkeeping): lane l moves 16
         # bytes from its own gsrc to lds_dst + 16 l
         src = re.sub(r'asm volatile\("s_mov_b32 %0, m0[^;]*;', "emul_glds(gsrc, (char *)lds_dst + (threadIdx.x & 63) * 16, 16); (void)keep; (void)dst;", src)
+        # csrc/vit_tall.inc::glds16_saddr — the same with an SGPR base + per-lane byte offset
+        src = re.sub(r'asm volatile\("s_mov_b32 m0, %2[^;]*;', "emul_glds((const char *)sbase + voff, (char *)lds_dst + (threadIdx.x & 63) * 16, 16); (void)dst;", src)
         src = re.sub(r'asm volatile\(""\s*:::\s*"memory"\);', ";", src)                  # compiler-only memory barrier
         src = re.sub(r'asm(?: volatile)?\(""\s*:\s*"\+v"\(\w+\)\);', ";", src)      # optimisation barrier on a VGPR value
         src = re.sub(r'asm\("s_nop 7\\n\\ts_nop 3\\n\\tv_max3_f32[^;]*;', "r = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), fmaxf(fmaxf(a4, a5), fmaxf(a6, a7)));", src)

@@ -621,6 +621,48 @@ def test_vision_tower_with_padded_head_dim_mlp_width_and_patch_k(E):
 
 
 
+ONE_FRAME_CHILD = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from oracle import vlo_oracle as O
+from tests.hip_emul import emul_engine as E
+vspec = O.VitSpec(hidden_size=320, intermediate_size=1280, num_layers=1, num_heads=5, image_size=64, patch_size=16, pooled=(3, 3))
+spec = O.LlmSpec(128, 192, 1, 2, 2, 256, 10000.0, 1e-5, vision_hidden_size=vspec.hidden_size)
+w, vw = O.init_llm_weights(spec, seed=3), O.init_vit_weights(vspec, seed=4)
+ref = O.LlamaOracle(spec, w, torch.bfloat16)
+eng = E.EmulEngine(spec, vit=vspec).load_weights({**w, **vw}, O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+for B in (1, 2):
+    frames = O.synthetic_frames(B, vspec.image_size, seed=7 + B)
+    gold = O.LlamaOracle(spec, w, torch.float32).visual_embed(vw, vspec, frames)
+    amp = ref.visual_embed(vw, vspec, frames, mm_dtype=torch.float16)
+    cpu = ref.visual_embed(vw, vspec, frames)
+    out = eng.visual_embed(frames)
+    scale = gold.abs().max().item()
+    e = (out.float() - gold).abs().max().item()
+    a = (amp.float() - gold).abs().max().item()
+    r = (cpu.float() - gold).abs().max().item()
+    print(f"[emul one-frame path B={B}] engine err {e:.4g} fp16-autocast err {a:.4g} cpu-ref err {r:.4g} scale {scale:.3g}")
+    assert e <= 2.0 * max(a, r) + 2 * 2 ** -8 * scale, (B, e, a, r)
+eng.close()
+print("OKPP")
+"""
+
+
+def test_one_frame_path_tall_tiles_split_attention_and_row_head_in_emulation(E):
+    """The one-frame encode of round 6 (csrc/vit_tall.inc: 144 x 64 tiles with the half-tile software pipeline and counted waits, fc2 as 4 K slices
+    into slabs; vit_attn.inc::vit_attn_split8_kernel; vit.hip::vit_im2col_kernel + the tall patch-embed GEMM; vit_rowvec_kernel in the MAP head) on
+    the smallest tower that takes it (hidden 320 = 5 heads of 64, MLP 1280, 16 + 1 tokens), one and two frames, against the oracle with the
+    tolerance of the ViT tests — with the emulated direct-to-LDS loads landing as LATE as the hardware may land them (only at the counted
+    s_waitcnt that retires them: a wait count one piece too generous reads stale shared memory and fails)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VLO_EMUL_GLDS="late")
+    r = subprocess.run([sys.executable, "-c", ONE_FRAME_CHILD % root], env=env, capture_output=True, text=True, timeout=1800)
+    print(r.stdout[-600:])
+    assert r.returncode == 0 and "OKPP" in r.stdout, r.stderr[-2000:]
+
+
 def test_unsupported_head_dims_are_rejected_not_silently_wrong(E):
     """vit_finalize takes head dim 64 exactly or 68..80 (padded storage).  52 / 56 / 60 also round up to 64 columns / rows, but the
     unpadded kernel would store 64 columns per head at a stride of hd — the engine must refuse them (round-3 advisor finding)."""

@@ -75,6 +75,26 @@ static bool same(const void *p0, const void *p1, size_t n, bool f32 = false) {
     return false;
 }
 
+// phase boundaries of one launch of the tall kernel (VIT_STAMP, s_memrealtime = 100 MHz): mean and latest workgroup, relative to the first workgroup's start
+static unsigned long long *g_stamps = nullptr;
+static void stamp_report(const char *what, int blocks, const std::function<void()> &launch) {
+    CK(hipMemsetAsync(g_stamps, 0, (size_t)blocks * 32, st));
+    launch();
+    CK(hipStreamSynchronize(st));
+    std::vector<unsigned long long> h((size_t)blocks * 4);
+    CK(hipMemcpy(h.data(), g_stamps, (size_t)blocks * 32, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull;
+    for (int b = 0; b < blocks; ++b) if (h[(size_t)b * 4]) t0 = std::min(t0, h[(size_t)b * 4]);
+    printf("      %s, us after the first workgroup's start (mean / latest workgroup):", what);
+    const char *names[4] = {"start", "first K tile landed", "K loop done", "end"};
+    for (int k = 0; k < 4; ++k) {
+        double sum = 0, mx = 0; int n = 0;
+        for (int b = 0; b < blocks; ++b) { const unsigned long long v = h[(size_t)b * 4 + k]; if (v) { const double us = (double)(v - t0) / 100.0; sum += us; mx = std::max(mx, us); ++n; } }
+        if (n) printf(" %s %.2f / %.2f;", names[k], sum / n, mx);
+    }
+    printf("\n");
+}
+
 int main(int argc, char **argv) {
     std::vector<int> frames;
     for (int i = 1; i < argc; ++i) frames.push_back(atoi(argv[i]));
@@ -104,6 +124,7 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&lnw, D * 4));
     CK(hipMalloc(&lnb, D * 4));
     CK(hipMalloc(&slab, 4 * maxM * D * 4));
+    CK(hipMalloc(&g_stamps, 1024 * 32));
     for (int i = 0; i < 3; ++i) CK(hipMalloc(&h[i], maxM * D * 4));
     for (int i = 0; i < 2; ++i) {
         CK(hipMalloc(&x16[i], (maxM + 256) * D * 2));
@@ -167,6 +188,10 @@ int main(int argc, char **argv) {
             const char *v = ok ? "bit-exact" : "MISMATCH";
             report(B, g.name, "cur (64x64) GEMM alone", t_cur, flop, "ref");
             report(B, g.name, "tall GEMM alone", t_tall, flop, v);
+            stamp_report("tall GEMM", ((M + 143) / 144) * (g.N / 64), [&]() {
+                GemmArgs b = a; b.X = x16[1]; b.W = Wcopy(9, wsz); b.out16 = out16[1]; b.outVT = vT[1]; b.stamps = g_stamps;
+                CK(g.ep == EP_QKV ? (gemm_launch_tall<EP_QKV>(b, 1, st)) : (gemm_launch_tall<EP_F16_GELU>(b, 1, st)));
+            });
             report(B, g.name, "LayerNorm launch + cur GEMM", t_lcur, flop, "ref");
             report(B, g.name, "LayerNorm launch + tall GEMM", t_ltall, flop, v);
         }
@@ -195,6 +220,7 @@ int main(int argc, char **argv) {
             CK(hipStreamSynchronize(st));
             const char *vd = same(h[0], h[1], (size_t)M * D * 4, true) ? "bit-exact" : "MISMATCH";
             report(B, g.name, "tall direct (EP_RESID)", t_dt, flop, vd);
+            stamp_report("tall direct", ((M + 143) / 144) * (D / 64), [&]() { GemmArgs b = a; b.W = Wcopy(9, wsz); b.out32 = h[1]; b.stamps = g_stamps; CK((gemm_launch_tall<EP_RESID>(b, 1, st))); });
             report(B, g.name, "cur direct + LayerNorm launch", t_dcl, flop, "ref");
             report(B, g.name, "tall direct + LayerNorm launch", t_dtl, flop, vd);
             for (int ks : {2, 4}) {
@@ -213,6 +239,7 @@ int main(int argc, char **argv) {
                 report(B, g.name, nm, t_st, flop, vs);
                 snprintf(nm, sizeof nm, "tall slab k%d alone", ks);
                 report(B, g.name, nm, t_st0, flop, vs);
+                stamp_report("tall slab", ((M + 143) / 144) * (D / 64) * ks, [&]() { GemmArgs b = a; b.W = Wcopy(9, wsz); b.out32 = slab; b.ldo = M; b.stamps = g_stamps; CK((gemm_launch_tall<EP_SLAB>(b, ks, st))); });
             }
         }
     }

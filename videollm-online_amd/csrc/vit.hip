@@ -32,9 +32,12 @@
 
 // MAP head attention: one probe query per head over S keys.  grid = (heads, B), 256 threads.
 // kv: fp16 [B*S][2D] (K | V row-major), qp: fp16 [D] (probe @ Wq + bq, precomputed at load)
+// Scores: a thread per key (its K row: hd / 8 sixteen-byte loads, all in flight); P.V: threads = (hd / 4 dim groups) x (key groups), a thread walks
+// every nkg-th key with one 8-byte load of V per key, the key groups' partial sums meet in LDS.  (Round 5's form gave a thread ONE dim and a
+// quarter of the keys, two-byte loads a 4 KiB stride apart: 48.7 us for one frame.)
 __global__ __launch_bounds__(256) void map_attn_kernel(const f16_t *__restrict__ kv, const f16_t *__restrict__ qp,
                                                        f16_t *__restrict__ out, int S, int D, int hd, float scale) {
-    extern __shared__ float prob[];            // [S]
+    extern __shared__ float prob[];            // [max(S, 256 * 4)]
     __shared__ float sm[16];
     const int head = blockIdx.x, b = blockIdx.y;
     const f16_t *kb = kv + (size_t)b * S * 2 * D + (size_t)head * hd;
@@ -62,19 +65,99 @@ __global__ __launch_bounds__(256) void map_attn_kernel(const f16_t *__restrict__
     }
     sum = block_sum(sum, sm);
     __syncthreads();
-    // 256 threads = hd(64) x 4 key groups
-    const int d = threadIdx.x % hd, grp = threadIdx.x / hd, ng = blockDim.x / hd;
-    float acc = 0.f;
-    for (int t = grp; t < S; t += ng) acc += rh(prob[t] / sum) * h2f(vb[(size_t)t * 2 * D + d]);
-    __syncthreads();
-    float *red = prob;                          // reuse
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    if (grp == 0) {
-        float tot = 0.f;
-        for (int g = 0; g < ng; ++g) tot += red[g * hd + d];
-        out[(size_t)b * D + head * hd + d] = f2h(tot);
+    // threads = ndg dim groups (4 dims each) x nkg key groups
+    const int ndg = hd >> 2, nkg = (int)blockDim.x / ndg;
+    const int dg = threadIdx.x % ndg, kg = threadIdx.x / ndg;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kg < nkg) {
+#pragma unroll 4
+        for (int t = kg; t < S; t += nkg) {
+            const float p = rh(prob[t] / sum);
+            const uint2 v4 = *reinterpret_cast<const uint2 *>(vb + (size_t)t * 2 * D + dg * 4);
+            acc.x += p * h2f((f16_t)(v4.x & 0xffffu)); acc.y += p * h2f((f16_t)(v4.x >> 16));
+            acc.z += p * h2f((f16_t)(v4.y & 0xffffu)); acc.w += p * h2f((f16_t)(v4.y >> 16));
+        }
     }
+    __syncthreads();
+    float4 *red = reinterpret_cast<float4 *>(prob);          // reuse: [nkg][ndg]
+    if (kg < nkg) red[kg * ndg + dg] = acc;
+    __syncthreads();
+    if (threadIdx.x < ndg) {
+        float4 tot = red[threadIdx.x];
+        for (int g = 1; g < nkg; ++g) { const float4 u = red[g * ndg + threadIdx.x]; tot.x += u.x; tot.y += u.y; tot.z += u.z; tot.w += u.w; }
+        ushort4 o;
+        o.x = f2h(tot.x); o.y = f2h(tot.y); o.z = f2h(tot.z); o.w = f2h(tot.w);
+        *reinterpret_cast<ushort4 *>(out + (size_t)b * D + head * hd + threadIdx.x * 4) = o;
+    }
+}
+
+// Linear on a handful of rows (the MAP head's out-proj / fc1 / fc2 run on ONE row per frame): a tile GEMM would walk K = 4096 in 64 steps on 16
+// workgroups (21.8 us for one frame).  Here a wave owns one output column: lanes stride K in 16-byte chunks against up to 8 rows at a time (fp32
+// sums, one wave reduction per row, epilogue on lane 0), rows beyond 8 in further passes over the column — every row's sum is the same sequence of
+// operations whatever the batch size, so a frame encodes to the same bits alone or in a batch.  grid = N / 4, 256 threads.  Epilogues as
+// gemm_store4 (same rounding points).
+template <int EP>
+__global__ __launch_bounds__(256) void vit_rowvec_kernel(GemmArgs a) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= a.N) return;
+    const f16_t *wr = a.W + (size_t)n * a.K;
+    const float bias = a.bias[n];
+    for (int m0 = 0; m0 < a.M; m0 += 8) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int c = lane * 8; c < a.K; c += 512) {
+            const uint4 wv = *reinterpret_cast<const uint4 *>(wr + c);
+            const f16_t *we = reinterpret_cast<const f16_t *>(&wv);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                if (m0 + m < a.M) {
+                    const uint4 xv = *reinterpret_cast<const uint4 *>(a.X + (size_t)(m0 + m) * a.ldx + c);
+                    const f16_t *xe = reinterpret_cast<const f16_t *>(&xv);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[m] += h2f(xe[j]) * h2f(we[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[m] = wave_sum(acc[m]);
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                if (m0 + m >= a.M) break;
+                const float v = acc[m] + bias;
+                if (EP == EP_F16) a.out16[(size_t)(m0 + m) * a.ldo + n] = f2h(v);
+                else if (EP == EP_F16_GELU) a.out16[(size_t)(m0 + m) * a.ldo + n] = f2h(gelu_tanh_f(rh(v)));
+                else if (EP == EP_RESID) a.out32[(size_t)(m0 + m) * a.N + n] += rh(v);
+            }
+        }
+    }
+}
+template <int EP>
+static hipError_t rowvec_launch(const GemmArgs &a, hipStream_t st) {
+    if (a.M < 1 || (a.K & 7) || (a.ldx & 7)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((vit_rowvec_kernel<EP>), dim3((a.N + 3) / 4), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// frames (uint8 NCHW) -> the patch-embed GEMM's A operand, fp16 [M][Kp] (k = ch P P + py P + px, zero columns from Kreal up): the rescale + normalise of
+// vision_live.py:12 exactly as the fused A-tile load of vit_gemm_kernel<EP_PATCH> computes it (same fp32 operations, same fp16 rounding).  One frame:
+// this launch + the tall GEMM replace the register-ring kernel (30 us -> ~11).  8 elements per thread.
+__global__ __launch_bounds__(256) void vit_im2col_kernel(const uint8_t *__restrict__ frames, f16_t *__restrict__ X, int M, int S, int G, int R, int P, int Kreal, int Kp) {
+    const int cpr = Kp / 8;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * cpr) return;
+    const int m = idx / cpr, k0 = (idx - m * cpr) * 8;
+    const int b = m / S, t = m % S, gy = t / G, gx = t % G;
+    f16_t o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int kj = k0 + j;
+        const bool live = kj < Kreal;
+        const int ch = kj / (P * P), rem = kj % (P * P), py = rem / P, px = rem % P;
+        const uint8_t e = live ? frames[(((size_t)b * 3 + ch) * R + gy * P + py) * R + gx * P + px] : (uint8_t)0;
+        const float x = (float)e * 0.00392156862745098f;
+        o[j] = live ? f2h((x - 0.5f) / 0.5f) : (f16_t)0;
+    }
+    *reinterpret_cast<uint4 *>(X + (size_t)m * Kp + k0) = *reinterpret_cast<const uint4 *>(o);
 }
 
 // CLS + pooled tokens -> bf16 [B][1 + ph*pw][D]   (adaptive_avg_pool2d with exact G/ph blocks; vision_live.py:16-30)
@@ -117,6 +200,7 @@ __global__ void f16_to_f32_kernel(const f16_t *__restrict__ a, float *__restrict
 // ------------------------------------------------------------------------------------
 static size_t attn_lds(int hdv, int qs = 4) { return (size_t)4 * qs * (hdv / 16) * 64 * 16 + 4 * qs * 16 * 2 * 4; }     // O partials + (m, l) of vit_attn_kernel
 static const size_t kAttnLds = attn_lds(64);
+static const size_t kAttn8Lds = (size_t)8 * 4 * 4 * 64 * 16 + 8 * 4 * 16 * 2 * 4;     // vit_attn_split8_kernel: 8 waves' O partials + (m, l)
 
 struct VitLayer {
     const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
@@ -300,6 +384,7 @@ int vit_finalize(vlo_engine *e) {
 #undef TK
 #undef PAD
     VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnLds));
+    VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_split8_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttn8Lds));
     VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_kernel<96, 80>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds(80)));
     VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_kernel<96, 80, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds(80, 2)));
     {
@@ -414,7 +499,15 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
         GemmArgs a{};
         a.frames = frames_dev; a.W = v->wpe; a.bias = v->bpe; a.out32 = w_h; a.pos = v->pos;
         a.M = M; a.N = D; a.K = v->Kpe; a.Kreal = v->Kpe_real; a.S = S; a.R = v->R; a.P = v->P; a.G = v->G;
-        VIT_TRY(gemm_launch<EP_PATCH>(a, st));
+        if (tall && v->Kpe >= 5 * GEMM_BK && (size_t)v->Kpe <= (size_t)I) {
+            // one frame: the A operand as its own launch into the (still unused) MLP buffer, then the tall GEMM
+            const int chunks = M * (v->Kpe / 8);
+            hipLaunchKernelGGL(vit_im2col_kernel, dim3((chunks + 255) / 256), dim3(256), 0, st, frames_dev, w_mid16, M, S, v->G, v->R, v->P, v->Kpe_real, v->Kpe);
+            a.X = w_mid16; a.ldx = v->Kpe;
+            VIT_TRY(gemm_launch_tall<EP_PATCH>(a, 1, st));
+        } else {
+            VIT_TRY(gemm_launch<EP_PATCH>(a, st));
+        }
     }
     for (int l = 0; l < v->L; ++l) {
         const VitLayer &Ly = v->layers[l];
@@ -426,11 +519,14 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
             VIT_TRY(tall ? gemm_launch_tall<EP_QKV>(a, 1, st) : gemm_launch<EP_QKV>(a, st));
         }
         // batched frames: one workgroup per (frame, head) with K and V^T resident in LDS; few frames: 64-query tiles, keys split over 4 waves
+        static const int attn8_on = getenv("VLO_VIT_ATTN8") ? atoi(getenv("VLO_VIT_ATTN8")) : 1;
         static const int head_min = getenv("VLO_VIT_ATTN_HEAD_MIN") ? atoi(getenv("VLO_VIT_ATTN_HEAD_MIN")) : 96;     // workgroups; 0 = never
         static const int tiles_min = getenv("VLO_VIT_ATTN_TILES_MIN") ? atoi(getenv("VLO_VIT_ATTN_TILES_MIN")) : 192;   // workgroups of the tile-streamed padded-head kernel; 0 = never
         if (head_min > 0 && B * v->nh >= head_min && v->attn_head_lds > 0)
             hipLaunchKernelGGL((vit_attn_head_kernel<0>), dim3((S + 575) / 576, v->nh, B), dim3(768), v->attn_head_lds, st, w_qk16, w_vT, w_att16, S, D, v->nh,
                                scale * 1.4426950408889634f, v->attn_vrs);
+        else if (v->hdk == 64 && tall && S <= 768 && attn8_on)
+            hipLaunchKernelGGL((vit_attn_split8_kernel<3>), dim3((S + 63) / 64, v->nh, B), dim3(512), kAttn8Lds, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
         else if (v->hdk == 64)
             hipLaunchKernelGGL((vit_attn_kernel<64>), dim3((S + 63) / 64, v->nh, B), dim3(256), kAttnLds, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
         else if (B * v->nh * ((S + 255) / 256) >= tiles_min && tiles_min > 0) {
@@ -463,12 +559,12 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
         a.M = M; a.N = 2 * D; a.K = D; a.ldx = D; a.ldo = 2 * D;
         VIT_TRY(gemm_launch<EP_F16>(a, st));
     }
-    hipLaunchKernelGGL(map_attn_kernel, dim3(v->nh, B), dim3(256), (size_t)std::max(S, 256) * 4, st, w_kv16, v->q_probe, w_hatt16, S, D, v->hd, scale);
+    hipLaunchKernelGGL(map_attn_kernel, dim3(v->nh, B), dim3(256), (size_t)std::max(S, 1024) * 4, st, w_kv16, v->q_probe, w_hatt16, S, D, v->hd, scale);
     {   // out_proj -> attention output a (fp16), kept as the residual
         GemmArgs a{};
         a.X = w_hatt16; a.W = v->hout_w; a.bias = v->hout_b; a.out16 = w_ho16;
         a.M = B; a.N = D; a.K = D; a.ldx = D; a.ldo = D;
-        VIT_TRY(gemm_launch<EP_F16>(a, st));
+        VIT_TRY(rowvec_launch<EP_F16>(a, st));
     }
     hipLaunchKernelGGL(f16_to_f32_kernel, dim3((B * D + 255) / 256), dim3(256), 0, st, w_ho16, w_tmp32, B * D);
     hipLaunchKernelGGL((vit_layernorm_kernel<false>), dim3((B + 3) / 4), dim3(256), 0, st, w_tmp32, v->hln_w, v->hln_b, w_hx16, (float *)nullptr, B, D, v->eps,
@@ -477,13 +573,13 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
         GemmArgs a{};
         a.X = w_hx16; a.W = v->hfc1_w; a.bias = v->hfc1_b; a.out16 = w_hmid16;
         a.M = B; a.N = I; a.K = D; a.ldx = D; a.ldo = I;
-        VIT_TRY(gemm_launch<EP_F16_GELU>(a, st));
+        VIT_TRY(rowvec_launch<EP_F16_GELU>(a, st));
     }
     {   // cls = residual + mlp(...)
         GemmArgs a{};
         a.X = w_hmid16; a.W = v->hfc2_w; a.bias = v->hfc2_b; a.out32 = w_tmp32;
         a.M = B; a.N = D; a.K = I; a.ldx = I;
-        VIT_TRY(gemm_launch<EP_RESID>(a, st));
+        VIT_TRY(rowvec_launch<EP_RESID>(a, st));
     }
     hipLaunchKernelGGL(pool_concat_kernel, dim3(1 + v->ph * v->pw, B, (D + 255) / 256), dim3(256), 0, st, w_last, w_tmp32, w_tokens, v->G, D, v->ph, v->pw);
     VIT_TRY(hipGetLastError());
