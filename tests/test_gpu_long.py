@@ -8,9 +8,10 @@ restatement of demo/inference.py:40-123 teacher-forced with the engine's own tok
 and every greedy token must be the reference-bf16 path's, except at a near-tie of the reference's own logits where the engine
 may pick another of the tied candidates (rule in Follower._judge; DESIGN.md §2 states it and its history).
 
-OPT-IN (VLO_LONG_TESTS=1; numbers kept in profiles/r*_parity_measurements.txt).  The follower of the 1 200-frame traces is the
-oracle's code executed by torch on the GPU (VLO_FOLLOWER_DEVICE=cuda, the default for these cases: a few minutes in all);
-VLO_FOLLOWER_DEVICE=cpu follows on the host cores as the 150-frame slice does (~23 minutes on an MI355X box):
+ALSO DEFAULT since round 6 (the driver's gate witnesses them: ~2 minutes in all with the follower on the GPU; `VLO_LONG_TESTS=0` skips them,
+numbers of every round in profiles/r*_parity_measurements.txt).  The follower of the 1 200-frame traces is the oracle's code executed by
+torch on the GPU (VLO_FOLLOWER_DEVICE=cuda, the default for these cases); VLO_FOLLOWER_DEVICE=cpu follows on the host cores as the
+150-frame slice does (~23 minutes on an MI355X box: opt-in):
 * the same trace over all 1 200 frames (KV to > 13 k tokens);
 * config 3's context: all-row logits 3-way at 66 000 cached tokens (narrow 3-layer model with the 8B head geometry);
 * tensor-parallel logical ranks T = 8 at 13 k cached tokens.
@@ -27,7 +28,7 @@ from tests.parity_util import fmt, ulp_report, within_band
 from videollm_online_amd.trace import FRAME, RESPONSE, FrameEvent, ResponseEvent      # the ONE event schema
 
 pytestmark = pytest.mark.gpu
-long_only = pytest.mark.skipif(os.environ.get("VLO_LONG_TESTS") != "1", reason="long parity runs: VLO_LONG_TESTS=1")
+long_only = pytest.mark.skipif(os.environ.get("VLO_LONG_TESTS", "1") == "0", reason="long parity runs switched off: VLO_LONG_TESTS=0")
 
 NEAR_TIE = 0.12     # logit units, as tests/test_gpu_liveinfer.py
 

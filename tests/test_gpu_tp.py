@@ -170,3 +170,32 @@ def test_tp_prefill_path_matches_oracle_and_the_16_row_steps(T, monkeypatch):
     child.close()
     sess.close()
     grp.close()
+
+
+def test_tp_long_input_with_a_gqa_group_the_flash_kernel_is_not_built_for():
+    """Round-5 advisor finding: tp_prefill calls the prefill attention kernel without a fallback, and that kernel exists for head dim 128 with
+    G in {1, 2, 4, 8} and head dim 64 with G in {2, 4, 8} only.  A group whose shard is head-dim-64 MHA (G = 1) passes every other shape gate of the
+    prefill path; its long inputs must keep the 16-row TP step (csrc/tp.hip::tp_prefill_ok asks llm_ops.hip::attention_prefill_supported) instead
+    of failing after layer 0's K / V were appended.  300 tokens + a decode step, 3-way against the oracle."""
+    from tests.test_gpu_long import _gpu_oracles
+    spec = O.LlmSpec(512, 1024, 2, 8, 8, 512, 10000.0, 1e-5)
+    w = O.init_llm_weights(spec, seed=11)
+    ref, gold = _gpu_oracles(spec, w)
+    grp = _group(spec, w, 2)
+    sess = grp.new_session()
+    g = torch.Generator().manual_seed(5)
+    rc = gc = None
+    for i, n in enumerate((300, 1)):
+        x = (torch.randn(n, spec.hidden_size, generator=g) * 0.7).bfloat16().cuda()
+        rl, rc = ref.forward(x, rc, logits_from=n - 1)
+        gl, gc = gold.forward(x, gc, logits_from=n - 1)
+        last, _ = grp.llm_step(sess, x, want_last=True)
+        torch.cuda.synchronize()
+        assert sess.get_seq_length() == len(rc)
+        e = (last.float().cpu() - gl[-1].cpu()).abs().max().item()
+        r = (rl[-1].float().cpu() - gl[-1].cpu()).abs().max().item()
+        scale = gl.abs().max().item()
+        print(f"[tp2 hd64 MHA long input] step {i} (n={n}): engine err {e:.4g} ref-bf16 err {r:.4g} scale {scale:.3g}")
+        assert within_band(e, r, 1e-3 * scale, "test_gpu_tp.py:unsupported_gqa_group"), f"step {i}: {e} vs {r}"
+    sess.close()
+    grp.close()

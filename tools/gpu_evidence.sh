@@ -10,7 +10,7 @@
 #   run NAME CMD...              any command, stdout+stderr -> NAME.txt (probes, sweeps)
 #   prof NAME CMD...             rocprofv3 --kernel-trace --stats -- CMD  -> kernel_stats_NAME.csv (tools/rocpd_stats.py)
 #   pmc NAME CTR [CTR...] -- CMD one rocprofv3 --kernel-trace --pmc pass (never combined with other trace domains) -> pmc_NAME.csv
-#   long [PYTEST ARGS]           the opt-in long parity file (VLO_LONG_TESTS=1), ~23 GPU-minutes for all of it
+#   long [PYTEST ARGS]           the long parity file alone (default-on since round 6; with VLO_FOLLOWER_DEVICE=cpu ~23 GPU-minutes)
 # A step's own time limit: prefix the string with `T=<seconds>` (default 600).  Steps never abort the script; each prints its exit code.
 #
 # Example (one gpurun call):

@@ -1,5 +1,5 @@
 """HBM bytes per launch of every Llama-step kernel from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate passes, TCC slots),
-summarised by tools/pmc_summary.py:  python tools/pmc_hbm_json.py fetch.csv write.csv out.csv out_gate_up.json
+summarised by tools/pmc_summary.py:  python tools/pmc_hbm_json.py fetch.csv write.csv out.csv out_gate_up.json [round label]
 
 bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE tallies the 128-byte
 read requests of wide coalesced streams at 64 bytes (MI355X_MICROARCH.md, HBM section), hence the factor 2 for these streaming kernels."""
@@ -29,7 +29,7 @@ with open(sys.argv[3], "w") as fh:
 gu = [r for r in rows if "gemv16_kernel<16, 8, 1, 3" in r[0]]
 if gu:
     k, n, f, w, b = gu[0]
-    json.dump({"kernel": k, "launches": n, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_per_launch": b,
+    json.dump({"kernel": k, "launches": n, "round": (sys.argv[5] if len(sys.argv) > 5 else "round ?"), "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_per_launch": b,
                "algorithmic_bytes_per_launch": 235286528,
                "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, --output-format csv) over "
                          "tools/probe_llm.py --frames 24; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at "

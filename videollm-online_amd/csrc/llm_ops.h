@@ -44,6 +44,7 @@ hipError_t attention_launch(const unsigned short *q, KvGeom kv, int layer, int n
 
 // flash-style attention for a block of n new tokens at positions pos0 .. pos0 + n - 1 whose keys are already appended (prefill path):
 // out bf16 [n][nh * hd] row-major.  hipErrorNotSupported for GQA shapes it is not instantiated for (the caller uses attention_launch).
+bool attention_prefill_supported(int head_dim, int gqa_group);      // is attn_prefill_kernel instantiated for this shape (else attention_prefill_launch returns hipErrorNotSupported)
 hipError_t attention_prefill_launch(const unsigned short *q, KvGeom kv, int layer, int num_heads, int64_t pos0, int n, unsigned short *out,
                                     hipStream_t st);
 

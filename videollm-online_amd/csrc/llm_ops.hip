@@ -356,6 +356,13 @@ __global__ __launch_bounds__(512, 4) void attn_prefill_kernel(const bf16_t *__re
 #undef VLO_PF_NCT
 }
 
+// the (head dim, GQA group) pairs attn_prefill_kernel is instantiated for — attention_prefill_launch returns hipErrorNotSupported for any other; a caller
+// WITHOUT a fallback (tp.hip::tp_prefill) asks first and keeps the 16-row step instead
+bool attention_prefill_supported(int head_dim, int gqa_group) {
+    return (head_dim == 128 && (gqa_group == 1 || gqa_group == 2 || gqa_group == 4 || gqa_group == 8)) ||
+           (head_dim == 64 && (gqa_group == 2 || gqa_group == 4 || gqa_group == 8));
+}
+
 hipError_t attention_prefill_launch(const unsigned short *q, KvGeom kv, int layer, int num_heads, int64_t pos0, int n, unsigned short *out, hipStream_t st) {
     const int nkv = kv.num_kv_heads, hd = kv.head_dim, G = num_heads / nkv;
     if (n <= 0 || nkv * G != num_heads) return hipErrorInvalidValue;

@@ -687,8 +687,12 @@ static int tp_chunk(vlo_tp_session *t, const unsigned short *src, int m, bool wa
 static bool tp_prefill_ok(const vlo_tp_session *t) {
     const vlo_tp_group *g = t->g;
     if (!(g->comm || (int)g->eng.size() == g->tp_size)) return false;       // mailbox-only groups keep the 16-row step
+    // tp_prefill has no fallback for its attention launch (the one-GPU run_prefill has: attention_launch over pooled partials), so a shard shape the
+    // flash kernel is not built for — hd 64 MHA, G = 16, odd groups — or VLO_PREFILL_FLASH=0 keeps the 16-row step for long inputs
+    static const bool flash = getenv("VLO_PREFILL_FLASH") ? atoi(getenv("VLO_PREFILL_FLASH")) != 0 : true;
+    if (!flash) return false;
     for (const vlo_engine *e : g->eng)
-        if (!prefill_ok(e)) return false;
+        if (!prefill_ok(e) || e->nkv_l <= 0 || e->nh_l % e->nkv_l || !attention_prefill_supported(e->head_dim, e->nh_l / e->nkv_l)) return false;
     return true;
 }
 static int tp_prefill_exchange(vlo_tp_session *t, int m, const void *(*norm_w)(const vlo_engine *, int), int layer, hipStream_t st) {
@@ -738,7 +742,7 @@ static int tp_prefill(vlo_tp_session *t, const unsigned short *src, int m, bool 
             if (l == 0) TP_TRY(add_rmsnorm_launch(s->ph, nullptr, 0, H, (const unsigned short *)L.ln_in, s->px, H, H, c.rms_eps, m, st));
             if ((rc = prefill_gemm(s, s->px, L.qkv, m, Nqkv, H, s->pqkv, Nqkv, LLM_GEMM_BF16, st))) return rc;
             TP_TRY(rope_kv_append_launch(s->pqkv, m, e->nh_l, (const unsigned short *)e->cos_tab, (const unsigned short *)e->sin_tab, kv, l, s->len, s->pq, st));
-            TP_TRY(attention_prefill_launch(s->pq, kv, l, e->nh_l, s->len, m, s->px, st));       // (prefill_ok: head dim 64 / 128; GQA groups the kernel is built for)
+            TP_TRY(attention_prefill_launch(s->pq, kv, l, e->nh_l, s->len, m, s->px, st));       // (tp_prefill_ok asked attention_prefill_supported for this shard's head dim / GQA group)
             if ((rc = prefill_gemm(s, s->px, L.o, m, H, qd, s->ppartial, H, LLM_GEMM_F32, st))) return rc;
         }
         if ((rc = tp_prefill_exchange(t, m, norm_post, l, st))) return rc;      // exchange 1: h += sum(o partials); x = post-attention norm

@@ -66,6 +66,7 @@ class LiveInfer:
         self._added_stream_generation_ids = list(tokens.stream_generation_ids)
         # device plumbing
         self.prefetch = prefetch
+        self.real_greedy = False                         # scheduled responses through the token-reading greedy loop instead of the forced-length one (bench.py)
         self.frame_wait_s = 10.0           # how long input_video_stream waits for a frame a FrameRing's feeder has not pushed yet
         self.prefetch_frames = max(1, prefetch_frames)   # frames encoded ahead in ONE batched ViT call (the reference
         # batches all pending frames the same way, demo/inference.py:105-106); the video is fully loaded up front
@@ -217,11 +218,21 @@ class LiveInfer:
         if self.past_key_values is None:
             self.past_key_values = self.model.new_cache()
         L0 = len(self.past_key_values)
-        output_ids, self.past_key_values = fast_greedy_generate(
-            model=self.model, inputs_embeds=inputs_embeds, past_key_values=self.past_key_values,
-            eos_token_id=self.eos_token_id, inplace_output_ids=self.inplace_output_ids,
-            force_len=forced[1] if forced is not None else 0)
+        if forced is not None and self.real_greedy:
+            # a scheduled response through the loop a real stream takes (models/modeling_live.py:173-182: every token read on the host, here with the
+            # next step enqueued speculatively): an EOS id the model cannot emit and a buffer of exactly the scheduled length — same tokens fed,
+            # same KV, same number of steps as the forced form, which never looks at a token (bench.py times both)
+            output_ids, self.past_key_values = fast_greedy_generate(
+                model=self.model, inputs_embeds=inputs_embeds, past_key_values=self.past_key_values,
+                eos_token_id=-1, inplace_output_ids=self.inplace_output_ids[:, :forced[1]], force_len=0)
+        else:
+            output_ids, self.past_key_values = fast_greedy_generate(
+                model=self.model, inputs_embeds=inputs_embeds, past_key_values=self.past_key_values,
+                eos_token_id=self.eos_token_id, inplace_output_ids=self.inplace_output_ids,
+                force_len=forced[1] if forced is not None else 0)
         out = output_ids[0].tolist()
+        if forced is not None and self.real_greedy:
+            out[-1] = self.eos_token_id          # the forced form ends every scheduled response with EOS (never fed to the model): the same token flow
         self._log_step(L0, len(self.last_ids))
         for j in range(len(out) - 1):
             self._log_step(L0 + len(self.last_ids) + j, 1)
