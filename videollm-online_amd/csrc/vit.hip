@@ -384,7 +384,8 @@ int vit_finalize(vlo_engine *e) {
 #undef TK
 #undef PAD
     VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnLds));
-    VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_split8_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttn8Lds));
+    VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_split8_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttn8Lds));
+    VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_split8_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttn8Lds / 2));
     VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_kernel<96, 80>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds(80)));
     VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_kernel<96, 80, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds(80, 2)));
     {
@@ -466,13 +467,15 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
     float *const w_slab = v->slab + r0 * D;
     const size_t slab_stride = (size_t)v->slab_rows * D;
     const bool slab_ok = r0 + (size_t)M <= (size_t)v->slab_rows;
-    // one frame (two): every GEMM on the tall tiles, one workgroup per CU (vit_tall.inc); fc2 (K = 4 x hidden) as 4 K slices into the slabs
+    // one frame (two): every GEMM on the tall tiles, one workgroup per CU (vit_tall.inc).
+    // K slices of the two residual GEMMs on the tall tiles: the most (<= 4) that leave a slice >= 3 K tiles — out-proj 4 x 4 tiles, fc2 4 x 16 at SigLIP-L
+    // (64 output tiles x 4 = one workgroup per CU; measured: out-proj 11.2 us straight into the residual stream on 64 CUs vs 5.9 us as 4 slices, and the
+    // LayerNorm behind it takes the slabs for +1 us)
     static const int tall_max_rows = getenv("VLO_VIT_TALL_MAX_ROWS") ? atoi(getenv("VLO_VIT_TALL_MAX_ROWS")) : 1152;
-    static const int tall_ks_out = getenv("VLO_VIT_TALL_KS_OUT") ? atoi(getenv("VLO_VIT_TALL_KS_OUT")) : 1;
-    static const int tall_ks_fc2 = getenv("VLO_VIT_TALL_KS_FC2") ? atoi(getenv("VLO_VIT_TALL_KS_FC2")) : 4;
-    const bool tall = M <= tall_max_rows && slab_ok && D % 64 == 0 && I % 64 == 0 && D >= 5 * GEMM_BK * tall_ks_out && I >= 5 * GEMM_BK * tall_ks_fc2 &&
-                      D % (GEMM_BK * tall_ks_out) == 0 && I % (GEMM_BK * tall_ks_fc2) == 0;
-    const int ks_out = tall ? tall_ks_out : (slab_ok ? vit_resid_ksplit(M, D, D) : 1), ks_fc2 = tall ? tall_ks_fc2 : (slab_ok ? vit_resid_ksplit(M, D, I) : 1);
+    const int tall_tiles = ((M + 143) / 144) * (D / 64);       // output tiles of a residual GEMM: slices fill the chip once (one frame: 64 x 4, two: 128 x 2)
+    auto tall_ks = [&](int K) { for (int ks = 4; ks > 1; ks >>= 1) if (tall_tiles * ks <= vit_num_cus() && K % (GEMM_BK * ks) == 0 && K / (GEMM_BK * ks) >= 3) return ks; return 1; };
+    const bool tall = M <= tall_max_rows && slab_ok && D % 64 == 0 && I % 64 == 0 && D >= 3 * GEMM_BK && I >= 3 * GEMM_BK;
+    const int ks_out = tall ? tall_ks(D) : (slab_ok ? vit_resid_ksplit(M, D, D) : 1), ks_fc2 = tall ? tall_ks(I) : (slab_ok ? vit_resid_ksplit(M, D, I) : 1);
     int pend_ks = 0;                          // K slices waiting in the slab for the next LayerNorm (0 = none)
     const float *pend_bias = nullptr;
     auto layernorm = [&](const float *g, const float *b, f16_t *o16, float *o32) {
@@ -519,14 +522,16 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
             VIT_TRY(tall ? gemm_launch_tall<EP_QKV>(a, 1, st) : gemm_launch<EP_QKV>(a, st));
         }
         // batched frames: one workgroup per (frame, head) with K and V^T resident in LDS; few frames: 64-query tiles, keys split over 4 waves
-        static const int attn8_on = getenv("VLO_VIT_ATTN8") ? atoi(getenv("VLO_VIT_ATTN8")) : 1;
+        static const int attn8_on = getenv("VLO_VIT_ATTN8") ? atoi(getenv("VLO_VIT_ATTN8")) : 4;      // 0: the 4-wave kernel; 2 / 4: the 8-wave kernel on 32- / 64-query blocks (one frame: 12.8 / 10.5 us)
         static const int head_min = getenv("VLO_VIT_ATTN_HEAD_MIN") ? atoi(getenv("VLO_VIT_ATTN_HEAD_MIN")) : 96;     // workgroups; 0 = never
         static const int tiles_min = getenv("VLO_VIT_ATTN_TILES_MIN") ? atoi(getenv("VLO_VIT_ATTN_TILES_MIN")) : 192;   // workgroups of the tile-streamed padded-head kernel; 0 = never
         if (head_min > 0 && B * v->nh >= head_min && v->attn_head_lds > 0)
             hipLaunchKernelGGL((vit_attn_head_kernel<0>), dim3((S + 575) / 576, v->nh, B), dim3(768), v->attn_head_lds, st, w_qk16, w_vT, w_att16, S, D, v->nh,
                                scale * 1.4426950408889634f, v->attn_vrs);
+        else if (v->hdk == 64 && tall && S <= 768 && attn8_on == 4)
+            hipLaunchKernelGGL((vit_attn_split8_kernel<3, 4>), dim3((S + 63) / 64, v->nh, B), dim3(512), kAttn8Lds, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
         else if (v->hdk == 64 && tall && S <= 768 && attn8_on)
-            hipLaunchKernelGGL((vit_attn_split8_kernel<3>), dim3((S + 63) / 64, v->nh, B), dim3(512), kAttn8Lds, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
+            hipLaunchKernelGGL((vit_attn_split8_kernel<3, 2>), dim3((S + 31) / 32, v->nh, B), dim3(512), kAttn8Lds / 2, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
         else if (v->hdk == 64)
             hipLaunchKernelGGL((vit_attn_kernel<64>), dim3((S + 63) / 64, v->nh, B), dim3(256), kAttnLds, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
         else if (B * v->nh * ((S + 255) / 256) >= tiles_min && tiles_min > 0) {
