@@ -441,6 +441,11 @@ def main():
     toks = stream_tokens(cfg.vocab_size)
     model = LiveModel(eng, eos_token_id=toks.eos_token_id, frame_token_interval_id=toks.interval_id)
     frames = gpu_synthetic_frames(n_frames, seed=1234 + (0 if tp else rank))
+    # experiment switch (not a default): the Llama steps on a HIGH-priority stream, the encoder on a normal one
+    if os.environ.get("VLO_BENCH_HIPRIO") == "1":
+        hi = torch.cuda.Stream(priority=-1)
+        hi.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(hi)
     li = LiveInfer(model, tokens=toks, frame_fps=args.fps, prefetch=not args.no_prefetch, prefetch_frames=args.prefetch_frames,
                    schedule=make_schedule(args.mode), record=1 << 20)
 

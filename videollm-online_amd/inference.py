@@ -15,7 +15,7 @@ from dataclasses import dataclass, field
 import torch
 
 from .modeling_live import LiveModel, fast_greedy_generate
-from .trace import frame_event, response_event
+from .trace import frame_event, response_event, stage
 
 
 @dataclass
@@ -173,7 +173,7 @@ class LiveInfer:
         else:
             frames, ready = self.video_tensor[lo2:hi2], self._video_ready
         self._enc.wait_event(ready)                  # the video upload / ingest; NOT the main stream's Llama work
-        with torch.cuda.stream(self._enc):
+        with stage("encode"), torch.cuda.stream(self._enc):
             emb = self.model.engine.visual_embed(frames, stream=self._enc)
             emb.record_stream(self._main)
             ev = torch.cuda.Event()
@@ -266,9 +266,10 @@ class LiveInfer:
             if len(self.last_ids) + self.frame_num_tokens > self._stage.shape[0]:
                 self._stage = torch.empty(len(self.last_ids) + self.frame_num_tokens, self.hidden_size, dtype=torch.bfloat16,
                                           device=self.model.device)
-            inputs_embeds = eng.step_input(self.last_ids, frame_embeds, self._stage)      # :61-68 without torch.tensor / torch.cat
-            self._log_step(len(self.past_key_values), inputs_embeds.shape[0])
-            eng.llm_step(self.past_key_values, inputs_embeds, want_last=False)
+            with stage("step"):
+                inputs_embeds = eng.step_input(self.last_ids, frame_embeds, self._stage)      # :61-68 without torch.tensor / torch.cat
+                self._log_step(len(self.past_key_values), inputs_embeds.shape[0])
+                eng.llm_step(self.past_key_values, inputs_embeds, want_last=False)
             self._frames_done += 1
             nxt = self.last_frame_idx + 1
             if self.prefetch and not self.frame_embeds_queue and nxt not in self._encoded:
@@ -280,10 +281,11 @@ class LiveInfer:
                 video_time, query = self.query_queue.popleft()
                 return video_time, query
             # 3. if the next is frame but next is not interval, then response
-            eng.stream_sample(self.past_key_values, self.frame_token_interval_threshold, self.frame_token_interval_id,
-                              tok_out=self._tok_dev, p_out=self._p_dev)
-            self._tok_host.copy_(self._tok_dev, non_blocking=True)
-            self._main.synchronize()
+            with stage("sample"):
+                eng.stream_sample(self.past_key_values, self.frame_token_interval_threshold, self.frame_token_interval_id,
+                                  tok_out=self._tok_dev, p_out=self._p_dev)
+                self._tok_host.copy_(self._tok_dev, non_blocking=True)
+                self._main.synchronize()
             tok = sampled = int(self._tok_host[0])
             forced = self.schedule(self._frames_done - 1) if self.schedule is not None else None
             if forced is not None:
@@ -302,7 +304,8 @@ class LiveInfer:
         video_time, query = self._call_for_streaming()
         response = None
         if video_time is not None:
-            query, response = self._call_for_response(video_time, query)
+            with stage("respond"):
+                query, response = self._call_for_response(video_time, query)
         return query, response
 
 

@@ -38,3 +38,59 @@ def frame_event(video_time, token, kv_len, sampled=None) -> FrameEvent:
 
 def response_event(video_time, query, output_ids) -> ResponseEvent:
     return ResponseEvent(RESPONSE, video_time, query, list(output_ids))
+
+
+# ---- per-stage trace ranges (the reference's only instrument is the wall clock of demo/cli.py:31-38) ---------------------------
+# With VLO_ROCTX=1 LiveInfer brackets its stages — "encode" (ViT + connector launches), "step" (the Llama frame step), "sample" (streaming sampler
+# + the host's read of its token), "respond" (greedy response) — with roctx ranges, so a `rocprofv3 --marker-trace --kernel-trace` run cuts the
+# kernel timeline by stage without kernel-name heuristics.  Off (the default) the context manager is a no-op object: nothing is loaded.
+class _NoRange:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_RANGE = _NoRange()
+_roctx = None
+
+
+def _load_roctx():
+    global _roctx
+    if _roctx is None:
+        import ctypes
+        import os
+        _roctx = False
+        if os.environ.get("VLO_ROCTX") == "1":
+            for name in ("librocprofiler-sdk-roctx.so", "libroctx64.so"):
+                try:
+                    lib = ctypes.CDLL(name)
+                    lib.roctxRangePushA.argtypes = [ctypes.c_char_p]
+                    lib.roctxRangePushA.restype = ctypes.c_int
+                    lib.roctxRangePop.restype = ctypes.c_int
+                    _roctx = lib
+                    break
+                except (OSError, AttributeError):
+                    continue
+    return _roctx
+
+
+class _Range:
+    __slots__ = ("name",)
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        _roctx.roctxRangePushA(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        _roctx.roctxRangePop()
+        return False
+
+
+def stage(name: str):
+    """`with stage("encode"): ...` — a roctx range when VLO_ROCTX=1 and the library loads, otherwise nothing."""
+    return _Range(name.encode()) if _load_roctx() else _NO_RANGE
