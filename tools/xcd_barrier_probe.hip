@@ -27,7 +27,9 @@ __device__ __forceinline__ unsigned xcc_id() {
     return v & 7u;
 }
 
-// MODE 0: XCD-local barrier only; 1: + 4 KiB hand-off inside the XCD; 2: flat chip-wide barrier (release / acquire fences); 3: flat + hand-off to any workgroup
+// MODE 0: XCD-local barrier only; 1: + 4 KiB hand-off inside the XCD; 2: flat chip-wide barrier (release / acquire fences); 3: flat + hand-off to any workgroup;
+// 4: as 1, but every round writes / reads a FRESH 4 KiB region (the reader's L1 has never seen those lines in this launch — the situation of
+// csrc/vit_band.inc, where a buffer is written and read once per launch) and the reads are PLAIN loads
 template <int MODE>
 __global__ __launch_bounds__(256) void barrier_kernel(Ctl *c, unsigned *payload, int rounds, int per_xcd) {
     __shared__ unsigned s_slot, s_xcc, s_dead;
@@ -40,11 +42,13 @@ __global__ __launch_bounds__(256) void barrier_kernel(Ctl *c, unsigned *payload,
     }
     __syncthreads();
     const unsigned x = s_xcc, me = s_slot;
-    const bool flat = MODE >= 2;
+    const bool flat = MODE == 2 || MODE == 3;
+    constexpr int REGIONS = 64;                // MODE 4: payload regions per workgroup slot, one per round (rounds <= REGIONS)
     unsigned *mine = payload + ((size_t)(flat ? blockIdx.x : x * 64 + me)) * 1024;
     unsigned bad = 0;
     for (int r = 1; r <= rounds; ++r) {
-        if (MODE == 1 || MODE == 3) {
+        if (MODE == 4) mine = payload + ((size_t)((r - 1) % REGIONS) * 512 + x * 64 + me) * 1024;
+        if (MODE == 1 || MODE == 3 || MODE == 4) {
             reinterpret_cast<uint4 *>(mine)[threadIdx.x] = make_uint4(r, r, r, r);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -72,11 +76,11 @@ __global__ __launch_bounds__(256) void barrier_kernel(Ctl *c, unsigned *payload,
         }
         __syncthreads();
         if (s_dead) break;           // a bounded spin ran out (uneven placement): stop instead of spinning through every round
-        if (MODE == 1 || MODE == 3) {
+        if (MODE == 1 || MODE == 3 || MODE == 4) {
             const unsigned other = flat ? (blockIdx.x + 37u) % gridDim.x : x * 64 + (me + 5u) % (unsigned)per_xcd;
-            const unsigned *src = payload + (size_t)other * 1024 + threadIdx.x * 4;
+            const unsigned *src = payload + (MODE == 4 ? (size_t)((r - 1) % REGIONS) * 512 * 1024 : 0) + (size_t)other * 1024 + threadIdx.x * 4;
             uint4 v;
-            if (!flat) {       // sc1 loads: bypass this CU's L1, served by the XCD's L2
+            if (!flat && MODE != 4) {       // sc1 loads: bypass this CU's L1, served by the XCD's L2
                 v.x = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 v.y = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 v.z = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -94,7 +98,7 @@ int main() {
     Ctl *c;
     unsigned *payload;
     CK(hipMalloc(&c, sizeof(Ctl)));
-    CK(hipMalloc(&payload, (size_t)8 * 64 * 4096));
+    CK(hipMalloc(&payload, (size_t)64 * 8 * 64 * 4096));          // 64 regions (MODE 4) of 8 x 64 slots of 4 KiB
     hipStream_t st;
     CK(hipStreamCreate(&st));
     hipEvent_t e0, e1;
@@ -111,25 +115,27 @@ int main() {
     bool even = true;
     for (int x = 0; x < 8; ++x) { printf(" xcd%d=%u", x, h.census[x][0]); even = even && h.census[x][0] == (unsigned)blocks / 8; }
     printf("%s\n", even ? "" : "   (uneven: the XCD-local rows below are skipped)");
-    const char *names[4] = {"XCD-local barrier (32 workgroups per XCD, 8 XCDs at once)", "XCD-local barrier + 4 KiB hand-off inside the XCD",
-                            "flat chip-wide barrier, release + acquire fences", "flat chip-wide barrier + 4 KiB hand-off"};
-    for (int mode = 0; mode < 4; ++mode) {
-        if (mode < 2 && !even) continue;
+    const char *names[5] = {"XCD-local barrier (32 workgroups per XCD, 8 XCDs at once)", "XCD-local barrier + 4 KiB hand-off inside the XCD",
+                            "flat chip-wide barrier, release + acquire fences", "flat chip-wide barrier + 4 KiB hand-off",
+                            "XCD-local barrier + 4 KiB hand-off, fresh region per round, PLAIN loads"};
+    for (int mode = 0; mode < 5; ++mode) {
+        if ((mode < 2 || mode == 4) && !even) continue;
         for (int rep = 0; rep < 2; ++rep) {
             CK(hipMemset(c, 0, sizeof(Ctl)));
-            CK(hipMemset(payload, 0, (size_t)8 * 64 * 4096));
+            CK(hipMemset(payload, 0, (size_t)64 * 8 * 64 * 4096));
             CK(hipEventRecord(e0, st));
             if (mode == 0) hipLaunchKernelGGL(barrier_kernel<0>, dim3(blocks), dim3(256), 0, st, c, payload, rounds, blocks / 8);
             if (mode == 1) hipLaunchKernelGGL(barrier_kernel<1>, dim3(blocks), dim3(256), 0, st, c, payload, rounds, blocks / 8);
             if (mode == 2) hipLaunchKernelGGL(barrier_kernel<2>, dim3(blocks), dim3(256), 0, st, c, payload, rounds, blocks / 8);
             if (mode == 3) hipLaunchKernelGGL(barrier_kernel<3>, dim3(blocks), dim3(256), 0, st, c, payload, rounds, blocks / 8);
+            if (mode == 4) hipLaunchKernelGGL(barrier_kernel<4>, dim3(blocks), dim3(256), 0, st, c, payload, 64, blocks / 8);
             CK(hipEventRecord(e1, st));
             CK(hipStreamSynchronize(st));
             CK(hipGetLastError());
             float ms;
             CK(hipEventElapsedTime(&ms, e0, e1));
             CK(hipMemcpy(&h, c, sizeof(Ctl), hipMemcpyDeviceToHost));
-            if (rep == 1) printf("%-62s: %6.2f us per barrier   stale words %u   timeouts %u\n", names[mode], ms * 1e3 / rounds, h.stale, h.timeouts);
+            if (rep == 1) printf("%-72s: %6.2f us per barrier   stale words %u   timeouts %u\n", names[mode], ms * 1e3 / (mode == 4 ? 64 : rounds), h.stale, h.timeouts);
         }
     }
     return 0;
