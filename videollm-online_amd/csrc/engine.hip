@@ -618,7 +618,6 @@ GemvArgs gemv_args(const PackedLinear &pl, const unsigned short *x, int ldx, int
 //   gate/up GEMV  [post-attention RMSNorm fused into the operand load | SwiGLU]        -> act
 //   down GEMV     [K split over blocks, fp32 partials]                                 -> partial
 static int run_chunk(vlo_session *s, const unsigned short *src, int m, bool want_last, bool want_all, hipStream_t st) {
-    static const bool fuse_norm = getenv("VLO_FUSE_NORM") ? atoi(getenv("VLO_FUSE_NORM")) != 0 : true;
     vlo_engine *e = s->e;
     const vlo_config &c = e->cfg;
     const int H = c.hidden_size, I = c.intermediate_size, hd = e->head_dim, nh = c.num_heads;
@@ -645,16 +644,14 @@ static int run_chunk(vlo_session *s, const unsigned short *src, int m, bool want
             sq_parts = gemv_grid_x(a, L.o.plan, EPI_RESID);
             HIP_TRY(gemv_launch(a, L.o.plan, XSRC_PLAIN, EPI_RESID, st));
         }
-        if (!fuse_norm)
-            HIP_TRY(add_rmsnorm_launch(s->h, nullptr, 0, H, (const unsigned short *)L.ln_post, s->x, H, H, c.rms_eps, m, st));
         {   // gate/up + SwiGLU
             hipEvent_t ev0 = nullptr, ev1 = nullptr;
             if (e->prof_stride > 0 && (e->prof_seen++ % e->prof_stride) == 0) prof_acquire(e, &ev0, &ev1);
-            GemvArgs a = gemv_args(L.gate_up, fuse_norm ? s->h : s->x, H, m);
+            GemvArgs a = gemv_args(L.gate_up, s->h, H, m);
             a.norm_w = (const unsigned short *)L.ln_post; a.sq_in = s->sq[0]; a.sq_in_parts = sq_parts; a.eps = c.rms_eps;
             a.out_bf16 = s->act; a.ldo = I;
             if (ev0) hipEventRecord(ev0, st);
-            HIP_TRY(gemv_launch(a, L.gate_up.plan, fuse_norm ? XSRC_NORM : XSRC_PLAIN, EPI_SWIGLU, st));
+            HIP_TRY(gemv_launch(a, L.gate_up.plan, XSRC_NORM, EPI_SWIGLU, st));
             if (ev1) hipEventRecord(ev1, st);
         }
         {   // down_proj: fp32 K-slice partials, combined by the next add_rmsnorm
@@ -804,7 +801,7 @@ static void release_prefill_ws(vlo_session *s) {
     s->pf_wexp = nullptr; s->pf_wexp_bytes = 0; s->ppartial = nullptr;
 }
 
-// partial states for the fallback attention kernel (shapes attn_prefill_kernel is not instantiated for, VLO_PREFILL_FLASH=0): 67 MB at the 8B shape,
+// partial states for the fallback attention kernel (shapes attn_prefill_kernel is not instantiated for): 67 MB at the 8B shape,
 // so only sessions that take the fallback pay for them
 static int ensure_prefill_partials(vlo_session *s) {
     if (s->ppart_ml) return VLO_OK;
@@ -867,8 +864,7 @@ static int run_prefill(vlo_session *s, const unsigned short *src, int m, bool wa
         HIP_TRY(rope_kv_append_launch(s->pqkv, m, nh, (const unsigned short *)e->cos_tab, (const unsigned short *)e->sin_tab, kv, l, s->len, s->pq, st));
         // the whole block's keys are appended: ONE attention launch, grid.z = the block's 16-query sub-chunks (causal mask per sub-chunk,
         // one split each); the output lands in px (the o-proj's X operand)
-        static const bool flash = getenv("VLO_PREFILL_FLASH") ? atoi(getenv("VLO_PREFILL_FLASH")) != 0 : true;
-        hipError_t ae = flash ? attention_prefill_launch(s->pq, kv, l, nh, s->len, m, s->px, st) : hipErrorNotSupported;
+        hipError_t ae = attention_prefill_launch(s->pq, kv, l, nh, s->len, m, s->px, st);
         if (ae == hipErrorNotSupported) {
             if ((rc = ensure_prefill_partials(s))) return rc;
             ae = attention_launch(s->pq, kv, l, nh, s->len, m, s->ppart_o, s->ppart_ml, s->px, st, -1, VLO_PREFILL_TOKENS / 16);
@@ -1330,7 +1326,7 @@ int vlo_bench_gemv(int N, int K, int n_rows, int epi, int iters, int nbuf, doubl
     a.x = (const unsigned short *)x; a.out_f32 = (float *)o32; a.out_bf16 = (unsigned short *)o16;
     a.K = K; a.ldx = K; a.ldo = (epi == EPI_SWIGLU) ? NT * 8 : NT * 16; a.NT = NT; a.N_valid = N; a.n_rows = n_rows;   // SwiGLU: 8 output columns per tile
     int xsrc = XSRC_PLAIN;
-    if (epi == EPI_SWIGLU && !(getenv("VLO_FUSE_NORM") && atoi(getenv("VLO_FUSE_NORM")) == 0)) {
+    if (epi == EPI_SWIGLU) {
         xsrc = XSRC_NORM;
         a.norm_w = (const unsigned short *)nw; a.sq_in = (const float *)sq; a.sq_in_parts = 128; a.eps = 1e-5f;
     }

@@ -150,7 +150,7 @@ static const NwKf kCombos[] = {{8, 16}, {8, 14}, {8, 11}, {8, 8}, {8, 4}, {8, 2}
 int gemv_plan(int K, bool allow_ksplit, GemvPlan *p) {
     if (K <= 0 || (K & 31)) return -1;
     const int KFtot = K >> 5;
-    const int force_ks = allow_ksplit ? env_int("VLO_GEMV_KSPLIT", 0) : 0;
+    const int force_ks = 0;
     // the combination that keeps the most weight bytes in flight per CU (NW x KF KiB) wins, earlier entries on ties: every
     // model shape gets the same plan as a first-match walk of the list except K = 1792 (Llama-3-8B down-proj at TP = 8),
     // which would otherwise stream with 1 KiB per wave and seven K slices instead of 4 waves x 14 KiB and one
@@ -172,8 +172,6 @@ int gemv_plan(int K, bool allow_ksplit, GemvPlan *p) {
 // rotary epilogue).  e.g. gate/up: 1792 tiles = 7.0 per CU as singles, 896 pairs = 3.5 -> 4 per CU (87.5 %).
 static bool single_tile_groups(const GemvArgs &a, const GemvPlan &p, int epi) {
     if (epi == EPI_ROPE) return false;
-    static const int force = env_int("VLO_GEMV_SINGLE", -1);     // experiments: 1 = single tiles wherever the epilogue allows, 0 = pairs everywhere
-    if (force >= 0) return force != 0;
     const int slots = 256 / p.ksplit > 0 ? 256 / p.ksplit : 1;
     auto eff = [&](int items) {
         const int rounds = (items + slots - 1) / slots;
@@ -187,7 +185,7 @@ static int groups_of(const GemvArgs &a, const GemvPlan &p, int epi) {
 }
 
 int gemv_grid_x(const GemvArgs &a, const GemvPlan &p, int epi) {
-    static const int kBPC = env_int("VLO_GEMV_BPC", 1);          // resident blocks per CU aimed at
+    constexpr int kBPC = 1;                                      // resident blocks per CU (2 / 3 measured slower: profiles/r3_gemv_blocks_per_cu_sweep.txt)
     static const int kCUs = env_int("VLO_GEMV_CUS", 256);        // (tests shrink the grid so that a block walks many groups)
     const int ngroups = groups_of(a, p, epi);
     int gx = (kCUs * kBPC) / p.ksplit;

@@ -367,14 +367,12 @@ hipError_t attention_prefill_launch(const unsigned short *q, KvGeom kv, int laye
     const int nkv = kv.num_kv_heads, hd = kv.head_dim, G = num_heads / nkv;
     if (n <= 0 || nkv * G != num_heads) return hipErrorInvalidValue;
     const float scale = 1.0f / sqrtf((float)hd);
-    static const int kStages = getenv("VLO_ATTN_STAGES") ? atoi(getenv("VLO_ATTN_STAGES")) : 4;      // tile buffers in the ring (2: one tile in flight)
     const char *ns = getenv("VLO_ATTN_NOSKIP");                            // read per call: the tests flip it between two passes over the same input
     const int noskip = ns && atoi(ns) != 0;
 #define VLO_ATTN_PF(HD_, G_)                                                                                                          \
     do {                                                                                                                              \
         constexpr int QB_ = 128 / G_;                                                                                                 \
-        if (kStages == 2) hipLaunchKernelGGL((attn_prefill_kernel<HD_, G_, 2>), dim3((n + QB_ - 1) / QB_, nkv), dim3(512), 0, st, q, kv, layer, num_heads, pos0, n, scale, out, noskip); \
-        else hipLaunchKernelGGL((attn_prefill_kernel<HD_, G_, 4>), dim3((n + QB_ - 1) / QB_, nkv), dim3(512), 0, st, q, kv, layer, num_heads, pos0, n, scale, out, noskip); \
+        hipLaunchKernelGGL((attn_prefill_kernel<HD_, G_, 4>), dim3((n + QB_ - 1) / QB_, nkv), dim3(512), 0, st, q, kv, layer, num_heads, pos0, n, scale, out, noskip); \
         return hipGetLastError();                                                                                                     \
     } while (0)
     if (hd == 128 && G == 4) VLO_ATTN_PF(128, 4);
@@ -396,24 +394,19 @@ hipError_t attention_geometry(const KvGeom &kv, int num_heads, int64_t pos0, int
     if (nhg > 8) return hipErrorInvalidValue;
     int KS = 8 / nhg;                                   // 8 waves per block
     if (KS > 4) KS = 4;
-    {
-        static const int force = getenv("VLO_ATTN_KS") ? atoi(getenv("VLO_ATTN_KS")) : 0;
-        if (force > 0) KS = force;
-    }
     // n > 16 (block path): grid.z sub-chunks of 16 queries share one launch and one split geometry; sub-chunk z sees the
     // keys [0, pos0 + 16 z + n_z), splits beyond that write empty partials
     const int nz = (n + 15) / 16;
     if (nz > part_cap || nz > 65535) return hipErrorInvalidValue;
     // short steps whose G * n (head, token) columns fit 3 MFMA column tiles take the column-packed kernel: 8 key sub-splits per block
-    static const int cols_off = getenv("VLO_ATTN_COLS") ? !atoi(getenv("VLO_ATTN_COLS")) : 0;
     g->nct = 0;
-    if (!cols_off && nz == 1 && G * n <= 48 && (hd == 128 || hd == 64)) {
+    if (nz == 1 && G * n <= 48 && (hd == 128 || hd == 64)) {
         g->nct = (G * n + 15) / 16;
         KS = 8;
     }
     // splits: ~one block per CU at long context; every wave should see at least one 32-key block
     int target = (L + KS * 32 - 1) / (KS * 32);
-    static const int want_blocks = getenv("VLO_ATTN_BLOCKS") ? atoi(getenv("VLO_ATTN_BLOCKS")) : 256;
+    constexpr int want_blocks = 256;                    // (128 / 512 measured slower)
     const int want = (want_blocks + nkv * nz - 1) / (nkv * nz);
     if (target > want) target = want;
     if (target > VLO_MAX_SPLITS / nz) target = VLO_MAX_SPLITS / nz;      // (the merge kernel holds one split per lane; 0 for nz > 64: one split below)

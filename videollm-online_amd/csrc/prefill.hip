@@ -320,9 +320,8 @@ hipError_t llm_gemm_launch(const unsigned short *X, const void *Wp, int M, int N
     a.bias = wscale;
     const int tx = N / 256;
     // tile height: 256 rows once such tiles fill the chip, else 128 (twice the tiles, half the work each)
-    static const int force_bm = getenv("VLO_PREFILL_BM") ? atoi(getenv("VLO_PREFILL_BM")) : 0;
     const int t256 = ((M + 255) / 256) * tx;
-    const int bm = force_bm ? force_bm : (t256 >= 200 ? 256 : 128);
+    const int bm = t256 >= 200 ? 256 : 128;
     // column groups of the 2-D XCD split: the smallest split whose W slice (N / cb columns x K) stays inside an XCD's L2 (vit_gemm.inc)
     int cb = 1;
     while (cb < 8 && tx % (cb * 2) == 0 && (size_t)(N / cb) * K * 2 > ((size_t)9 << 18)) cb *= 2;

@@ -388,7 +388,6 @@ static int p2p_allocate(vlo_tp_group *g, int first_kind = 0) {
     P.gat_base = p2p_gather_base(T, P.H);
     P.granules = p2p_total_granules(T, P.H, P.Vh);
     if (const char *v = getenv("VLO_TP_P2P_TIMEOUT_MS")) P.timeout_ticks = (long long)atoll(v) * 100000ll;
-    if (const char *v = getenv("VLO_TP_P2P_FUSED")) P.fused = atoi(v) != 0;
     if (!P.err_host) {
         if (hipHostMalloc((void **)&P.err_host, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess)
             return vlo_fail(VLO_E_HIP, "p2p exchange: hipHostMalloc of the error word failed");
@@ -688,9 +687,7 @@ static bool tp_prefill_ok(const vlo_tp_session *t) {
     const vlo_tp_group *g = t->g;
     if (!(g->comm || (int)g->eng.size() == g->tp_size)) return false;       // mailbox-only groups keep the 16-row step
     // tp_prefill has no fallback for its attention launch (the one-GPU run_prefill has: attention_launch over pooled partials), so a shard shape the
-    // flash kernel is not built for — hd 64 MHA, G = 16, odd groups — or VLO_PREFILL_FLASH=0 keeps the 16-row step for long inputs
-    static const bool flash = getenv("VLO_PREFILL_FLASH") ? atoi(getenv("VLO_PREFILL_FLASH")) != 0 : true;
-    if (!flash) return false;
+    // flash kernel is not built for — hd 64 MHA, G = 16, odd groups — keeps the 16-row step for long inputs
     for (const vlo_engine *e : g->eng)
         if (!prefill_ok(e) || e->nkv_l <= 0 || e->nh_l % e->nkv_l || !attention_prefill_supported(e->head_dim, e->nh_l / e->nkv_l)) return false;
     return true;

@@ -385,9 +385,7 @@ int vit_finalize(vlo_engine *e) {
 #undef PAD
     VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttnLds));
     VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_split8_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttn8Lds));
-    VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_split8_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttn8Lds / 2));
     VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_kernel<96, 80>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds(80)));
-    VIT_TRY(hipFuncSetAttribute((const void *)vit_attn_kernel<96, 80, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds(80, 2)));
     {
         const int cpr = v->Sp / 8;                                   // 16-byte chunks per V^T row
         v->attn_vrs = (cpr + ((10 - cpr % 16) + 16) % 16) * 16;
@@ -471,7 +469,7 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
     // K slices of the two residual GEMMs on the tall tiles: the most (<= 4) that leave a slice >= 3 K tiles — out-proj 4 x 4 tiles, fc2 4 x 16 at SigLIP-L
     // (64 output tiles x 4 = one workgroup per CU; measured: out-proj 11.2 us straight into the residual stream on 64 CUs vs 5.9 us as 4 slices, and the
     // LayerNorm behind it takes the slabs for +1 us)
-    static const int tall_max_rows = getenv("VLO_VIT_TALL_MAX_ROWS") ? atoi(getenv("VLO_VIT_TALL_MAX_ROWS")) : 1152;
+    constexpr int tall_max_rows = 1152;                          // one or two frames of SigLIP-L (three: the 64 x 64 tiles and the ping-pong kernel from four)
     const int tall_tiles = ((M + 143) / 144) * (D / 64);       // output tiles of a residual GEMM: slices fill the chip once (one frame: 64 x 4, two: 128 x 2)
     auto tall_ks = [&](int K) { for (int ks = 4; ks > 1; ks >>= 1) if (tall_tiles * ks <= vit_num_cus() && K % (GEMM_BK * ks) == 0 && K / (GEMM_BK * ks) >= 3) return ks; return 1; };
     const bool tall = M <= tall_max_rows && slab_ok && D % 64 == 0 && I % 64 == 0 && D >= 3 * GEMM_BK && I >= 3 * GEMM_BK;
@@ -522,29 +520,20 @@ static int vit_run(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_de
             VIT_TRY(tall ? gemm_launch_tall<EP_QKV>(a, 1, st) : gemm_launch<EP_QKV>(a, st));
         }
         // batched frames: one workgroup per (frame, head) with K and V^T resident in LDS; few frames: 64-query tiles, keys split over 4 waves
-        static const int attn8_on = getenv("VLO_VIT_ATTN8") ? atoi(getenv("VLO_VIT_ATTN8")) : 4;      // 0: the 4-wave kernel; 2 / 4: the 8-wave kernel on 32- / 64-query blocks (one frame: 12.8 / 10.5 us)
         static const int head_min = getenv("VLO_VIT_ATTN_HEAD_MIN") ? atoi(getenv("VLO_VIT_ATTN_HEAD_MIN")) : 96;     // workgroups; 0 = never
         static const int tiles_min = getenv("VLO_VIT_ATTN_TILES_MIN") ? atoi(getenv("VLO_VIT_ATTN_TILES_MIN")) : 192;   // workgroups of the tile-streamed padded-head kernel; 0 = never
         if (head_min > 0 && B * v->nh >= head_min && v->attn_head_lds > 0)
             hipLaunchKernelGGL((vit_attn_head_kernel<0>), dim3((S + 575) / 576, v->nh, B), dim3(768), v->attn_head_lds, st, w_qk16, w_vT, w_att16, S, D, v->nh,
                                scale * 1.4426950408889634f, v->attn_vrs);
-        else if (v->hdk == 64 && tall && S <= 768 && attn8_on == 4)
+        else if (v->hdk == 64 && tall && S <= 768)       // one frame (two): 8 waves per 64 queries, every load up front (32-query blocks measured 12.8 vs 10.5 us)
             hipLaunchKernelGGL((vit_attn_split8_kernel<3, 4>), dim3((S + 63) / 64, v->nh, B), dim3(512), kAttn8Lds, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
-        else if (v->hdk == 64 && tall && S <= 768 && attn8_on)
-            hipLaunchKernelGGL((vit_attn_split8_kernel<3, 2>), dim3((S + 31) / 32, v->nh, B), dim3(512), kAttn8Lds / 2, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
         else if (v->hdk == 64)
             hipLaunchKernelGGL((vit_attn_kernel<64>), dim3((S + 63) / 64, v->nh, B), dim3(256), kAttnLds, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
         else if (B * v->nh * ((S + 255) / 256) >= tiles_min && tiles_min > 0) {
             // padded heads, batched frames: 256-query workgroups over LDS-staged key tiles (vit_attn.inc::vit_attn_tiles_kernel)
-            static const int kStages = getenv("VLO_ATTN_STAGES") ? atoi(getenv("VLO_ATTN_STAGES")) : 4;        // tile buffers in the ring (2: one tile in flight)
-            if (kStages == 2) hipLaunchKernelGGL((vit_attn_tiles_kernel<96, 80, 2>), dim3((S + 255) / 256, v->nh, B), dim3(512), 0, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
-            else hipLaunchKernelGGL((vit_attn_tiles_kernel<96, 80, 4>), dim3((S + 255) / 256, v->nh, B), dim3(512), 0, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
+            hipLaunchKernelGGL((vit_attn_tiles_kernel<96, 80, 4>), dim3((S + 255) / 256, v->nh, B), dim3(512), 0, st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
         } else {
-            static const int qs = getenv("VLO_VIT_ATTN_QS") ? atoi(getenv("VLO_VIT_ATTN_QS")) : 4;     // 16-query sub-tiles per block for the padded-head kernel
-            if (qs == 2)
-                hipLaunchKernelGGL((vit_attn_kernel<96, 80, 2>), dim3((S + 31) / 32, v->nh, B), dim3(256), attn_lds(80, 2), st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
-            else
-                hipLaunchKernelGGL((vit_attn_kernel<96, 80>), dim3((S + 63) / 64, v->nh, B), dim3(256), attn_lds(80), st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
+            hipLaunchKernelGGL((vit_attn_kernel<96, 80>), dim3((S + 63) / 64, v->nh, B), dim3(256), attn_lds(80), st, w_qk16, w_vT, w_att16, S, D, v->nh, scale);
         }
         VIT_TRY(resid_gemm(w_att16, Ly.wo, Ly.bo, D, ks_out));
         layernorm(Ly.ln2_w, Ly.ln2_b, w_x16, nullptr);
@@ -626,9 +615,9 @@ static int vit_run_branches(vlo_engine *e, const uint8_t *frames_dev, int B, voi
 // Entry point.  The launch sequence is static for a given B, so it is captured once into a hipGraph and
 // replayed (one host call instead of ~180; the host thread also feeds the Llama stream).  Frames are
 // staged into a fixed input buffer and the embeddings leave through a fixed output buffer so the
-// captured kernel arguments stay valid.  VLO_VIT_GRAPH=0 disables the graph.
+// captured kernel arguments stay valid.  (The null stream cannot be captured: eager launches.)
 int vit_visual_embed(vlo_engine *e, const uint8_t *frames_dev, int B, void *out_dev, hipStream_t st) {
-    static const bool use_graph = getenv("VLO_VIT_GRAPH") ? atoi(getenv("VLO_VIT_GRAPH")) != 0 : true;
+    constexpr bool use_graph = true;
     VitState *v = e->vit;
     int rc;
     if ((rc = vit_reserve(e, v, B))) return rc;
