@@ -631,7 +631,8 @@ spec = O.LlmSpec(128, 192, 1, 2, 2, 256, 10000.0, 1e-5, vision_hidden_size=vspec
 w, vw = O.init_llm_weights(spec, seed=3), O.init_vit_weights(vspec, seed=4)
 ref = O.LlamaOracle(spec, w, torch.bfloat16)
 eng = E.EmulEngine(spec, vit=vspec).load_weights({**w, **vw}, O.rope_inv_freq(spec.head_dim, spec.rope_theta))
-for B in (1, 2):
+import os
+for B in ((1, 2) if os.environ.get("VLO_EMUL_FULL") == "1" else (1,)):
     frames = O.synthetic_frames(B, vspec.image_size, seed=7 + B)
     gold = O.LlamaOracle(spec, w, torch.float32).visual_embed(vw, vspec, frames)
     amp = ref.visual_embed(vw, vspec, frames, mm_dtype=torch.float16)
@@ -651,7 +652,7 @@ print("OKPP")
 def test_one_frame_path_tall_tiles_split_attention_and_row_head_in_emulation(E):
     """The one-frame encode of round 6 (csrc/vit_tall.inc: 144 x 64 tiles with the half-tile software pipeline and counted waits, fc2 as 4 K slices
     into slabs; vit_attn.inc::vit_attn_split8_kernel; vit.hip::vit_im2col_kernel + the tall patch-embed GEMM; vit_rowvec_kernel in the MAP head) on
-    the smallest tower that takes it (hidden 320 = 5 heads of 64, MLP 1280, 16 + 1 tokens), one and two frames, against the oracle with the
+    the smallest tower that takes it (hidden 320 = 5 heads of 64, MLP 1280, 16 + 1 tokens), one frame (two with VLO_EMUL_FULL=1), against the oracle with the
     tolerance of the ViT tests — with the emulated direct-to-LDS loads landing as LATE as the hardware may land them (only at the counted
     s_waitcnt that retires them: a wait count one piece too generous reads stale shared memory and fails)."""
     import subprocess
