@@ -13,8 +13,10 @@ typedef __attribute__((ext_vector_type(8))) _Float16 h8;
 typedef __attribute__((ext_vector_type(8))) __bf16 b8;
 typedef __attribute__((ext_vector_type(4))) float f4;
 typedef __attribute__((ext_vector_type(16))) float f16v;
+typedef __attribute__((ext_vector_type(8))) int i8v;
 
-// SHAPE 0: v_mfma_f32_16x16x32_f16 (16 K FLOP), 1: v_mfma_f32_32x32x16_f16 (32 K FLOP), 2 / 3: the bf16 forms
+// SHAPE 0: v_mfma_f32_16x16x32_f16 (16 K FLOP), 1: v_mfma_f32_32x32x16_f16 (32 K FLOP), 2 / 3: the bf16 forms,
+// 4: v_mfma_f32_16x16x128_f8f6f4 on e4m3 operands (64 K FLOP; BASELINE.json configs[4]'s "fp8 MFMA"), 5: v_mfma_f32_16x16x32_fp8_fp8 (16 K FLOP)
 template <int SHAPE, int NACC, int NT>
 __global__ __launch_bounds__(NT) void mfma_kernel(float *out, int iters, float seed) {
     h8 a, b;
@@ -27,7 +29,24 @@ __global__ __launch_bounds__(NT) void mfma_kernel(float *out, int iters, float s
         bb[i] = (__bf16)(float)b[i];
     }
     float r = 0.f;
-    if (SHAPE == 0 || SHAPE == 2) {
+    if (SHAPE == 4 || SHAPE == 5) {
+        i8v qa, qb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { qa[i] = 0x38383838 + (int)threadIdx.x * 0x01010101 * (i & 1); qb[i] = 0x3c343c34 ^ ((int)threadIdx.x << (i & 3)); }
+        f4 acc[NACC];
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) acc[j] = (f4){0.f, 0.f, 0.f, 0.f};
+        const long qa8 = ((long)qa[1] << 32) | (unsigned)qa[0], qb8 = ((long)qb[1] << 32) | (unsigned)qb[0];
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int j = 0; j < NACC; ++j) {
+                if (SHAPE == 4) acc[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(qa, qb, acc[j], 0, 0, 0, 0, 0, 0);
+                else acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(qa8, qb8, acc[j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) r += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    } else if (SHAPE == 0 || SHAPE == 2) {
         f4 acc[NACC];
 #pragma unroll
         for (int j = 0; j < NACC; ++j) acc[j] = (f4){0.f, 0.f, 0.f, 0.f};
@@ -77,7 +96,7 @@ static void run(const char *name, float *out, hipStream_t st) {
             float ms;
             CK(hipEventElapsedTime(&ms, e0, e1));
             const double n_mfma = 256.0 * (NT / 64) * (double)iters * NACC;
-            const double flop = n_mfma * ((SHAPE & 1) ? 32768.0 : 16384.0);
+            const double flop = n_mfma * (SHAPE == 4 ? 65536.0 : SHAPE == 5 ? 16384.0 : (SHAPE & 1) ? 32768.0 : 16384.0);
             const double per_simd = n_mfma / (256.0 * 4);
             printf("%-28s %d waves/CU, %d chains/wave: %8.3f ms  %7.0f TFLOP/s  %5.2f cycles per MFMA per SIMD @ 2.4 GHz\n", name, NT / 64, NACC, ms, flop / (ms * 1e-3) / 1e12,
                    ms * 1e-3 * 2.4e9 / per_simd);
@@ -100,5 +119,8 @@ int main() {
     run<1, 4, 512>("v_mfma_f32_32x32x16_f16", out, st);
     run<2, 8, 512>("v_mfma_f32_16x16x32_bf16", out, st);
     run<3, 4, 512>("v_mfma_f32_32x32x16_bf16", out, st);
+    run<4, 4, 256>("v_mfma_f32_16x16x128_f8f6f4 (e4m3)", out, st);
+    run<4, 8, 512>("v_mfma_f32_16x16x128_f8f6f4 (e4m3)", out, st);
+    run<5, 8, 512>("v_mfma_f32_16x16x32_fp8_fp8", out, st);
     return 0;
 }
