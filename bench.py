@@ -621,7 +621,8 @@ def main():
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "strong" if tp else "weak",
             "vs_baseline": None,
-            "dtype": "bf16" if args.weight_dtype == "bf16" else "bf16 activations / KV / accumulate-in-fp32, fp8 e4m3 weights (per-output-channel scales)",
+            "dtype": "bf16" if args.weight_dtype == "bf16" else "bf16 activations / KV / accumulate-in-fp32, fp8 e4m3 weights (per-output-channel scales) expanded to bf16 in registers for the live step's bf16 MFMA; "
+                     "native fp8 MFMA (W8A8) only on long-input prefill GEMMs with prefill_act_dtype=fp8, which this stream does not contain",
             "vit_dtype": "fp16 operands / fp32 accumulate + fp32 residual stream (the reference's GPU autocast, models/vision_live.py:13)",
             "data": "synthetic",
             "p50_frame_latency_ms": round(statistics.median(costs) * 1e3, 4),

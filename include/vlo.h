@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VLO_ABI_VERSION 2
+#define VLO_ABI_VERSION 3
 
 enum {
     VLO_OK = 0,
@@ -86,6 +86,12 @@ typedef struct vlo_config {
      * per output channel (BASELINE.json configs[4] "fp8 MFMA weights").  With 1, vlo_engine_load_weight takes those matrices as
      * VLO_DT_FP8_E4M3 [N][K] plus "<name>_scale" f32 [N] (W ~= q * scale[n]); activations, KV and accumulation are unchanged. */
     int32_t weight_dtype;
+    /* X operands of the LONG-INPUT projections (>= 256 new tokens: teacher-forced evaluation, a long first prompt) on an engine with
+     * weight_dtype = 1: 0 = bf16 (the e4m3 image is expanded to bf16 per GEMM, bf16 MFMA: the arithmetic of the live step); 1 = every X row
+     * quantised to e4m3 with one fp32 scale (max|row| / 448) and multiplied e4m3 x e4m3 on v_mfma_f32_16x16x128_f8f6f4 (W8A8; twice the MFMA
+     * rate; own parity band: the oracle run with the same activation rule).  The live step (<= 16 rows) and the 64-token block path keep
+     * bf16 activations either way. */
+    int32_t prefill_act_dtype;
 } vlo_config;
 
 /* ---- engine lifetime: replaces build_model_and_tokenizer(...)[0] + model.to('cuda')
@@ -187,6 +193,11 @@ double vlo_step_algorithmic_bytes(const vlo_engine *e, int64_t Lc, int n);
 int vlo_test_gemv(const void *x_dev, const void *W_dev, float *y_dev, int n, int N, int K, void *stream);
 /* the same through the fp8 e4m3 weight image: Wq_dev fp8 [N][K], scale_dev f32 [N]; y = (x @ Wq^T) * scale */
 int vlo_test_gemv_fp8(const void *x_dev, const void *Wq_dev, const float *scale_dev, float *y_dev, int n, int N, int K, void *stream);
+/* the long-input W8A8 GEMM of an engine with prefill_act_dtype = 1 (csrc/prefill.h): x bf16 [M][K] quantised per row to e4m3, multiplied with
+ * Wq fp8 [N][K] on the native fp8 MFMA; y f32 [M][N] = (xq @ Wq^T) * scale[n] * xscale[m].  N, K multiples of 256.  Optional outputs: xq_dev
+ * [M][K] e4m3 codes in the kernel's row order (prefill.h::vlo_fp8_row_pos), xscale_dev f32 [M]; iters > 0: *avg_us = the GEMM alone, timed. */
+int vlo_test_gemm_fp8(const void *x_dev, const void *Wq_dev, const float *scale_dev, float *y_dev, void *xq_dev, float *xscale_dev, int M, int N, int K,
+                      int iters, double *avg_us, void *stream);
 
 /* ---- teacher-forced evaluation: the arithmetic of LiveMixin.joint_embed / stream_evaluate /
  *      trim_past_key_values (models/modeling_live.py:29-42, 44-168, 170-171).  The per-turn bookkeeping over these

@@ -371,6 +371,24 @@ FP8_STREAMED = ("q_proj.weight", "k_proj.weight", "v_proj.weight", "o_proj.weigh
                 "down_proj.weight", "lm_head.weight")
 
 
+def e4m3_rne(x: torch.Tensor) -> torch.Tensor:
+    """fp32 values (|x| <= 448) rounded to the nearest OCP e4m3 value, ties to even: 8 steps per binade, 2^-9 below 2^-6"""
+    _, ex = torch.frexp(x)
+    step_exp = (ex - 4).clamp_min(-9)
+    q = torch.ldexp(torch.round(torch.ldexp(x, -step_exp)), step_exp).clamp(-448.0, 448.0)
+    return q
+
+
+def fp8_quantize_rows(x: torch.Tensor):
+    """The W8A8 prefill rule of an fp8 engine with prefill_act_dtype = 1 (include/vlo.h; csrc/prefill.h) — the weights' rule applied to an
+    activation row: scale[m] = max|x[m]| * (1/448) (1 for a zero row), q[m] = e4m3_rne(clamp(x[m] / scale[m], -448, 448)).
+    Returns (q as fp32 e4m3 values, scale fp32 [m, 1]).  The reference has no fp8 path (config 5 exceeds it)."""
+    xf = x.float()
+    amax = xf.abs().amax(dim=-1, keepdim=True)
+    s = torch.where(amax > 0, amax * (1.0 / 448.0), torch.ones_like(amax))
+    return e4m3_rne((xf / s).clamp(-448.0, 448.0)), s
+
+
 def fp8_dequantized_weights(weights: dict) -> dict:
     """BASELINE.json configs[4] ("fp8 MFMA weights"): the streamed Llama projections replaced by what an fp8 e4m3 store with one
     scale per output channel holds — W' = e4m3_rne(W / s) * s, s[n] = max|W[n]| * (1/448) — as fp32 tensors; everything else
@@ -383,10 +401,7 @@ def fp8_dequantized_weights(weights: dict) -> dict:
             Wf = v.float()
             amax = Wf.abs().amax(dim=1)
             s = torch.where(amax > 0, amax * (1.0 / 448.0), torch.ones_like(amax))
-            x = (Wf / s[:, None]).clamp(-448.0, 448.0)
-            _, ex = torch.frexp(x)                      # e4m3 round-to-nearest-even: 8 steps per binade, 2^-9 below 2^-6
-            step_exp = (ex - 4).clamp_min(-9)
-            q = torch.ldexp(torch.round(torch.ldexp(x, -step_exp)), step_exp).clamp(-448.0, 448.0)
+            q = e4m3_rne((Wf / s[:, None]).clamp(-448.0, 448.0))
             assert torch.equal(q, q.to(torch.float8_e4m3fn).float())     # every q is an e4m3 value
             out[k] = q * s[:, None]
         else:
@@ -394,9 +409,13 @@ def fp8_dequantized_weights(weights: dict) -> dict:
     return out
 
 
-def _llm_linear(x, W):
+def _llm_linear(x, W, act_fp8=False):
     """F.linear; a weight kept in fp32 next to lower-precision activations (fp8_dequantized_weights) is applied in fp32 and
-    the output rounded to the activation dtype"""
+    the output rounded to the activation dtype.  ``act_fp8``: the rows of x go through fp8_quantize_rows first (W8A8 prefill):
+    y = (q @ W^T) * scale[m], accumulated in fp32, rounded to the activation dtype."""
+    if act_fp8:
+        q, s = fp8_quantize_rows(x)
+        return (F.linear(q, W.float()) * s).to(x.dtype)
     if W.dtype == x.dtype:
         return F.linear(x, W)
     return F.linear(x.float(), W.float()).to(x.dtype)
@@ -420,8 +439,10 @@ class LlamaOracle:
         return F.embedding(ids, self.W["model.embed_tokens.weight"])
 
     @torch.no_grad()
-    def forward(self, inputs_embeds: torch.Tensor, cache: KVCacheOracle | None, taps: dict | None = None, logits_from: int = 0):
+    def forward(self, inputs_embeds: torch.Tensor, cache: KVCacheOracle | None, taps: dict | None = None, logits_from: int = 0, act_fp8: bool = False):
         """inputs_embeds [n,H] -> (logits [n,V], cache).  LlamaModel.forward :367-417.
+        ``act_fp8``: every decoder-layer projection of THIS call (q/k/v/o, gate/up/down; not the lm_head) quantises its input rows to e4m3
+        (fp8_quantize_rows) — what an fp8 engine with prefill_act_dtype = 1 does on a long input; not a reference feature.
         ``logits_from`` (test bookkeeping for long cache fills): lm_head only on rows [logits_from, n) — the rows are
         independent, so the rows that are produced equal HF's; n means "no logits" (returns an empty [0,V])."""
         s, W = self.spec, self.W
@@ -440,9 +461,9 @@ class LlamaOracle:
         for i in range(s.num_layers):
             p = f"model.layers.{i}."
             x = rmsnorm(h, W[p + "input_layernorm.weight"], s.rms_eps)
-            q = _llm_linear(x, W[p + "self_attn.q_proj.weight"]).view(n, nh, hd).transpose(0, 1)
-            k = _llm_linear(x, W[p + "self_attn.k_proj.weight"]).view(n, nkv, hd).transpose(0, 1)
-            v = _llm_linear(x, W[p + "self_attn.v_proj.weight"]).view(n, nkv, hd).transpose(0, 1)
+            q = _llm_linear(x, W[p + "self_attn.q_proj.weight"], act_fp8).view(n, nh, hd).transpose(0, 1)
+            k = _llm_linear(x, W[p + "self_attn.k_proj.weight"], act_fp8).view(n, nkv, hd).transpose(0, 1)
+            v = _llm_linear(x, W[p + "self_attn.v_proj.weight"], act_fp8).view(n, nkv, hd).transpose(0, 1)
             q = (q * cos) + (rotate_half(q) * sin)                       # :157-158
             k = (k * cos) + (rotate_half(k) * sin)
             K, V = cache.update(i, k, v)
@@ -456,15 +477,15 @@ class LlamaOracle:
             a = a.transpose(0, 1).reshape(n, nh * hd)
             if taps is not None and i in taps.get("_layers", ()):
                 taps[f"attn{i}"] = a.clone()
-            h = h + _llm_linear(a, W[p + "self_attn.o_proj.weight"])        # :317
+            h = h + _llm_linear(a, W[p + "self_attn.o_proj.weight"], act_fp8)        # :317
             x = rmsnorm(h, W[p + "post_attention_layernorm.weight"], s.rms_eps)
-            x = _llm_linear(F.silu(_llm_linear(x, W[p + "mlp.gate_proj.weight"])) * _llm_linear(x, W[p + "mlp.up_proj.weight"]),
-                         W[p + "mlp.down_proj.weight"])                  # :174-176
+            x = _llm_linear(F.silu(_llm_linear(x, W[p + "mlp.gate_proj.weight"], act_fp8)) * _llm_linear(x, W[p + "mlp.up_proj.weight"], act_fp8),
+                         W[p + "mlp.down_proj.weight"], act_fp8)         # :174-176
             h = h + x                                                    # :323
             if taps is not None and i in taps.get("_layers", ()):
                 taps[f"h{i}"] = h.clone()
         h = rmsnorm(h[logits_from:], W["model.norm.weight"], s.rms_eps)
-        logits = _llm_linear(h, W["lm_head.weight"])                        # :477-480 (all rows, as HF, unless logits_from > 0)
+        logits = _llm_linear(h, W["lm_head.weight"])                        # :477-480 (all rows, as HF, unless logits_from > 0); never act_fp8
         return logits, cache
 
     @torch.no_grad()

@@ -53,6 +53,10 @@ def build(force=False, sanitize=None):
         src = re.sub(r'asm volatile\("s_mov_b32 %0, m0[^;]*;', "emul_glds(gsrc, (char *)lds_dst + (threadIdx.x & 63) * 16, 16); (void)keep; (void)dst;", src)
         # csrc/vit_tall.inc::glds16_saddr — the same with an SGPR base + per-lane byte offset
         src = re.sub(r'asm volatile\("s_mov_b32 m0, %2[^;]*;', "emul_glds((const char *)sbase + voff, (char *)lds_dst + (threadIdx.x & 63) * 16, 16); (void)dst;", src)
+        # csrc/common.cuh::mfma_fp8_k128_acc — the fp8 MFMA accumulating in place through inline asm, and the software wait states around it
+        src = re.sub(r'asm volatile\("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0"\s*:\s*"\+v"\((\w+)\)\s*:\s*"v"\((\w+)\),\s*"v"\((\w+)\)\);',
+                     r"\1 = emul_mfma_fp8_16x16x128(\2, \3, \1);", src)
+        src = re.sub(r'asm volatile\("s_nop[^"]*"(?:\s*:::\s*"memory")?\);', ";", src)
         src = re.sub(r'asm volatile\(""\s*:::\s*"memory"\);', ";", src)                  # compiler-only memory barrier
         src = re.sub(r'asm(?: volatile)?\(""\s*:\s*"\+v"\(\w+\)\);', ";", src)      # optimisation barrier on a VGPR value
         src = re.sub(r'asm\("s_nop 7\\n\\ts_nop 3\\n\\tv_max3_f32[^;]*;', "r = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), fmaxf(fmaxf(a4, a5), fmaxf(a6, a7)));", src)

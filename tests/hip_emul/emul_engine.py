@@ -52,6 +52,18 @@ def test_gemv_fp8(x, Wq, scale):
     return y
 
 
+def test_gemm_fp8(x, Wq, scale):
+    """The W8A8 prefill GEMM of the emulated library (vlo_test_gemm_fp8): (y f32 [M,N], e4m3 codes [M,K] in column order, row scales f32 [M])."""
+    from videollm_online_amd.engine import fp8_row_order
+    x, Wq, scale = x.to(torch.bfloat16).contiguous(), Wq.contiguous().view(torch.uint8), scale.float().contiguous()
+    M, K, N = x.shape[0], x.shape[1], Wq.shape[0]
+    y = torch.zeros(M, N, dtype=torch.float32)
+    xq = torch.zeros(M, K, dtype=torch.uint8)
+    xs = torch.zeros(M, dtype=torch.float32)
+    check(lib().vlo_test_gemm_fp8(_ptr(x), _ptr(Wq), _ptr(scale), _ptr(y), _ptr(xq), _ptr(xs), M, N, K, 0, None, None))
+    return y, xq[:, fp8_row_order(K)].view(torch.float8_e4m3fn), xs
+
+
 def gemv_plan(K, allow_ksplit):
     out = (C.c_int * 4)()
     check(lib().vlo_debug_gemv_plan(K, int(allow_ksplit), out))
@@ -59,10 +71,11 @@ def gemv_plan(K, allow_ksplit):
 
 
 class EmulEngine:
-    def __init__(self, spec, kv_pool_tokens=1024, tp_rank=0, tp_size=1, vit=None, weight_dtype=0):
+    def __init__(self, spec, kv_pool_tokens=1024, tp_rank=0, tp_size=1, vit=None, weight_dtype=0, prefill_act_dtype=0):
         self.spec, self.vit = spec, vit
         c = _C.VloConfig()
         c.weight_dtype = weight_dtype                    # 1: fp8 e4m3 image of the streamed projections (+ "<name>_scale")
+        c.prefill_act_dtype = prefill_act_dtype          # 1 (fp8 engines): W8A8 prefill GEMMs on the fp8 MFMA
         if vit is not None:
             c.has_vit = 1
             c.vit_hidden_size, c.vit_intermediate_size = vit.hidden_size, vit.intermediate_size

@@ -180,6 +180,33 @@ static inline V4 emul_mfma_16x16x32(V8 a, V8 b, V4 c) {
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emul_mfma_16x16x32((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) emul_mfma_16x16x32((a), (b), (c))
 
+// v_mfma_f32_16x16x128_f8f6f4 on e4m3 bytes (cbsz = blgp = 0, unscaled): a lane's 32 operand bytes are row / column l & 15 and k slots
+// (l >> 4) * 32 + [0, 32) — four passes of the 16x16x32 scratch.  fp32 accumulation here (the hardware's adder keeps fewer bits: DESIGN.md).
+static inline float emul_fp8_e4m3(unsigned b);
+template <class V8I, class V4>
+static inline V4 emul_mfma_fp8_16x16x128(V8I a, V8I b, V4 c) {
+    emul_wave_ctx &W = emul_ctx->waves[threadIdx.x >> 6];
+    const int l = threadIdx.x & 63, i = l & 15, kb = (l >> 4) * 8;
+    V4 d = c;
+    for (int p = 0; p < 4; ++p) {
+        for (int j = 0; j < 8; ++j) {
+            const int byte = p * 8 + j;
+            W.A[i * 32 + kb + j] = emul_fp8_e4m3(((unsigned)a[byte >> 2] >> ((byte & 3) * 8)) & 0xffu);
+            W.B[(kb + j) * 16 + i] = emul_fp8_e4m3(((unsigned)b[byte >> 2] >> ((byte & 3) * 8)) & 0xffu);
+        }
+        pthread_barrier_wait(&W.bar);
+        for (int r = 0; r < 4; ++r) {
+            const int m = (l >> 4) * 4 + r;
+            float s = d[r];
+            for (int k = 0; k < 32; ++k) s += W.A[m * 32 + k] * W.B[k * 16 + i];
+            d[r] = s;
+        }
+        pthread_barrier_wait(&W.bar);
+    }
+    return d;
+}
+#define __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, cbsz, blgp, oa, sa, ob, sb) emul_mfma_fp8_16x16x128((a), (b), (c))
+
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 #define __expf(x) expf(x)                // glibc declares __expf but does not export it
@@ -225,6 +252,27 @@ static inline emul_f32x2 emul_cvt_pk_f32_fp8(int src, bool hi) {
     return r;
 }
 #define __builtin_amdgcn_cvt_pk_f32_fp8(src, sel) emul_cvt_pk_f32_fp8((src), (sel))
+// v_cvt_pk_fp8_f32: two floats -> two e4m3fn bytes (round to nearest even, saturating at 448) into the low / high half of `old`
+static inline unsigned emul_f32_to_e4m3(float f) {
+    const unsigned sign = std::signbit(f) ? 0x80u : 0u;
+    float a = fabsf(f);
+    if (std::isnan(a)) return sign | 0x7fu;
+    if (a > 448.f) a = 448.f;
+    int ex;
+    (void)frexpf(a, &ex);                                   // a = m 2^ex, m in [0.5, 1)
+    const int step_exp = (ex - 4) < -9 ? -9 : (ex - 4);     // 8 steps per binade, 2^-9 below 2^-6
+    const float q = ldexpf(nearbyintf(ldexpf(a, -step_exp)), step_exp);     // default rounding mode: ties to even
+    if (q == 0.f) return sign;
+    int e2;
+    const float m = frexpf(q, &e2);                          // q = m 2^e2
+    if (e2 - 1 < -6) return sign | (unsigned)lrintf(ldexpf(q, 9));          // subnormal: q / 2^-9
+    return sign | ((unsigned)(e2 - 1 + 7) << 3) | (unsigned)lrintf((m * 2.f - 1.f) * 8.f);
+}
+static inline int emul_cvt_pk_fp8_f32(float a, float b, int old, bool hi) {
+    const unsigned pair = emul_f32_to_e4m3(a) | (emul_f32_to_e4m3(b) << 8);
+    return hi ? (int)(((unsigned)old & 0x0000ffffu) | (pair << 16)) : (int)(((unsigned)old & 0xffff0000u) | pair);
+}
+#define __builtin_amdgcn_cvt_pk_fp8_f32(a, b, old, sel) emul_cvt_pk_fp8_f32((a), (b), (old), (sel))
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(order)
 // HW_REG_XCC_ID: a scrambled, uneven block -> "XCD" map (5 populated groups), so nothing may rely on a placement pattern
 #define __builtin_amdgcn_s_getreg(imm) ((unsigned)((blockIdx.x * 5u + 3u) % 7u % 5u))

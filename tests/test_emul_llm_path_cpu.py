@@ -529,6 +529,58 @@ def test_fp8_weight_image_gemv(E, n, N, K):
 FP8_TINY = O.LlmSpec(512, 1024, 1, 4, 2, 256, 10000.0, 1e-5, vision_hidden_size=128)    # K = 512 / 1024: the smallest shapes the fp8 image takes
 
 
+def test_fp8_mfma_prefill_gemm_in_emulation(E):
+    """The W8A8 prefill GEMM (csrc/prefill.h: quantize_rows_fp8_kernel + vit_gemm_pp_kernel<.., F8 = 1> on v_mfma_f32_16x16x128_f8f6f4, the shim's
+    emulation of it): one 128-row tile, four K tiles.  Codes and scales bit for bit against the oracle's rule; the sums against fp64 on the same
+    codes (the emulated instruction accumulates in fp32 — the hardware's narrower adder is measured in tests/test_gpu_fp8_mfma.py)."""
+    from videollm_online_amd.checkpoint import quantize_fp8_per_channel
+    g = torch.Generator().manual_seed(21)
+    M, N, K = 70, 256, 512
+    x = torch.randn(M, K, generator=g)
+    x[:, ::61] *= 25.0
+    x[3] = 0.0
+    x = x.bfloat16()
+    W = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    q, s = quantize_fp8_per_channel(W)
+    y, codes, xs = E.test_gemm_fp8(x, q, s)
+    oq, osc = O.fp8_quantize_rows(x)
+    assert torch.equal(xs, osc[:, 0])
+    assert torch.equal(codes.float(), oq)
+    ref = (oq.double() @ q.float().double().T) * s.double()[None, :] * osc.double()
+    assert (y.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+
+
+@pytest.mark.skipif(not FULL, reason="longer emulation cases: VLO_EMUL_FULL=1")
+def test_fp8_mfma_engine_prefill_path_in_emulation(E):
+    """An fp8 engine with prefill_act_dtype = 1 on the prefill path: 300 tokens W8A8 (decoder-layer projections; the lm_head keeps bf16
+    activations), then a decode step on bf16 activations — 3-way against the oracle run with the same rule per call."""
+    from videollm_online_amd.checkpoint import quantize_fp8_per_channel
+    spec = O.LlmSpec(512, 512, 1, 4, 1, 256, 10000.0, 1e-5, vision_hidden_size=128)
+    w = O.init_llm_weights(spec, seed=12)
+    eng_w, ora_w, keep = {}, {}, set()
+    for k, v in w.items():
+        if k.endswith(O.FP8_STREAMED):
+            q, sc = quantize_fp8_per_channel(v)
+            eng_w[k], eng_w[k + "_scale"] = q, sc
+            ora_w[k] = q.float() * sc[:, None]
+            keep.add(k)
+        else:
+            eng_w[k] = ora_w[k] = v
+    ref, gold = O.LlamaOracle(spec, ora_w, torch.bfloat16, keep_fp32=keep), O.LlamaOracle(spec, ora_w, torch.float32)
+    eng = E.EmulEngine(spec, kv_pool_tokens=1024, weight_dtype=1, prefill_act_dtype=1).load_weights(eng_w, O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+    s = eng.new_session()
+    g = torch.Generator().manual_seed(4)
+    rc = gc = None
+    for i, n in enumerate((300, 1)):
+        x = (torch.randn(n, spec.hidden_size, generator=g) * 0.7).bfloat16()
+        rl, rc = ref.forward(x, rc, act_fp8=(n >= 256))
+        gl, gc = gold.forward(x, gc, act_fp8=(n >= 256))
+        last, allr = eng.llm_step(s, x)
+        assert eng.session_len(s) == len(rc)
+        _three_way("fp8 mfma prefill path", i, allr, rl, gl)
+    eng.close()
+
+
 @pytest.mark.skipif(not FULL, reason="longer emulation cases: VLO_EMUL_FULL=1 (1.5 minutes; the bf16 prefill path runs in the default suite, the hardware case is tests/test_gpu_fp8.py::test_fp8_prefill_path_teacher_forced_rows)")
 def test_fp8_engine_prefill_path_in_emulation(E):
     """An fp8 engine on the prefill path: the e4m3 image expanded to the packed bf16 image per GEMM (prefill.hip::expand_fp8_image_kernel)

@@ -8,7 +8,7 @@ import torch  # noqa: F401  — loads torch's bundled libamdhip64 first so libvl
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libvlo.so")
 
-VLO_ABI_VERSION = 2
+VLO_ABI_VERSION = 3
 DT_F32, DT_BF16, DT_F16, DT_FP8_E4M3 = 0, 1, 2, 3
 
 
@@ -23,6 +23,7 @@ class VloConfig(C.Structure):
         ("vit_num_layers", C.c_int32), ("vit_num_heads", C.c_int32), ("vit_image_size", C.c_int32),
         ("vit_patch_size", C.c_int32), ("vit_ln_eps", C.c_float), ("pool_h", C.c_int32), ("pool_w", C.c_int32),
         ("kv_pool_tokens", C.c_int64), ("tp_rank", C.c_int32), ("tp_size", C.c_int32), ("weight_dtype", C.c_int32),
+        ("prefill_act_dtype", C.c_int32),
     ]
 
 
@@ -37,7 +38,7 @@ EXPORTS = [
     "vlo_tp_unique_id", "vlo_tp_group_create", "vlo_tp_group_destroy", "vlo_tp_session_create", "vlo_tp_session_reset",
     "vlo_tp_session_len", "vlo_tp_session_destroy", "vlo_tp_llm_step", "vlo_tp_stream_sample", "vlo_tp_greedy_generate",
     "vlo_joint_embed", "vlo_logit_rows", "vlo_session_fork", "vlo_session_crop", "vlo_tp_selftest", "vlo_debug_gemm64_plan", "vlo_debug_pack64_elem",
-    "vlo_step_input", "vlo_build_id", "vlo_frame_ingest", "vlo_frame_ingest_geometry", "vlo_test_gemv_fp8", "vlo_tp_comm_info", "vlo_tp_allgather",
+    "vlo_step_input", "vlo_build_id", "vlo_frame_ingest", "vlo_frame_ingest_geometry", "vlo_test_gemv_fp8", "vlo_test_gemm_fp8", "vlo_tp_comm_info", "vlo_tp_allgather",
     "vlo_tp_p2p_export", "vlo_tp_p2p_enable", "vlo_tp_p2p_status", "vlo_debug_p2p_layout", "vlo_tp_bench_exchange",
     "vlo_tp_session_fork", "vlo_tp_session_crop",
 ]
@@ -103,6 +104,7 @@ def bind(L):
     L.vlo_step_algorithmic_bytes.restype = C.c_double
     L.vlo_test_gemv.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.vlo_test_gemv_fp8.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
+    L.vlo_test_gemm_fp8.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, C.POINTER(C.c_double), vp]
     L.vlo_bench_gemv.argtypes = [i32, i32, i32, i32, i32, i32, C.POINTER(C.c_double)]
     L.vlo_debug_read.argtypes = [vp, i32, vp, i64, vp]
     L.vlo_debug_gemv_plan.argtypes = [i32, i32, C.POINTER(i32)]

@@ -42,6 +42,24 @@ VLO_DEV f32x4 mfma_f16(frag_ab a, frag_ab b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(frag_h, a), __builtin_bit_cast(frag_h, b), c, 0, 0, 0);
 }
 
+// v_mfma_f32_16x16x128_f8f6f4 on OCP e4m3 bytes (cbsz = blgp = 0; zero scale operands select the UNSCALED instruction): a lane's operand is
+// 32 bytes = row / column l & 15, 32 of the 128 k's.  Which 32 is the caller's business — a dot product does not care about the order of its
+// terms as long as A and B agree — so the operand is given as the two 16-byte halves the callers already hold (D layout = the 16x16x32 forms').
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+VLO_DEV f32x4 mfma_fp8_k128(frag_ab a0, frag_ab a1, frag_ab b0, frag_ab b1, f32x4 c) {
+    const i32x8_t A = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, a0), __builtin_bit_cast(i32x4_t, a1), 0, 1, 2, 3, 4, 5, 6, 7);
+    const i32x8_t B = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, b0), __builtin_bit_cast(i32x4_t, b1), 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, c, 0, 0, 0, 0, 0, 0);
+}
+
+// the same, accumulating IN PLACE (vdst = srcC) through inline asm — see vit_gemm.inc (F8) for why and for the hazards the caller covers
+VLO_DEV void mfma_fp8_k128_acc(frag_ab a0, frag_ab a1, frag_ab b0, frag_ab b1, f32x4 &c) {
+    const i32x8_t A = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, a0), __builtin_bit_cast(i32x4_t, a1), 0, 1, 2, 3, 4, 5, 6, 7);
+    const i32x8_t B = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, b0), __builtin_bit_cast(i32x4_t, b1), 0, 1, 2, 3, 4, 5, 6, 7);
+    asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+v"(c) : "v"(A), "v"(B));
+}
+
 VLO_DEV float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -39,6 +39,7 @@ struct PrefillWs {
     void *wexp = nullptr;
     size_t wexp_bytes = 0;
     float *partial = nullptr;
+    void *xq = nullptr;
 };
 
 struct vlo_engine {
@@ -115,6 +116,9 @@ struct vlo_session {
     // step on streams of their own, a scratch shared through the engine would be overwritten under another session's GEMM
     void *pf_wexp = nullptr;
     size_t pf_wexp_bytes = 0;
+    // prefill_act_dtype = 1: the e4m3 codes of ONE projection's X operand ([VLO_PREFILL_TOKENS + 256][widest layer K] bytes) followed by its
+    // row scales ([VLO_PREFILL_TOKENS + 256] floats), rewritten before each GEMM (prefill.h::quantize_rows_fp8_launch)
+    void *pxq = nullptr;
     float *ppartial = nullptr;                   // TP prefill: this rank's o-proj / down-proj partial sums fp32 [VLO_PREFILL_TOKENS][H] awaiting the all-reduce
 };
 
@@ -126,7 +130,9 @@ GemvArgs gemv_args(const PackedLinear &pl, const unsigned short *x, int ldx, int
 KvGeom kv_geom(const vlo_session *s);
 int ensure_prefill_ws(vlo_session *s);                        // prefill-path workspaces of a session (sized for the engine's shard)
 bool prefill_ok(const vlo_engine *e);                         // do this engine's (shard) shapes take the prefill GEMMs
-int prefill_gemm(vlo_session *s, const unsigned short *X, const PackedLinear &pl, int m, int N, int K, void *out, int ldo, int kind, hipStream_t st);
+// layer_proj: a decoder-layer projection (takes the native fp8 MFMA when the engine asks for it); false = the lm_head (bf16 activations always)
+int prefill_gemm(vlo_session *s, const unsigned short *X, const PackedLinear &pl, int m, int N, int K, void *out, int ldo, int kind, hipStream_t st,
+                 bool layer_proj = true);
 void ingest_create(vlo_engine *e);
 void ingest_destroy(vlo_engine *e);
 int connector_run(vlo_engine *e, int slot, const void *feats_dev, int rows, void *out_dev, hipStream_t st);   // slot 0 / 1: scratch set

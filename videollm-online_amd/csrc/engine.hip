@@ -90,6 +90,8 @@ int vlo_engine_create(const vlo_config *cfg, int device, vlo_engine **out) {
     const int hd = cfg->hidden_size / cfg->num_heads;
     if (hd != 64 && hd != 128) return fail(VLO_E_UNSUPPORTED, "head_dim must be 64 or 128");
     if (cfg->weight_dtype != 0 && cfg->weight_dtype != 1) return fail(VLO_E_INVALID, "weight_dtype must be 0 (bf16) or 1 (fp8 e4m3)");
+    if (cfg->prefill_act_dtype != 0 && !(cfg->prefill_act_dtype == 1 && cfg->weight_dtype == 1))
+        return fail(VLO_E_INVALID, "prefill_act_dtype must be 0 (bf16), or 1 (fp8 e4m3 per-row-scaled, native fp8 MFMA) on an engine with weight_dtype = 1");
     if ((cfg->hidden_size & 31) || (cfg->intermediate_size & 31) || (cfg->vocab_size & 3))
         return fail(VLO_E_UNSUPPORTED, "hidden/intermediate must be multiples of 32, vocab of 4");
     const int T = cfg->tp_size > 1 ? cfg->tp_size : 1;
@@ -122,7 +124,7 @@ void vlo_engine_destroy(vlo_engine *e) {
     for (auto &kv : e->raw) hipFree(kv.second.ptr);
     for (void *p : e->owned) hipFree(p);
     for (const PrefillWs &w : e->prefill_free)
-        for (void *p : {(void *)w.ph, (void *)w.px, (void *)w.pqkv, (void *)w.pq, (void *)w.pact, w.wexp, (void *)w.partial}) if (p) hipFree(p);
+        for (void *p : {(void *)w.ph, (void *)w.px, (void *)w.pqkv, (void *)w.pq, (void *)w.pact, w.wexp, (void *)w.partial, w.xq}) if (p) hipFree(p);
     for (auto &pr : e->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     vit_destroy(e);
     ingest_destroy(e);
@@ -763,7 +765,7 @@ int ensure_prefill_ws(vlo_session *s) {
             const PrefillWs w = e->prefill_free.back();
             e->prefill_free.pop_back();
             s->ph = w.ph; s->px = w.px; s->pqkv = w.pqkv; s->pq = w.pq;
-            s->pf_wexp = w.wexp; s->pf_wexp_bytes = w.wexp_bytes; s->ppartial = w.partial;
+            s->pf_wexp = w.wexp; s->pf_wexp_bytes = w.wexp_bytes; s->ppartial = w.partial; s->pxq = w.xq;
             s->pact = w.pact;
             return VLO_OK;
         }
@@ -786,19 +788,19 @@ int ensure_prefill_ws(vlo_session *s) {
 
 // a destroyed session's prefill set goes back to its engine's pool (the device is idle: vlo_session_destroy synchronises first)
 static void release_prefill_ws(vlo_session *s) {
-    if (!s->ph && !s->px && !s->pqkv && !s->pq && !s->pact && !s->pf_wexp && !s->ppartial) return;
+    if (!s->ph && !s->px && !s->pqkv && !s->pq && !s->pact && !s->pf_wexp && !s->ppartial && !s->pxq) return;
     vlo_engine *e = s->e;
     if (!s->pact) {                             // an allocation failed half way: nothing reusable
-        for (void *p : {(void *)s->ph, (void *)s->px, (void *)s->pqkv, (void *)s->pq, s->pf_wexp, (void *)s->ppartial}) if (p) hipFree(p);
+        for (void *p : {(void *)s->ph, (void *)s->px, (void *)s->pqkv, (void *)s->pq, s->pf_wexp, (void *)s->ppartial, s->pxq}) if (p) hipFree(p);
     } else {
         PrefillWs w;
         w.ph = s->ph; w.px = s->px; w.pqkv = s->pqkv; w.pq = s->pq; w.pact = s->pact;
-        w.wexp = s->pf_wexp; w.wexp_bytes = s->pf_wexp_bytes; w.partial = s->ppartial;
+        w.wexp = s->pf_wexp; w.wexp_bytes = s->pf_wexp_bytes; w.partial = s->ppartial; w.xq = s->pxq;
         std::lock_guard<std::mutex> g(e->pool_mu);
         e->prefill_free.push_back(w);
     }
     s->ph = s->px = s->pqkv = s->pq = s->pact = nullptr;
-    s->pf_wexp = nullptr; s->pf_wexp_bytes = 0; s->ppartial = nullptr;
+    s->pf_wexp = nullptr; s->pf_wexp_bytes = 0; s->ppartial = nullptr; s->pxq = nullptr;
 }
 
 // partial states for the fallback attention kernel (shapes attn_prefill_kernel is not instantiated for): 67 MB at the 8B shape,
@@ -819,9 +821,30 @@ static int ensure_prefill_partials(vlo_session *s) {
 // One projection of a prefill block: out = X W^T through the GEMM of prefill.h (kind = LLM_GEMM_*).  fp8 engines: the projection's e4m3 image is
 // expanded to bf16 (exactly) into the session's scratch right before its GEMM — 3 bytes of extra traffic per weight against hundreds of tokens of
 // MFMA work per weight — and its per-channel scales go to the GEMM's epilogue.  Shared with tp.hip (a rank's shard of a tensor-parallel prefill).
-int prefill_gemm(vlo_session *s, const unsigned short *X, const PackedLinear &pl, int m, int N, int K, void *out, int ldo, int kind, hipStream_t st) {
+int prefill_gemm(vlo_session *s, const unsigned short *X, const PackedLinear &pl, int m, int N, int K, void *out, int ldo, int kind, hipStream_t st,
+                 bool layer_proj) {
     vlo_engine *e = s->e;
     if (!pl.wq) { HIP_TRY(llm_gemm_launch(X, pl.Wp, m, N, K, out, ldo, kind, st)); return VLO_OK; }
+    if (layer_proj && e->cfg.prefill_act_dtype == 1 && llm_gemm_fp8_ok(N, K)) {
+        // native fp8 MFMA (prefill.h): X quantised per row into the session's code scratch (codes, then the scales), W = the fp8 image as stored.
+        // Rows past m keep whatever the scratch held: they are computed and dropped, no output row depends on another row's X.
+        const size_t RX = VLO_PREFILL_TOKENS + 256;
+        const LayerWeights &L0 = e->layers[0];
+        const size_t kmax = (size_t)std::max({L0.qkv.K, L0.o.K, L0.gate_up.K, L0.down.K});
+        if ((size_t)K > kmax) return fail(VLO_E_STATE, "prefill_gemm: a layer projection wider than the layer's widest K");
+        if (!s->pxq) {
+            void *p = nullptr;
+            int rc2 = dev_alloc(&p, RX * kmax + RX * sizeof(float));
+            if (rc2) return rc2;
+            HIP_TRY(hipMemset(p, 0, RX * kmax + RX * sizeof(float)));
+            HIP_TRY(hipDeviceSynchronize());
+            s->pxq = p;
+        }
+        float *xs = reinterpret_cast<float *>((char *)s->pxq + RX * kmax);
+        HIP_TRY(quantize_rows_fp8_launch(X, m, K, s->pxq, xs, st));
+        HIP_TRY(llm_gemm_fp8_launch(s->pxq, xs, pl.Wp, pl.wscale, m, N, K, out, ldo, kind, st));
+        return VLO_OK;
+    }
     // sized for the largest projection of a layer at the first use (not grown projection by projection); the lm_head image may grow it once more
     const LayerWeights &L0 = e->layers[0];
     const size_t img = (size_t)pl.NT * 16 * K * 2;
@@ -879,7 +902,7 @@ static int run_prefill(vlo_session *s, const unsigned short *src, int m, bool wa
         HIP_TRY(add_rmsnorm_launch(s->ph, nullptr, 0, H, (const unsigned short *)e->norm_w, s->px, H, H, c.rms_eps, m, st));
         if (all_logits) {                       // every row, straight into the caller's matrix
             if (V % 256 == 0) {
-                if ((rc = gemm(s->px, e->lm_head, V, H, all_logits, V, LLM_GEMM_BF16))) return rc;
+                if ((rc = prefill_gemm(s, s->px, e->lm_head, m, V, H, all_logits, V, LLM_GEMM_BF16, st, false))) return rc;   // logits: bf16 activations always
             } else {                            // vocabularies that are not whole 256-column tiles: 16 rows at a time through the GEMV
                 for (int r0 = 0; r0 < m; r0 += 16) {
                     GemvArgs a = gemv_args(e->lm_head, s->px + (size_t)r0 * H, H, std::min(16, m - r0));
@@ -1279,6 +1302,42 @@ int vlo_test_gemv_fp8(const void *x_dev, const void *Wq_dev, const float *scale_
     hipLaunchKernelGGL(sum_partials_kernel, dim3((n * NT * 16 + 255) / 256), dim3(256), 0, st, P, plan.ksplit, NT * 16, Y, n, NT * 16);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy2DAsync(y_dev, (size_t)N * 4, Y, (size_t)NT * 16 * 4, (size_t)N * 4, n, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return VLO_OK;
+}
+
+int vlo_test_gemm_fp8(const void *x_dev, const void *Wq_dev, const float *scale_dev, float *y_dev, void *xq_dev, float *xscale_dev, int M, int N, int K,
+                      int iters, double *avg_us, void *stream) {
+    if (!x_dev || !Wq_dev || !scale_dev || !y_dev || M <= 0 || !llm_gemm_fp8_ok(N, K)) return fail(VLO_E_INVALID, "bad test_gemm_fp8 arguments (N, K multiples of 256)");
+    hipStream_t st = (hipStream_t)stream;
+    const int NT = N / 16;
+    const size_t RX = (size_t)((M + 255) / 256) * 256 + 256;
+    ScratchBufs sc;
+    void *Wp = nullptr, *xq = nullptr;
+    float *sp = nullptr, *xs = nullptr;
+    HIP_TRY(sc.alloc(&Wp, (size_t)N * K));
+    HIP_TRY(sc.alloc(&xq, RX * K));
+    HIP_TRY(sc.alloc((void **)&sp, (size_t)N * 4));
+    HIP_TRY(sc.alloc((void **)&xs, RX * 4));
+    HIP_TRY(hipMemsetAsync(xq, 0, RX * K, st));
+    HIP_TRY(hipMemsetAsync(xs, 0, RX * 4, st));
+    HIP_TRY(pack_weight_fp8_launch(Wq_dev, scale_dev, Wp, sp, N, K, K, NT, 1, 0, -1, st));
+    HIP_TRY(quantize_rows_fp8_launch((const unsigned short *)x_dev, M, K, xq, xs, st));
+    HIP_TRY(llm_gemm_fp8_launch(xq, xs, Wp, sp, M, N, K, y_dev, N, LLM_GEMM_F32, st));
+    if (xq_dev) HIP_TRY(hipMemcpyAsync(xq_dev, xq, (size_t)M * K, hipMemcpyDeviceToDevice, st));
+    if (xscale_dev) HIP_TRY(hipMemcpyAsync(xscale_dev, xs, (size_t)M * 4, hipMemcpyDeviceToDevice, st));
+    if (iters > 0 && avg_us) {                   // the GEMM alone, back to back (tools/probe_prefill.py --gemm)
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, st));
+        for (int i = 0; i < iters; ++i) HIP_TRY(llm_gemm_fp8_launch(xq, xs, Wp, sp, M, N, K, y_dev, N, LLM_GEMM_F32, st));
+        HIP_TRY(hipEventRecord(e1, st));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        *avg_us = (double)ms * 1e3 / iters;
+        hipEventDestroy(e0); hipEventDestroy(e1);
+    }
     HIP_TRY(hipStreamSynchronize(st));
     return VLO_OK;
 }

@@ -34,6 +34,19 @@ hipError_t llm_gemm_launch(const unsigned short *X, const void *Wp, int M, int N
                            const float *wscale = nullptr);
 // fp8 e4m3 image Wp8[tile][kf2][lane] (gemv.hip) -> bf16 image Wp[tile][kf][lane], exact (every e4m3 value is a bf16 value); NT tiles of K
 hipError_t expand_fp8_image_launch(const void *Wp8, void *Wp_bf16, int NT, int K, hipStream_t st);
+// ---- native fp8 MFMA for the prefill GEMMs of an fp8 engine (vlo_config.prefill_act_dtype = 1; BASELINE.json configs[4] "fp8 MFMA weights") ----
+// W8A8: the X operand of a projection is quantised per ROW to OCP e4m3 — scale[m] = max|X[m]| * (1 / 448) (1 for a zero row), code =
+// e4m3_rne(clamp(X[m][k] / scale[m], -448, 448)), the weights' rule — and the GEMM multiplies e4m3 by e4m3 on v_mfma_f32_16x16x128_f8f6f4
+// (fp32 accumulation, 2 x the bf16 MFMA rate), W read from the fp8 GEMV image AS STORED (no expansion pass, no bf16 scratch);
+// out[m][n] = (sum_k xq wq) * wscale[n] * scale[m], then the kind's epilogue with its usual rounding points.
+// Xq layout: [M][K] bytes, row-major, the k's of every 64-k group in the order the image holds them: byte p of group g is
+// k = 64 g + (p % 16 / 8) * 32 + (p / 16) * 8 + p % 8 (vlo_fp8_row_pos below is the inverse).  Xq and scale must stay readable 256 rows past M.
+// N % 256 == 0, K % 256 == 0 (llm_gemm_fp8_ok); kinds as llm_gemm_launch.
+static inline int vlo_fp8_row_pos(int k) { const int g = k >> 6, r = k & 63; return g * 64 + ((r & 31) >> 3) * 16 + (r >> 5) * 8 + (r & 7); }
+hipError_t quantize_rows_fp8_launch(const unsigned short *X, int M, int K, void *Xq, float *scale, hipStream_t st);
+bool llm_gemm_fp8_ok(int N, int K);
+hipError_t llm_gemm_fp8_launch(const void *Xq, const float *xscale, const void *Wp8, const float *wscale, int M, int N, int K, void *out, int ldo,
+                               int kind, hipStream_t st);
 // qkv bf16 [M][(nh + 2 nkv) hd] (projection outputs) -> RoPE (HF rounding points) -> q bf16 [M][nh hd], K / V^T appended to the paged pool
 // at positions pos0 .. pos0 + M - 1
 hipError_t rope_kv_append_launch(const unsigned short *qkv, int M, int num_heads, const unsigned short *cos_tab, const unsigned short *sin_tab,

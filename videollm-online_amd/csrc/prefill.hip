@@ -341,6 +341,80 @@ hipError_t llm_gemm_launch(const unsigned short *X, const void *Wp, int M, int N
     return hipErrorInvalidValue;
 }
 
+// ---- native fp8 MFMA (prefill.h): X rows quantised to e4m3 with one fp32 scale each, W = the fp8 GEMV image as stored ------------------------
+// One workgroup per row, two passes over the row (the second one hits L2): max |x|, then 16-byte chunks of codes.  Output chunk j of a row holds
+// the k's of the image's register (kf2 = j / 4, quad = j % 4): 64 kf2 + 8 quad + [0, 8) and 64 kf2 + 32 + 8 quad + [0, 8) — two 16-byte loads in,
+// one 16-byte store out.  scale = max|x| * (1 / 448) (1 for an all-zero row), code = e4m3_rne(clamp(x / scale, -448, 448)): the weights' rule
+// (checkpoint.quantize_fp8_per_channel) applied to an activation row.
+__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const bf16_t *__restrict__ X, int K, uint4 *__restrict__ Xq, float *__restrict__ scale) {
+    __shared__ float sm[16];
+    const size_t row = blockIdx.x;
+    const uint4 *src = reinterpret_cast<const uint4 *>(X + row * (size_t)K);
+    const int nchunk = K >> 4;                                   // 16-byte chunks of codes = 16 k's each
+    unsigned m = 0;                                              // max of the magnitudes' bit patterns (monotonic for finite bf16)
+    for (int j = threadIdx.x; j < (K >> 3); j += blockDim.x) {
+        const uint4 v = src[j];
+        const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m = max(m, max(w4[i] & 0x7fffu, (w4[i] >> 16) & 0x7fffu));
+    }
+    const float amax = block_max(__uint_as_float(m << 16), sm);
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    if (threadIdx.x == 0) scale[row] = sc;
+    uint4 *dst = Xq + row * (size_t)nchunk;
+    auto code2 = [&](unsigned pair, unsigned old, bool hi) {     // two bf16 -> two e4m3 bytes into the low / high half of `old`
+        const float a = fminf(fmaxf(__uint_as_float(pair << 16) / sc, -448.f), 448.f);
+        const float b = fminf(fmaxf(__uint_as_float(pair & 0xffff0000u) / sc, -448.f), 448.f);
+        return hi ? (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, true) : (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, false);
+    };
+    for (int j = threadIdx.x; j < nchunk; j += blockDim.x) {
+        const int kf2 = j >> 2, quad = j & 3;
+        const uint4 lo = src[kf2 * 8 + quad], hi = src[kf2 * 8 + 4 + quad];
+        uint4 o;
+        o.x = code2(lo.y, code2(lo.x, 0u, false), true);
+        o.y = code2(lo.w, code2(lo.z, 0u, false), true);
+        o.z = code2(hi.y, code2(hi.x, 0u, false), true);
+        o.w = code2(hi.w, code2(hi.z, 0u, false), true);
+        dst[j] = o;
+    }
+}
+hipError_t quantize_rows_fp8_launch(const unsigned short *X, int M, int K, void *Xq, float *scale, hipStream_t st) {
+    if (!X || !Xq || !scale || M <= 0 || K <= 0 || (K & 63)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3(M), dim3(256), 0, st, X, K, (uint4 *)Xq, scale);
+    return hipGetLastError();
+}
+
+bool llm_gemm_fp8_ok(int N, int K) { return N > 0 && !(N & 255) && K >= 256 && !(K & 255); }
+
+hipError_t llm_gemm_fp8_launch(const void *Xq, const float *xscale, const void *Wp8, const float *wscale, int M, int N, int K, void *out, int ldo,
+                               int kind, hipStream_t st) {
+    if (!Xq || !xscale || !Wp8 || !wscale || !out || M <= 0 || !llm_gemm_fp8_ok(N, K)) return hipErrorInvalidValue;
+    GemmArgs a{};
+    // the kernel's "element" is a pair of bytes (vit_gemm.inc, F8): K / 2 elements per row, K tiles of 64 elements = 128 k's
+    a.X = (const f16_t *)Xq; a.W = (const f16_t *)Wp8; a.M = M; a.N = N; a.K = K / 2; a.ldx = K / 2; a.ldo = ldo;
+    a.outb = (unsigned short *)out; a.out32 = (float *)out; a.xpad = 1;
+    a.bias = wscale; a.rscale = xscale;
+    const int tx = N / 256;
+    const int t256 = ((M + 255) / 256) * tx;
+    const int bm = t256 >= 200 ? 256 : 128;
+    int cb = 1;
+    while (cb < 8 && tx % (cb * 2) == 0 && (size_t)(N / cb) * K > ((size_t)9 << 18)) cb *= 2;
+    a.cb = cb;
+    const int tiles = ((M + bm - 1) / bm) * tx, grid = std::min(tiles, vit_num_cus());
+#define VLO_LLM8_GO(EP_)                                                                                                  \
+    do {                                                                                                                  \
+        if (bm == 256) hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP_, 1, 0, 1>), dim3(grid), dim3(512), 0, st, a);      \
+        else hipLaunchKernelGGL((vit_gemm_pp_kernel<128, EP_, 1, 0, 1>), dim3(grid), dim3(512), 0, st, a);                \
+        return hipGetLastError();                                                                                         \
+    } while (0)
+    if (kind == LLM_GEMM_BF16) VLO_LLM8_GO(EP_LLM_BF16);
+    if (kind == LLM_GEMM_SWIGLU) VLO_LLM8_GO(EP_LLM_SWIGLU);
+    if (kind == LLM_GEMM_RESID) VLO_LLM8_GO(EP_LLM_RESID);
+    if (kind == LLM_GEMM_F32) VLO_LLM8_GO(EP_LLM_F32);
+#undef VLO_LLM8_GO
+    return hipErrorInvalidValue;
+}
+
 // one thread per (token, head, 4 rotary columns): the GEMV path's EPI_ROPE on a [M][(nh + 2 nkv) hd] matrix
 __global__ __launch_bounds__(256) void rope_kv_append_kernel(const bf16_t *__restrict__ qkv, int M, int nh, const bf16_t *__restrict__ cos_tab,
                                                              const bf16_t *__restrict__ sin_tab, KvGeom kv, int layer, long long pos0,

@@ -36,6 +36,9 @@ class EngineConfig:
     # (BASELINE.json configs[4]; include/vlo.h vlo_config.weight_dtype).  bf16 weights handed to an fp8 engine are quantised
     # on the way in (checkpoint.quantize_fp8_per_channel)
     weight_dtype: str = "bf16"
+    # fp8 engines only: "fp8" = the long-input (prefill) projections quantise their X rows to e4m3 (one fp32 scale per row) and run on the native
+    # fp8 MFMA (include/vlo.h vlo_config.prefill_act_dtype); "bf16" = expand the weight image per GEMM, bf16 MFMA.  The live step is bf16 either way.
+    prefill_act_dtype: str = "bf16"
 
     def to_c(self) -> _C.VloConfig:
         c = _C.VloConfig()
@@ -50,6 +53,9 @@ class EngineConfig:
         if self.weight_dtype not in ("bf16", "fp8"):
             raise ValueError("weight_dtype must be 'bf16' or 'fp8'")
         c.weight_dtype = 1 if self.weight_dtype == "fp8" else 0
+        if self.prefill_act_dtype not in ("bf16", "fp8") or (self.prefill_act_dtype == "fp8" and self.weight_dtype != "fp8"):
+            raise ValueError("prefill_act_dtype must be 'bf16', or 'fp8' on an engine with weight_dtype='fp8'")
+        c.prefill_act_dtype = 1 if self.prefill_act_dtype == "fp8" else 0
         if self.vit:
             v = self.vit
             c.has_vit = 1
@@ -357,6 +363,28 @@ def test_gemv_fp8(x: torch.Tensor, Wq: torch.Tensor, scale: torch.Tensor) -> tor
     y = torch.empty(x.shape[0], Wq.shape[0], dtype=torch.float32, device=x.device)
     _C.check(_C.lib().vlo_test_gemv_fp8(_ptr(x), _ptr(Wq), _ptr(scale), _ptr(y), x.shape[0], Wq.shape[0], Wq.shape[1], _stream_handle()))
     return y
+
+
+def fp8_row_order(K: int) -> torch.Tensor:
+    """pos[k] = byte of a quantised activation row that holds column k (csrc/prefill.h::vlo_fp8_row_pos: inside every 64 k's the order of
+    the fp8 weight image's registers)"""
+    k = torch.arange(K)
+    r = k & 63
+    return (k >> 6) * 64 + ((r & 31) >> 3) * 16 + (r >> 5) * 8 + (r & 7)
+
+
+def test_gemm_fp8(x: torch.Tensor, Wq: torch.Tensor, scale: torch.Tensor, iters: int = 0):
+    """The long-input W8A8 GEMM (prefill_act_dtype='fp8'): x bf16 [M,K] -> (y f32 [M,N], codes e4m3 [M,K] in column order, row scales f32 [M]
+    [, microseconds per GEMM when iters > 0]) — unit tests and tools/probe_prefill.py."""
+    x, Wq, scale = x.contiguous(), Wq.contiguous().view(torch.uint8), scale.float().contiguous()
+    M, K, N = x.shape[0], x.shape[1], Wq.shape[0]
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    xq = torch.empty(M, K, dtype=torch.uint8, device=x.device)
+    xs = torch.empty(M, dtype=torch.float32, device=x.device)
+    us = C.c_double(0.0)
+    _C.check(_C.lib().vlo_test_gemm_fp8(_ptr(x), _ptr(Wq), _ptr(scale), _ptr(y), _ptr(xq), _ptr(xs), M, N, K, iters, C.byref(us), _stream_handle()))
+    codes = xq[:, fp8_row_order(K).to(x.device)].view(torch.float8_e4m3fn)
+    return (y, codes, xs, us.value) if iters > 0 else (y, codes, xs)
 
 
 class TpSession:
