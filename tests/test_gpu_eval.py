@@ -140,6 +140,30 @@ def test_prefill_attention_shortcuts_are_bit_identical(monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("spec_name,n", [("toy128", 1500), ("llama-3-8b-2l", 1300)])
+def test_prefill_attention_variants_are_bit_identical(monkeypatch, spec_name, n):
+    """The prefill attention that ships — a two-group ping-pong (attn_prefill_pp_body.inc: softmax of tile t on one wave of a SIMD while its partner
+    runs P.V of tile t and Q.K of tile t + 1, fragment reads batched ahead of the MFMAs) — against the lock-step kernel (VLO_ATTN_PF=0): same tiles,
+    same operations per element — logits and appended K bit for bit, ragged last block included."""
+    spec = O.LLM_SPECS[spec_name]
+    w = O.init_llm_weights(spec, seed=3)
+    eng = _engine(spec, w, kv_pool_tokens=4096)
+    x = (torch.randn(n, spec.hidden_size, generator=torch.Generator().manual_seed(5)) * 0.05).bfloat16().cuda()
+    outs = []
+    for variant in ("0", "1"):
+        monkeypatch.setenv("VLO_ATTN_PF", variant)
+        a = eng.new_session()
+        _, lg = eng.llm_step(a, x[:n - 401], want_last=False, want_all=True)          # a block from an empty cache ...
+        _, lg2 = eng.llm_step(a, x[n - 401:], want_last=False, want_all=True)         # ... and a ragged one over a prefix (pos0 > 0)
+        torch.cuda.synchronize()
+        outs.append((lg.clone(), lg2.clone(), a.read_kv(spec.num_layers - 1, 0, 0, 0, n).clone()))
+        a.close()
+    for v in (1,):
+        for i in range(3):
+            assert torch.equal(outs[0][i], outs[v][i]), f"VLO_ATTN_PF={v} differs from the lock-step kernel (output {i})"
+    eng.close()
+
+
 def test_full_logits_forward_matches_oracle():
     """model(input_ids=, frames=) returns every row (the evaluation path), 3-way checked against fp32 gold."""
     from videollm_online_amd.modeling_live import LiveModel

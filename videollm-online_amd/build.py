@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvlo.so")
 SOURCES = ["gemv.hip", "prefill.hip", "llm_ops.hip", "vit.hip", "ingest.hip", "engine.hip", "tp.hip"]
-HEADERS = ["common.cuh", "glds_asm.cuh", "vit_gemm.inc", "vit_attn.inc", "vit_ln.inc", "vit_tall.inc", "gemv.h", "prefill.h", "llm_ops.h", "vit.h", "engine.h", "tp_p2p.cuh", "gemv_body.inc", "gemv_head.inc", "gemv_epi.inc", "attn_body.inc", "attn_prefill_body.inc", "rmsnorm_body.inc", os.path.join("..", "..", "include", "vlo.h")]
+HEADERS = ["common.cuh", "glds_asm.cuh", "vit_gemm.inc", "vit_attn.inc", "vit_ln.inc", "vit_tall.inc", "gemv.h", "prefill.h", "llm_ops.h", "vit.h", "engine.h", "tp_p2p.cuh", "gemv_body.inc", "gemv_head.inc", "gemv_epi.inc", "attn_body.inc", "attn_prefill_body.inc", "attn_prefill_pp_body.inc", "rmsnorm_body.inc", os.path.join("..", "..", "include", "vlo.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 

@@ -34,6 +34,11 @@ struct LayerWeights {
 
 struct VitState;
 
+// Prefill workspaces (~275 MB per set at the 8B shape, + the fp8 scratches, + 64 MiB of partials under TP) are pooled per engine: a destroyed
+// session hands its set back, the next session that needs one takes it.  The pool keeps at most VLO_PREFILL_POOL_MAX idle sets — more are freed
+// on release — so the resident cost is bounded by (live sessions that ran a prefill) + 2 sets.  A pooled set's spare rows hold whatever the
+// last block left there: finite or not, they are computed and dropped (no output row depends on another row's X).
+#define VLO_PREFILL_POOL_MAX 2
 struct PrefillWs {
     unsigned short *ph = nullptr, *px = nullptr, *pqkv = nullptr, *pq = nullptr, *pact = nullptr;
     void *wexp = nullptr;

@@ -796,8 +796,13 @@ static void release_prefill_ws(vlo_session *s) {
         PrefillWs w;
         w.ph = s->ph; w.px = s->px; w.pqkv = s->pqkv; w.pq = s->pq; w.pact = s->pact;
         w.wexp = s->pf_wexp; w.wexp_bytes = s->pf_wexp_bytes; w.partial = s->ppartial; w.xq = s->pxq;
-        std::lock_guard<std::mutex> g(e->pool_mu);
-        e->prefill_free.push_back(w);
+        std::unique_lock<std::mutex> g(e->pool_mu);
+        if (e->prefill_free.size() < VLO_PREFILL_POOL_MAX) {
+            e->prefill_free.push_back(w);
+        } else {                                // a burst of long-prompt sessions does not pin its peak for the engine's lifetime (engine.h)
+            g.unlock();
+            for (void *p : {(void *)w.ph, (void *)w.px, (void *)w.pqkv, (void *)w.pq, (void *)w.pact, w.wexp, (void *)w.partial, w.xq}) if (p) hipFree(p);
+        }
     }
     s->ph = s->px = s->pqkv = s->pq = s->pact = nullptr;
     s->pf_wexp = nullptr; s->pf_wexp_bytes = 0; s->ppartial = nullptr; s->pxq = nullptr;

@@ -254,6 +254,9 @@ hipError_t gemv_launch(GemvArgs a, const GemvPlan &p, int xsrc, int epi, hipStre
     size_t lds = 0;
     const hipError_t pe = gemv_prepare(&a, p, epi, &gx, &gy, &lds);
     if (pe != hipSuccess) return pe;
+    // the kernel's first weight-fragment and activation-row loads are UNCONDITIONAL (gemv_head.inc, gemv_body.inc): every block must own at
+    // least one group and there must be a first row to read — an oversized grid or an empty input would read past the image instead of idling
+    if (a.n_rows < 1 || a.n_rows > 16 || gx < 1 || gx > groups_of(a, p, epi)) return hipErrorInvalidValue;
     dim3 grid(gx, gy);
 #define VLO_CASE(NW_, KF_) \
     if (p.NW == NW_ && p.KF == KF_) return launch_variant<KF_, NW_>(a, xsrc, epi, grid, lds, st);

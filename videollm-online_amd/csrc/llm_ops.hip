@@ -350,12 +350,21 @@ VLO_DEV float quad_lanes_maxf(float x) {
 // profiles/r5_prefill_attention_one_column_tile.txt.  The two-tile kernel is gone.)
 template <int HD, int G, int NS>
 __global__ __launch_bounds__(512, 4) void attn_prefill_kernel(const bf16_t *__restrict__ q, KvGeom kv, int layer, int nh, int64_t pos0, int n, float scale,
-                                                              bf16_t *__restrict__ out, int noskip) {
+                                                              bf16_t *__restrict__ out, int noskip, int nkv, int nqb) {
 #define VLO_PF_NCT 1
 #include "attn_prefill_body.inc"
 #undef VLO_PF_NCT
 }
 
+// The same tiles as a two-group ping-pong with batched fragment reads (attn_prefill_pp_body.inc) — the kernel that ships; the lock-step kernel
+// above stays as the reference the variants test compares it with, bit for bit (VLO_ATTN_PF=0).
+template <int HD, int G, int NS>
+__global__ __launch_bounds__(512, 4) void attn_prefill_pp_kernel(const bf16_t *__restrict__ q, KvGeom kv, int layer, int nh, int64_t pos0, int n, float scale,
+                                                                 bf16_t *__restrict__ out, int noskip, int nkv, int nqb) {
+#define VLO_PF_NCT 1
+#include "attn_prefill_pp_body.inc"
+#undef VLO_PF_NCT
+}
 // the (head dim, GQA group) pairs attn_prefill_kernel is instantiated for — attention_prefill_launch returns hipErrorNotSupported for any other; a caller
 // WITHOUT a fallback (tp.hip::tp_prefill) asks first and keeps the 16-row step instead
 bool attention_prefill_supported(int head_dim, int gqa_group) {
@@ -369,10 +378,17 @@ hipError_t attention_prefill_launch(const unsigned short *q, KvGeom kv, int laye
     const float scale = 1.0f / sqrtf((float)hd);
     const char *ns = getenv("VLO_ATTN_NOSKIP");                            // read per call: the tests flip it between two passes over the same input
     const int noskip = ns && atoi(ns) != 0;
+    const char *pv = getenv("VLO_ATTN_PF");                                // tests: 0 = the lock-step reference kernel
+    const int variant = pv ? atoi(pv) : 1;
 #define VLO_ATTN_PF(HD_, G_)                                                                                                          \
     do {                                                                                                                              \
         constexpr int QB_ = 128 / G_;                                                                                                 \
-        hipLaunchKernelGGL((attn_prefill_kernel<HD_, G_, 4>), dim3((n + QB_ - 1) / QB_, nkv), dim3(512), 0, st, q, kv, layer, num_heads, pos0, n, scale, out, noskip); \
+        const int nqb = (n + QB_ - 1) / QB_;                                                                                          \
+        const dim3 grid((unsigned)((nqb * nkv + 7) & ~7));               /* 1-D: the kernel maps workgroups to (kv head, query block) per XCD */ \
+        if (variant != 0)                                                                                                             \
+            hipLaunchKernelGGL((attn_prefill_pp_kernel<HD_, G_, 4>), grid, dim3(512), 0, st, q, kv, layer, num_heads, pos0, n, scale, out, noskip, nkv, nqb); \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((attn_prefill_kernel<HD_, G_, 4>), grid, dim3(512), 0, st, q, kv, layer, num_heads, pos0, n, scale, out, noskip, nkv, nqb); \
         return hipGetLastError();                                                                                                     \
     } while (0)
     if (hd == 128 && G == 4) VLO_ATTN_PF(128, 4);
