@@ -58,7 +58,7 @@ def build(force=False, sanitize=None):
                      r"\1 = emul_mfma_fp8_16x16x128(\2, \3, \1);", src)
         src = re.sub(r'asm volatile\("s_nop[^"]*"(?:\s*:::\s*"memory")?\);', ";", src)
         src = re.sub(r'asm volatile\(""\s*:::\s*"memory"\);', ";", src)                  # compiler-only memory barrier
-        src = re.sub(r'asm(?: volatile)?\(""\s*:\s*"\+v"\(\w+\)\);', ";", src)      # optimisation barrier on a VGPR value
+        src = re.sub(r'asm(?: volatile)?\(""\s*:\s*"\+v"\([\w\[\]]+\)\);', ";", src)      # optimisation barrier on a VGPR value
         src = re.sub(r'asm\("s_nop 7\\n\\ts_nop 3\\n\\tv_max3_f32[^;]*;', "r = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), fmaxf(fmaxf(a4, a5), fmaxf(a6, a7)));", src)
         src = re.sub(r'asm\("v_max_f32 %0, %1, %2"\s*:\s*"=v"\((\w+)\)\s*:\s*"v"\((\w+)\),\s*"v"\((\w+)\)\);', r"\1 = fmaxf(\2, \3);", src)
         return src

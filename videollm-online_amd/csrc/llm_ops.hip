@@ -349,7 +349,7 @@ VLO_DEV float quad_lanes_maxf(float x) {
 // waves per SIMD cannot hide.  Measured on the MI355X, bit-identical outputs: 13 312 tokens 242.2 -> 232.4 ms, 2 048 tokens 33.7 -> 33.9 ms;
 // profiles/r5_prefill_attention_one_column_tile.txt.  The two-tile kernel is gone.)
 template <int HD, int G, int NS>
-__global__ __launch_bounds__(512, 4) void attn_prefill_kernel(const bf16_t *__restrict__ q, KvGeom kv, int layer, int nh, int64_t pos0, int n, float scale,
+__global__ __launch_bounds__(512, 4) void attn_prefill_kernel(const bf16_t *__restrict__ q, KvGeom kv, int layer, int nh, int64_t pos0, int n, float scale_l2e,
                                                               bf16_t *__restrict__ out, int noskip, int nkv, int nqb) {
 #define VLO_PF_NCT 1
 #include "attn_prefill_body.inc"
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(512, 4) void attn_prefill_kernel(const bf16_t *__re
 // The same tiles as a two-group ping-pong with batched fragment reads (attn_prefill_pp_body.inc) — the kernel that ships; the lock-step kernel
 // above stays as the reference the variants test compares it with, bit for bit (VLO_ATTN_PF=0).
 template <int HD, int G, int NS>
-__global__ __launch_bounds__(512, 4) void attn_prefill_pp_kernel(const bf16_t *__restrict__ q, KvGeom kv, int layer, int nh, int64_t pos0, int n, float scale,
+__global__ __launch_bounds__(512, 4) void attn_prefill_pp_kernel(const bf16_t *__restrict__ q, KvGeom kv, int layer, int nh, int64_t pos0, int n, float scale_l2e,
                                                                  bf16_t *__restrict__ out, int noskip, int nkv, int nqb) {
 #define VLO_PF_NCT 1
 #include "attn_prefill_pp_body.inc"
@@ -375,7 +375,7 @@ bool attention_prefill_supported(int head_dim, int gqa_group) {
 hipError_t attention_prefill_launch(const unsigned short *q, KvGeom kv, int layer, int num_heads, int64_t pos0, int n, unsigned short *out, hipStream_t st) {
     const int nkv = kv.num_kv_heads, hd = kv.head_dim, G = num_heads / nkv;
     if (n <= 0 || nkv * G != num_heads) return hipErrorInvalidValue;
-    const float scale = 1.0f / sqrtf((float)hd);
+    const float scale = (1.0f / sqrtf((float)hd)) * 1.4426950408889634f;   // log2(e) / sqrt(hd): the kernels' softmax runs on exp2 (attn_prefill_pp_body.inc)
     const char *ns = getenv("VLO_ATTN_NOSKIP");                            // read per call: the tests flip it between two passes over the same input
     const int noskip = ns && atoi(ns) != 0;
     const char *pv = getenv("VLO_ATTN_PF");                                // tests: 0 = the lock-step reference kernel
