@@ -75,6 +75,9 @@ def reduce_elapsed_max(dist, elapsed, device="cuda"):
     return float(t.item())
 
 
+PREFILL_PROBE_TOKENS = 4096
+
+
 def rocprof_cross_check(bytes_per_launch, profiles_dir=None):
     """The dominant kernel's kernel-only average from the builder's committed `rocprofv3 --kernel-trace --stats` run of the bench command
     (the newest profiles/rN_kernel_stats_bench200*.csv; Llama-3-8B, bf16: gemv16_kernel<16, 8, XSRC_NORM, EPI_SWIGLU, bf16>), as extra keys
@@ -340,6 +343,7 @@ def main():
                          "demo/inference.py:105-106).  56 frames = 32256 token rows = 126 row tiles of 256: every GEMM of the tower is a whole "
                          "number of 256-CU rounds within 2 %% (504 / 1512 / 2016 tiles); 28 frames give 252 / 756 / 1008")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefill-probe", action="store_true", help="skip the 4096-token teacher-forced block timed after the stream (`prefill`)")
     ap.add_argument("--no-live-feed", action="store_true", help="skip the two no-look-ahead re-runs of the timed frames (`live_feed`)")
     ap.add_argument("--cpu-sample-frames", type=int, default=20)
     ap.add_argument("--cpu-budget-s", type=float, default=12.0, help="time budget of the CPU baseline's from-the-start sample (its frame loop stops once it is spent)")
@@ -409,10 +413,11 @@ def main():
     preroll = total - K                       # frames streamed un-timed before the K timed ones (0 when --steps covers the stream)
     n_frames = max(total, Wm) + 2
     # KV: start prompt + 11 tokens per frame + responses (query + "]\nAssistant:" + 16 tokens, every 10th frame)
-    kv_tokens = 64 + 11 * n_frames + (n_frames // 10 + 2) * 24 + 4096
+    kv_tokens = 64 + 11 * n_frames + (n_frames // 10 + 2) * 24 + 4096 + PREFILL_PROBE_TOKENS + 512
     vit_shape = VIT_SHAPES[args.vit]
     vit_gflop = VIT_GFLOP_PER_FRAME if args.vit == "siglip-l16-384" else vit_gflop_per_frame(vit_shape, shape["hidden_size"])
-    cfg = EngineConfig(**shape, vision_hidden_size=vit_shape["hidden_size"], vit=vit_shape, kv_pool_tokens=kv_tokens, weight_dtype=args.weight_dtype)
+    cfg = EngineConfig(**shape, vision_hidden_size=vit_shape["hidden_size"], vit=vit_shape, kv_pool_tokens=kv_tokens, weight_dtype=args.weight_dtype,
+                       prefill_act_dtype="fp8" if args.weight_dtype == "fp8" else "bf16")       # (only the `prefill` probe below takes that path)
     log(f"building engine ({args.model} + {args.vit}), kv pool {kv_tokens} tokens")
     tp = args.tp and world > 1
     if tp:
@@ -562,6 +567,28 @@ def main():
                              f"token-reading greedy loop (models/modeling_live.py:173-182: async read of every token + speculative next step) instead of the "
                              f"forced-length loop that never looks at a token")
         live_feed["frames_per_s"] = live_feed["no_lookahead"]["frames_per_s"]
+    # the long-input path (stream_evaluate's whole-dialogue forward, a long first prompt): ONE 4096-token teacher-forced block through
+    # vlo_llm_step on a session of its own (prefill GEMMs + flash-style attention) — an extra key, outside the timed region
+    prefill = None
+    if not tp and rank == 0 and not args.no_prefill_probe:
+        try:
+            ps = eng.new_session()
+            px = (torch.randn(PREFILL_PROBE_TOKENS, shape["hidden_size"], device="cuda") * 0.5).bfloat16()
+            eng.llm_step(ps, px[:512])                      # allocates the prefill workspaces
+            ps.reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.llm_step(ps, px)
+            torch.cuda.synchronize()
+            dtp = time.perf_counter() - t0
+            ps.close()
+            prefill = {"tokens": PREFILL_PROBE_TOKENS, "ms": round(dtp * 1e3, 2), "tokens_per_s": round(PREFILL_PROBE_TOKENS / dtp, 1),
+                       "arithmetic": ("W8A8: e4m3 weights x per-row e4m3 activation codes on v_mfma_f32_16x16x128_f8f6f4 (prefill_act_dtype=fp8), lm_head bf16"
+                                      if args.weight_dtype == "fp8" else "bf16 MFMA, fp32 accumulation"),
+                       "note": "one block from an empty cache, last-row logits only; 13 312-token passes and the kernel-level A/B: profiles/r6_prefill_*.txt"}
+            log(f"prefill probe: {PREFILL_PROBE_TOKENS} tokens in {dtp * 1e3:.1f} ms = {PREFILL_PROBE_TOKENS / dtp:.0f} tok/s")
+        except Exception as ex:
+            prefill = {"error": repr(ex)}
     # tensor-parallel runs: latency of ONE exchange (all-reduce of [n, H] fp32 + residual add + RMSNorm) at the frame-step and the
     # decode-step size, every rank in lock-step — the number the xGMI all-reduce discussion of SURVEY.md §8e is about
     tp_exchange_us = None
@@ -622,7 +649,7 @@ def main():
             "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "strong" if tp else "weak",
             "vs_baseline": None,
             "dtype": "bf16" if args.weight_dtype == "bf16" else "bf16 activations / KV / accumulate-in-fp32, fp8 e4m3 weights (per-output-channel scales) expanded to bf16 in registers for the live step's bf16 MFMA; "
-                     "native fp8 MFMA (W8A8) only on long-input prefill GEMMs with prefill_act_dtype=fp8, which this stream does not contain",
+                     "native fp8 MFMA (W8A8) only on long-input prefill GEMMs (prefill_act_dtype=fp8): the `prefill` key, not this stream",
             "vit_dtype": "fp16 operands / fp32 accumulate + fp32 residual stream (the reference's GPU autocast, models/vision_live.py:13)",
             "data": "synthetic",
             "p50_frame_latency_ms": round(statistics.median(costs) * 1e3, 4),
@@ -661,6 +688,7 @@ def main():
                                    "note": "frame 0 of the stream, host wall time: its one-frame encode, the first Llama step (start prompt + 10 frame tokens "
                                            "through the 64-token block path), the t = 0 query and its 16-token response"}} if pre is not None and pre[1] else {}),
             **({"live_feed": live_feed} if live_feed else {}),
+            **({"prefill": prefill} if prefill else {}),
             "stream_hbm_roofline": {"algorithmic_llm_bytes": alg_bytes, "frac_of_hbm_peak": round(alg_bytes / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
             "roofline": {"bound": "hbm", "kernel": "gemv16_kernel<KF,EPI_SWIGLU> (gate/up projection + SwiGLU)" + (", fp8 weight image" if args.weight_dtype == "fp8" else ""),
                          "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
