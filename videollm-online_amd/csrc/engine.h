@@ -21,6 +21,8 @@ struct RawTensor {
 struct PackedLinear {
     void *Wp = nullptr;
     int N = 0, K = 0, NT = 0;
+    int NT_gemm = 0;          // tiles the image is ALLOCATED (and zero-filled) for: NT rounded up to 16 where a GEMM reads whole 256-column tiles of a
+                              // width that is not one (a TP rank's lm_head shard: 16 032 -> 16 128 columns); 0 = NT
     int wq = 0;               // 1: Wp is the fp8 e4m3 image (gemv.hip) and wscale holds the per-output-channel scales
     float *wscale = nullptr;  // fp32 [NT * 16], packed row order
     GemvPlan plan{};
@@ -124,6 +126,7 @@ struct vlo_session {
     // prefill_act_dtype = 1: the e4m3 codes of ONE projection's X operand ([VLO_PREFILL_TOKENS + 256][widest layer K] bytes) followed by its
     // row scales ([VLO_PREFILL_TOKENS + 256] floats), rewritten before each GEMM (prefill.h::quantize_rows_fp8_launch)
     void *pxq = nullptr;
+    unsigned short *plogits = nullptr;           // TP prefill, every row's logits: this rank's PADDED vocabulary shard of one row chunk, bf16 [VLO_TP_LOGIT_ROWS][NT_gemm * 16]
     float *ppartial = nullptr;                   // TP prefill: this rank's o-proj / down-proj partial sums fp32 [VLO_PREFILL_TOKENS][H] awaiting the all-reduce
 };
 

@@ -216,26 +216,29 @@ static int pack_into(vlo_engine *e, const std::string &name, int Nfull, int Kful
     return VLO_OK;
 }
 
-static int make_linear(vlo_engine *e, PackedLinear *pl, int N, int K, bool allow_ksplit, bool fp8 = false) {
+static int make_linear(vlo_engine *e, PackedLinear *pl, int N, int K, bool allow_ksplit, bool fp8 = false, bool pad_for_gemm = false) {
     pl->N = N;
     pl->K = K;
     pl->NT = (N + 15) / 16;
+    pl->NT_gemm = pad_for_gemm ? (pl->NT + 15) & ~15 : pl->NT;
     pl->wq = fp8 ? 1 : 0;
     if (gemv_plan(K, allow_ksplit, &pl->plan)) return fail(VLO_E_UNSUPPORTED, "no GEMV plan for K=" + std::to_string(K));
     if (fp8 && ((pl->plan.KF & 1) || !(pl->plan.NW == 8 || (pl->plan.NW == 4 && pl->plan.KF == 14)) || (K & 63)))      // (4 x 14: K = 1792, gemv.hip)
         return fail(VLO_E_UNSUPPORTED, "fp8 weight image needs an even fragment count per wave (K=" + std::to_string(K) + ")");
     if (gemm64_plan(K, &pl->plan64, fp8))
         return fail(VLO_E_UNSUPPORTED, "no block-GEMM plan for K=" + std::to_string(K));
-    const size_t bytes = (size_t)pl->NT * 16 * K * (fp8 ? 1 : 2);
+    const size_t bytes = (size_t)pl->NT_gemm * 16 * K * (fp8 ? 1 : 2);
     int rc = dev_alloc(&pl->Wp, bytes);
     if (rc) return rc;
     e->owned.push_back(pl->Wp);
     e->weight_bytes += (int64_t)bytes;
+    if (pl->NT_gemm > pl->NT)                    // the pad tiles: zero weights (and zero scales below) = zero logits in columns nobody reads
+        HIP_TRY(hipMemset((char *)pl->Wp + (size_t)pl->NT * 16 * K * (fp8 ? 1 : 2), 0, (size_t)(pl->NT_gemm - pl->NT) * 16 * K * (fp8 ? 1 : 2)));
     if (fp8) {
-        if ((rc = dev_alloc((void **)&pl->wscale, (size_t)pl->NT * 16 * 4))) return rc;
+        if ((rc = dev_alloc((void **)&pl->wscale, (size_t)pl->NT_gemm * 16 * 4))) return rc;
         e->owned.push_back(pl->wscale);
-        HIP_TRY(hipMemset(pl->wscale, 0, (size_t)pl->NT * 16 * 4));
-        e->weight_bytes += (int64_t)pl->NT * 16 * 4;
+        HIP_TRY(hipMemset(pl->wscale, 0, (size_t)pl->NT_gemm * 16 * 4));
+        e->weight_bytes += (int64_t)pl->NT_gemm * 16 * 4;
     }
     return VLO_OK;
 }
@@ -298,7 +301,9 @@ int vlo_engine_finalize(vlo_engine *e) {
         }
     }
     if ((rc = take_vec(e, "model.norm.weight", H, &e->norm_w))) return rc;
-    if ((rc = make_linear(e, &e->lm_head, e->V_l, H, false, f8))) return rc;
+    // a tensor-parallel rank's vocabulary shard is padded to whole 256-column GEMM tiles (Llama-3 at T = 8: 16 032 -> 16 128), so that every row's
+    // logits of a long input take the GEMM path like every other projection (tp.hip::tp_prefill)
+    if ((rc = make_linear(e, &e->lm_head, e->V_l, H, false, f8, e->tp_size > 1))) return rc;
     if ((rc = pack_into(e, "lm_head.weight", c.vocab_size, H, r * e->V_l, e->V_l, 0, H, e->lm_head, 1, 0))) return rc;
     {   // embedding table stays row-major (gather), replicated on every rank
         RawTensor t;
@@ -852,7 +857,8 @@ int prefill_gemm(vlo_session *s, const unsigned short *X, const PackedLinear &pl
     }
     // sized for the largest projection of a layer at the first use (not grown projection by projection); the lm_head image may grow it once more
     const LayerWeights &L0 = e->layers[0];
-    const size_t img = (size_t)pl.NT * 16 * K * 2;
+    const int NTg = std::max(pl.NT, N / 16);                  // (N may be the padded width of a TP lm_head shard: pl.NT_gemm tiles)
+    const size_t img = (size_t)NTg * 16 * K * 2;
     auto bytes = [](const PackedLinear &q) { return (size_t)q.NT * 16 * q.K * 2; };
     const size_t need = std::max({img, bytes(L0.qkv), bytes(L0.o), bytes(L0.gate_up), bytes(L0.down)});
     if (s->pf_wexp_bytes < need) {
@@ -863,7 +869,7 @@ int prefill_gemm(vlo_session *s, const unsigned short *X, const PackedLinear &pl
         if (s->pf_wexp) hipFree(s->pf_wexp);                     // the superseded scratch: nothing reads it after the synchronise above
         s->pf_wexp = p; s->pf_wexp_bytes = need;
     }
-    HIP_TRY(expand_fp8_image_launch(pl.Wp, s->pf_wexp, pl.NT, K, st));
+    HIP_TRY(expand_fp8_image_launch(pl.Wp, s->pf_wexp, NTg, K, st));
     HIP_TRY(llm_gemm_launch(X, s->pf_wexp, m, N, K, out, ldo, kind, st, pl.wscale));
     return VLO_OK;
 }

@@ -123,6 +123,7 @@ struct vlo_tp_session {
     vlo_tp_group *g = nullptr;
     std::vector<vlo_session *> ss;     // one KV shard per local rank
     unsigned short *gather_tmp = nullptr;   // [T][16][V_l] receive buffer of the logits all-gather
+    unsigned short *gather_big = nullptr;   // RCCL, every row's logits of a long input: [T][VLO_TP_LOGIT_ROWS][padded V_l] (allocated on first use)
 };
 
 struct PtrList { float *p[8]; int n; };
@@ -281,6 +282,7 @@ void vlo_tp_session_destroy(vlo_tp_session *t) {
     if (!t) return;
     for (vlo_session *s : t->ss) vlo_session_destroy(s);
     if (t->gather_tmp) hipFree(t->gather_tmp);
+    if (t->gather_big) hipFree(t->gather_big);
     delete t;
 }
 int vlo_tp_session_reset(vlo_tp_session *t) {
@@ -683,6 +685,7 @@ static int tp_chunk(vlo_tp_session *t, const unsigned short *src, int m, bool wa
 // all-reduced in fp32 and then folded into the residual stream by the row kernel (h += bf16(sum); x = RMSNorm(h) w) — the rounding points of the
 // 16-row TP step and of the one-GPU prefill.  The exchange here is bandwidth-sized (m x H x 4 bytes: 64 MiB at 4 096 tokens of the 8B model), so
 // it goes through RCCL (one process per GPU) or the sum kernel (all ranks in this process); the latency-sized p2p mailboxes are not used for it.
+#define VLO_TP_LOGIT_ROWS 1024      // rows of a long input whose logits one lm_head GEMM + one gather handle (33 MB per rank at the 8B shape, T = 8)
 static bool tp_prefill_ok(const vlo_tp_session *t) {
     const vlo_tp_group *g = t->g;
     if (!(g->comm || (int)g->eng.size() == g->tp_size)) return false;       // mailbox-only groups keep the 16-row step
@@ -757,24 +760,56 @@ static int tp_prefill(vlo_tp_session *t, const unsigned short *src, int m, bool 
             if ((rc = tp_prefill_exchange(t, m, norm_final, 0, st))) return rc;
         }
     }
-    if (want_last || all_logits) {
-        // logits: the vocabulary shards of 16 rows at a time through the GEMV + the logits all-gather of the 16-row step (V / T is not a whole number
-        // of 256-column GEMM tiles for Llama-3's vocabulary at T = 8); every row, or the last one only
-        for (int r0 = all_logits ? 0 : m - 1; r0 < m; r0 += 16) {
-            const int nr = std::min(16, m - r0);
+    if (all_logits) {
+        // every row's logits: each rank's vocabulary shard as ONE GEMM per chunk of VLO_TP_LOGIT_ROWS rows over its lm_head image — padded at load to whole
+        // 256-column tiles (engine.hip::make_linear: Llama-3 at T = 8 holds 16 032 columns in 16 128) — into a padded [rows][V_l'] matrix, whose real
+        // columns are then laid side by side into the caller's [m][V] matrix: straight copies between the local ranks, or one ncclAllGather per chunk.
+        // (Rounds 4 - 5 sent these rows 16 at a time through the GEMV: 256 passes over the vocabulary shard for a 4096-token block.)
+        const int Vl = g->eng[0]->V_l, Vp = g->eng[0]->lm_head.NT_gemm * 16;
+        for (int r0 = 0; r0 < m; r0 += VLO_TP_LOGIT_ROWS) {
+            const int nr = std::min(VLO_TP_LOGIT_ROWS, m - r0);
             for (int r = 0; r < R; ++r) {
                 vlo_session *s = t->ss[r];
-                vlo_engine *e = s->e;
-                GemvArgs a = gemv_args(e->lm_head, s->px + (size_t)r0 * H, H, nr);
-                a.out_bf16 = s->logits_local; a.ldo = e->V_l;
-                TP_TRY(gemv_launch(a, e->lm_head.plan, XSRC_PLAIN, EPI_BF16, st));
+                if (!s->plogits) {
+                    void *p = nullptr;
+                    if ((rc = dev_alloc(&p, (size_t)VLO_TP_LOGIT_ROWS * Vp * 2))) return rc;
+                    s->owned.push_back(p);
+                    s->plogits = (unsigned short *)p;
+                }
+                if ((rc = prefill_gemm(s, s->px + (size_t)r0 * H, s->e->lm_head, nr, Vp, H, s->plogits, Vp, LLM_GEMM_BF16, st, false))) return rc;
             }
-            if ((rc = tp_gather_logits(t, nr, st))) return rc;
-            if (all_logits) TP_TRY(hipMemcpyAsync(all_logits + (size_t)r0 * V, t->ss[0]->logits, (size_t)nr * V * 2, hipMemcpyDeviceToDevice, st));
-            for (int r = 0; r < R; ++r) {
-                t->ss[r]->last_logits = t->ss[r]->logits + (size_t)(nr - 1) * V;
-                t->ss[r]->has_logits = true;
+            if (g->comm) {
+                if (!t->gather_big && (rc = dev_alloc((void **)&t->gather_big, (size_t)g->tp_size * VLO_TP_LOGIT_ROWS * Vp * 2))) return rc;
+                if (g_rccl.AllGather(t->ss[0]->plogits, t->gather_big, (size_t)nr * Vp * 2, kNcclInt8, g->comm, st) != 0)
+                    return vlo_fail(VLO_E_HIP, "ncclAllGather failed");
+                for (int r = 0; r < g->tp_size; ++r)      // [T][nr][Vp] -> columns [r Vl, (r + 1) Vl) of rows r0 .. r0 + nr
+                    TP_TRY(hipMemcpy2DAsync(all_logits + (size_t)r0 * V + (size_t)r * Vl, (size_t)V * 2, t->gather_big + (size_t)r * nr * Vp, (size_t)Vp * 2,
+                                            (size_t)Vl * 2, nr, hipMemcpyDeviceToDevice, st));
+            } else {
+                for (int r = 0; r < R; ++r)
+                    TP_TRY(hipMemcpy2DAsync(all_logits + (size_t)r0 * V + (size_t)t->ss[r]->e->tp_rank * Vl, (size_t)V * 2, t->ss[r]->plogits, (size_t)Vp * 2,
+                                            (size_t)Vl * 2, nr, hipMemcpyDeviceToDevice, st));
             }
+        }
+        for (int r = 0; r < R; ++r) {               // the last row is what the samplers read on every local rank
+            vlo_session *s = t->ss[r];
+            TP_TRY(hipMemcpyAsync(s->logits, all_logits + (size_t)(m - 1) * V, (size_t)V * 2, hipMemcpyDeviceToDevice, st));
+            s->last_logits = s->logits;
+            s->has_logits = true;
+        }
+    } else if (want_last) {
+        // the last row only: the vocabulary shards through the GEMV + the logits all-gather of the 16-row step
+        for (int r = 0; r < R; ++r) {
+            vlo_session *s = t->ss[r];
+            vlo_engine *e = s->e;
+            GemvArgs a = gemv_args(e->lm_head, s->px + (size_t)(m - 1) * H, H, 1);
+            a.out_bf16 = s->logits_local; a.ldo = e->V_l;
+            TP_TRY(gemv_launch(a, e->lm_head.plan, XSRC_PLAIN, EPI_BF16, st));
+        }
+        if ((rc = tp_gather_logits(t, 1, st))) return rc;
+        for (int r = 0; r < R; ++r) {
+            t->ss[r]->last_logits = t->ss[r]->logits;
+            t->ss[r]->has_logits = true;
         }
     }
     for (int r = 0; r < R; ++r) t->ss[r]->len += m;
