@@ -90,6 +90,36 @@ def test_p2p_logical_ranks_match_oracle_and_sum_kernel(name, seed, T):
         g.close()
 
 
+def test_p2p_epilogue_publishing_is_bit_identical_to_the_exchange_kernels_publish_pass(monkeypatch):
+    """Round 6: where the o / down GEMV has one K slice per block (the 8B shard shapes at T = 8: K = 512 / 1792) its epilogue writes the fp32 sums as
+    granules straight into every rank's mailbox (csrc/gemv.h EPI_PARTIAL_MBOX) and the exchange kernel only collects; VLO_TP_P2P_DIRECT=0 (read when
+    the p2p exchange is enabled) keeps the partial matrix + publish pass of rounds 3-5.  Same sums, same order: every logit bit for bit."""
+    from videollm_online_amd.engine import TpGroup
+    spec = O.LLM_SPECS["llama-3-8b-2l"]
+    w = O.init_llm_weights(spec, seed=6)
+    toks = O.default_tokens(spec, seed=7, n_start=35)
+    ref = O.LlamaOracle(spec, w, torch.bfloat16)
+    outs = {}
+    for direct in ("1", "0"):
+        monkeypatch.setenv("VLO_TP_P2P_DIRECT", direct)
+        g = TpGroup(_cfg(spec), 8, allreduce="p2p")
+        g.load_weights(w)
+        g.load_weight("rope.inv_freq", O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+        g.finalize()
+        sess = g.new_session()
+        rows = []
+        for x in _steps(spec, ref, toks, 6):
+            _, allr = g.llm_step(sess, x.cuda(), want_last=True, want_all=True)
+            torch.cuda.synchronize()
+            rows.append(allr.clone())
+        assert g.p2p_status()["timed_out"] == 0
+        outs[direct] = rows
+        sess.close()
+        g.close()
+    for a, b in zip(outs["1"], outs["0"]):
+        assert torch.equal(a, b)
+
+
 def test_p2p_lonely_rank_times_out_instead_of_hanging(monkeypatch):
     """A one-process-per-GPU rank whose peers never publish: every spin is bounded, the stream drains, the NEXT step
     reports the failure.  (The peer 'handles' here are this process's own mailbox, which hipIpc refuses to re-open in the

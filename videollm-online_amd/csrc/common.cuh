@@ -53,13 +53,6 @@ VLO_DEV f32x4 mfma_fp8_k128(frag_ab a0, frag_ab a1, frag_ab b0, frag_ab b1, f32x
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, c, 0, 0, 0, 0, 0, 0);
 }
 
-// the same, accumulating IN PLACE (vdst = srcC) through inline asm — see vit_gemm.inc (F8) for why and for the hazards the caller covers
-VLO_DEV void mfma_fp8_k128_acc(frag_ab a0, frag_ab a1, frag_ab b0, frag_ab b1, f32x4 &c) {
-    const i32x8_t A = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, a0), __builtin_bit_cast(i32x4_t, a1), 0, 1, 2, 3, 4, 5, 6, 7);
-    const i32x8_t B = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, b0), __builtin_bit_cast(i32x4_t, b1), 0, 1, 2, 3, 4, 5, 6, 7);
-    asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+v"(c) : "v"(A), "v"(B));
-}
-
 VLO_DEV float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

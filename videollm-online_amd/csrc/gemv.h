@@ -12,7 +12,9 @@ enum {
     EPI_BF16_GELU_ERF = 2,   // HF python-GELU on bf16(acc + bias)                   (connector.0)
     EPI_SWIGLU = 3,          // tile = 8 gate rows + 8 up rows of the same columns -> bf16(silu(g) * u)   (gate_up)
     EPI_RESID = 4,           // h[m][col] = bf16(h + bf16(acc)); per-row sum of squares partials (o_proj, down_proj)
-    EPI_ROPE = 5             // q/k/v split, RoPE, q buffer + paged K / V^T append   (qkv)
+    EPI_ROPE = 5,            // q/k/v split, RoPE, q buffer + paged K / V^T append   (qkv)
+    EPI_PARTIAL_MBOX = 6     // tensor parallel, ksplit == 1: a rank's o / down partial sums published as {epoch, fp32} granules straight into EVERY
+                             // rank's p2p mailbox (tp.hip "p2p exchange"): no partial matrix in HBM, no publish pass in the exchange kernel
 };
 // activation operand source
 enum {
@@ -47,6 +49,11 @@ struct GemvArgs {
     KvGeom kv;
     int layer, num_heads;
     long long pos0;
+    // EPI_PARTIAL_MBOX
+    unsigned long long *mbox[8];  // every rank's mailbox, by global rank (tp_p2p.cuh::P2PPeers)
+    unsigned long long mbox_off;  // granule offset of [slot][this rank][row 0][column 0] in the reduce region; rows are ldo granules apart
+    unsigned mbox_epoch;
+    int mbox_T;
 };
 
 struct GemvPlan { int NW, KF, KC, ksplit; };

@@ -233,6 +233,7 @@ static hipError_t launch_variant(const GemvArgs &a, int xsrc, int epi, dim3 grid
         if (epi == EPI_BF16) VLO_GO(XSRC_PLAIN, EPI_BF16);
         if (epi == EPI_BF16_GELU_ERF) VLO_GO(XSRC_PLAIN, EPI_BF16_GELU_ERF);
         if (epi == EPI_PARTIAL_F32) VLO_GO(XSRC_PLAIN, EPI_PARTIAL_F32);
+        if (epi == EPI_PARTIAL_MBOX) VLO_GO(XSRC_PLAIN, EPI_PARTIAL_MBOX);
     }
 #undef VLO_GO
     return hipErrorInvalidValue;
@@ -240,6 +241,7 @@ static hipError_t launch_variant(const GemvArgs &a, int xsrc, int epi, dim3 grid
 
 hipError_t gemv_prepare(GemvArgs *a, const GemvPlan &p, int epi, int *grid_x, int *grid_y, size_t *lds_bytes) {
     if (epi != EPI_PARTIAL_F32 && p.ksplit != 1) return hipErrorInvalidValue;
+    if (epi == EPI_PARTIAL_MBOX && (a->mbox_T < 1 || a->mbox_T > 8 || !a->mbox[0])) return hipErrorInvalidValue;
     if (epi == EPI_ROPE && ((a->NT & 1) || (a->kv.head_dim != 64 && a->kv.head_dim != 128))) return hipErrorInvalidValue;
     a->CT = single_tile_groups(*a, p, epi) ? 1 : 2;
     a->KC = p.KC;

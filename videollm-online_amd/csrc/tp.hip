@@ -111,6 +111,7 @@ struct P2PState {
     unsigned *err_host = nullptr;          // pinned, device-visible: the host reads it without synchronising
     long long timeout_ticks = 200000000;   // s_memrealtime ticks (100 MHz): 2 s
     bool fused = true;                     // one kernel publishes AND collects (one process per GPU only)
+    bool direct = true;                    // o / down GEMVs with ksplit == 1 publish their sums from the epilogue (EPI_PARTIAL_MBOX); VLO_TP_P2P_DIRECT=0: tests' A/B
 };
 
 struct vlo_tp_group {
@@ -332,6 +333,9 @@ int vlo_tp_session_crop(vlo_tp_session *t, int64_t n_tokens) {
 // An exchange = every rank PUBLISHES its [m][H] row sums into slot (epoch & 1) of all T mailboxes (its own included),
 // then COLLECTS the T source rows of its own mailbox in rank order 0..T-1 — the same fp32 sum on every rank — and goes
 // straight on with `h += bf16(sum); x = RMSNorm(h) * w` (what add_rmsnorm_kernel does after an RCCL all-reduce).
+// Round 6: when the o / down GEMV's plan has ONE K slice per block (every TP = 8 shard shape) the PUBLISH step is the GEMV's own epilogue
+// (gemv.h EPI_PARTIAL_MBOX: the reduced fp32 sums leave the block as granules, tag and slot fixed on the host before the launch: p2p_begin_reduce) and
+// the exchange kernel runs collect-only — no partial matrix in HBM, no publish pass.  VLO_TP_P2P_DIRECT=0 keeps the round-3 form (tests' A/B).
 // Two slots per region suffice: a rank can only publish the region's exchange k+2 (the slot of k) after collecting k+1,
 // which needs every peer's k+1 granules, which a peer stores (stream order) after it finished collecting k.  Tags are
 // compared for equality with the epoch, a host-side counter that all ranks advance in lock-step, so stale slots never match.  Every spin is bounded
@@ -488,6 +492,7 @@ int vlo_tp_p2p_enable(vlo_tp_group *g, const void *handles) {
         }
     }
     P.enabled = true;
+    P.direct = !(getenv("VLO_TP_P2P_DIRECT") && atoi(getenv("VLO_TP_P2P_DIRECT")) == 0);
     return VLO_OK;
 }
 
@@ -527,8 +532,27 @@ static int tp_allreduce(vlo_tp_session *t, float *(vlo_session::*buf), size_t co
 
 // all-reduce of every local rank's partial sums `buf` [ks][16][H] + `h += bf16(sum); x = RMSNorm(h) * w` on every local rank.
 // RCCL / sum-kernel: the slabs are all-reduced in place, add_rmsnorm_kernel combines them.  p2p: see "p2p exchange".
+// One exchange of the reduce region = a tag and a slot, fixed on the host BEFORE the kernels that publish into it are launched
+struct XchgId { unsigned epoch; size_t slot_off; };
+static XchgId p2p_begin_reduce(vlo_tp_group *g) {
+    P2PState &P = g->p2p;
+    P.epoch = p2p_next_epoch(P.epoch);              // the tag is never 0 (zeroed mailboxes must not match)
+    return XchgId{P.epoch, p2p_reduce_slot_off(g->tp_size, g->eng[0]->cfg.hidden_size, P.n_reduce++)};
+}
+// may the o / down GEMV of this step publish straight from its epilogue?  (one K slice per block: the sums a block holds are final)
+static bool p2p_direct(const vlo_tp_group *g, const GemvPlan &plan) { return g->p2p.enabled && g->p2p.direct && plan.ksplit == 1; }
+static void p2p_publish_args(const vlo_tp_group *g, int local_idx, const XchgId &x, GemvArgs *a) {
+    const int T = g->tp_size, H = g->eng[0]->cfg.hidden_size;
+    for (int p = 0; p < 8; ++p) a->mbox[p] = p < T ? g->p2p.peer[local_idx][p] : nullptr;
+    a->mbox_off = x.slot_off + (size_t)g->eng[local_idx]->tp_rank * 16 * H;
+    a->mbox_epoch = x.epoch;
+    a->mbox_T = T;
+    a->ldo = H;
+}
+
+// `published`: the partial sums are already in the mailboxes (the GEMVs' epilogues wrote them under *published): collect only
 static int tp_reduce_norm(vlo_tp_session *t, float *(vlo_session::*buf), int ks, int m, const void *(*norm_w)(const vlo_engine *, int), int layer,
-                          hipStream_t st) {
+                          hipStream_t st, const XchgId *published = nullptr) {
     vlo_tp_group *g = t->g;
     const int R = (int)t->ss.size();
     const vlo_config &c = g->eng[0]->cfg;
@@ -543,18 +567,18 @@ static int tp_reduce_norm(vlo_tp_session *t, float *(vlo_session::*buf), int ks,
         }
         return VLO_OK;
     }
-    P.epoch = p2p_next_epoch(P.epoch);              // the tag is never 0 (zeroed mailboxes must not match)
+    const XchgId x = published ? *published : p2p_begin_reduce(g);
     XchgArgs a{};
     a.ks = ks; a.ld = H; a.T = g->tp_size;
-    a.slot_off = p2p_reduce_slot_off(g->tp_size, H, P.n_reduce++);
-    a.epoch = P.epoch; a.H = H; a.ldx = H; a.eps = c.rms_eps;
+    a.slot_off = x.slot_off;
+    a.epoch = x.epoch; a.H = H; a.ldx = H; a.eps = c.rms_eps;
     a.err_host = P.err_host; a.timeout_ticks = P.timeout_ticks;
-    const int passes = P.fused ? 1 : 2;
+    const int passes = (P.fused || published) ? 1 : 2;
     for (int pass = 0; pass < passes; ++pass)
         for (int r = 0; r < R; ++r) {
             vlo_session *s = t->ss[r];
             a.partial = s->*buf; a.peers = p2p_peers(P, r, g->tp_size); a.me = s->e->tp_rank;
-            a.mode = P.fused ? 3 : (pass == 0 ? 1 : 2);
+            a.mode = published ? 2 : (P.fused ? 3 : (pass == 0 ? 1 : 2));
             a.h = s->h; a.w = (const unsigned short *)norm_w(s->e, layer); a.x = s->x; a.err_dev = P.err_dev[r];
             hipLaunchKernelGGL(tp_xchg_norm_kernel, dim3(m), dim3(XCHG_THREADS), 0, st, a);
             TP_TRY(hipGetLastError());
@@ -622,6 +646,8 @@ static int tp_chunk(vlo_tp_session *t, const unsigned short *src, int m, bool wa
         TP_TRY(copy_rows_launch(src, s->h, m, H, st));
     }
     int ks_d = 1;
+    bool pub_o = false, pub_d = false;          // this exchange's sums were published by the GEMV epilogues (p2p_direct)
+    XchgId xo{}, xd{};
     for (int l = 0; l < c.num_layers; ++l) {
         int ks_o = 1;
         for (int r = 0; r < R; ++r) {           // attention half: everything up to the o_proj partial sums
@@ -637,12 +663,18 @@ static int tp_chunk(vlo_tp_session *t, const unsigned short *src, int m, bool wa
             TP_TRY(gemv_launch(a, L.qkv.plan, XSRC_PLAIN, EPI_ROPE, st));
             TP_TRY(attention_launch(s->q, kv, l, e->nh_l, s->len, m, s->part_o, s->part_ml, s->attn, st));
             GemvArgs o = gemv_args(L.o, s->attn, e->nh_l * hd, m);
-            o.out_f32 = s->partial_o; o.ldo = H;
-            TP_TRY(gemv_launch(o, L.o.plan, XSRC_PLAIN, EPI_PARTIAL_F32, st));
+            if (r == 0 && (pub_o = p2p_direct(g, L.o.plan))) xo = p2p_begin_reduce(g);
+            if (pub_o) {                        // the sums leave the epilogue as granules in every rank's mailbox
+                p2p_publish_args(g, r, xo, &o);
+                TP_TRY(gemv_launch(o, L.o.plan, XSRC_PLAIN, EPI_PARTIAL_MBOX, st));
+            } else {
+                o.out_f32 = s->partial_o; o.ldo = H;
+                TP_TRY(gemv_launch(o, L.o.plan, XSRC_PLAIN, EPI_PARTIAL_F32, st));
+            }
             ks_o = L.o.plan.ksplit;
         }
         // exchange 1: h += all-reduce(o_proj partials); x = post-attention RMSNorm(h)
-        if ((rc = tp_reduce_norm(t, &vlo_session::partial_o, ks_o, m, norm_post, l, st))) return rc;
+        if ((rc = tp_reduce_norm(t, &vlo_session::partial_o, ks_o, m, norm_post, l, st, pub_o ? &xo : nullptr))) return rc;
         for (int r = 0; r < R; ++r) {           // MLP half
             vlo_session *s = t->ss[r];
             vlo_engine *e = s->e;
@@ -651,17 +683,25 @@ static int tp_chunk(vlo_tp_session *t, const unsigned short *src, int m, bool wa
             a.out_bf16 = s->act; a.ldo = e->I_l;
             TP_TRY(gemv_launch(a, L.gate_up.plan, XSRC_PLAIN, EPI_SWIGLU, st));
             GemvArgs d = gemv_args(L.down, s->act, e->I_l, m);
-            d.out_f32 = s->partial; d.ldo = H;
-            TP_TRY(gemv_launch(d, L.down.plan, XSRC_PLAIN, EPI_PARTIAL_F32, st));
+            // (the last layer's sums are only exchanged when logits are wanted: nothing is published that nobody collects)
+            const bool exchanged = l + 1 < c.num_layers || want_last || want_all;
+            if (r == 0 && (pub_d = exchanged && p2p_direct(g, L.down.plan))) xd = p2p_begin_reduce(g);
+            if (pub_d) {
+                p2p_publish_args(g, r, xd, &d);
+                TP_TRY(gemv_launch(d, L.down.plan, XSRC_PLAIN, EPI_PARTIAL_MBOX, st));
+            } else {
+                d.out_f32 = s->partial; d.ldo = H;
+                TP_TRY(gemv_launch(d, L.down.plan, XSRC_PLAIN, EPI_PARTIAL_F32, st));
+            }
             ks_d = L.down.plan.ksplit;
         }
         // exchange 2: h += all-reduce(down_proj partials); x = the next layer's input RMSNorm(h).  After the last layer it
         // is the final norm, and only when logits are wanted (h is not read again otherwise).
-        if (l + 1 < c.num_layers && (rc = tp_reduce_norm(t, &vlo_session::partial, ks_d, m, norm_in, l + 1, st))) return rc;
+        if (l + 1 < c.num_layers && (rc = tp_reduce_norm(t, &vlo_session::partial, ks_d, m, norm_in, l + 1, st, pub_d ? &xd : nullptr))) return rc;
     }
     if (want_last || want_all) {
         const int r0 = want_all ? 0 : m - 1, nr = want_all ? m : 1;
-        if ((rc = tp_reduce_norm(t, &vlo_session::partial, ks_d, m, norm_final, 0, st))) return rc;
+        if ((rc = tp_reduce_norm(t, &vlo_session::partial, ks_d, m, norm_final, 0, st, pub_d ? &xd : nullptr))) return rc;
         for (int r = 0; r < R; ++r) {
             vlo_session *s = t->ss[r];
             vlo_engine *e = s->e;
