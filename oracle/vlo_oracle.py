@@ -409,13 +409,20 @@ def fp8_dequantized_weights(weights: dict) -> dict:
     return out
 
 
-def _llm_linear(x, W, act_fp8=False):
+def _llm_linear(x, W, act_fp8=False, k_groups=1):
     """F.linear; a weight kept in fp32 next to lower-precision activations (fp8_dequantized_weights) is applied in fp32 and
     the output rounded to the activation dtype.  ``act_fp8``: the rows of x go through fp8_quantize_rows first (W8A8 prefill):
-    y = (q @ W^T) * scale[m], accumulated in fp32, rounded to the activation dtype."""
+    y = (q @ W^T) * scale[m], accumulated in fp32, rounded to the activation dtype.  ``k_groups`` > 1: a ROW-sharded projection of a
+    tensor-parallel group (o_proj, down_proj: rank r holds columns [r K/T, (r+1) K/T) of x) — every rank quantises ITS slice of the row
+    with its own scale, the fp32 partial products are summed across the ranks."""
     if act_fp8:
-        q, s = fp8_quantize_rows(x)
-        return (F.linear(q, W.float()) * s).to(x.dtype)
+        Kg = x.shape[-1] // k_groups
+        y = None
+        for gi in range(k_groups):
+            q, s = fp8_quantize_rows(x[..., gi * Kg:(gi + 1) * Kg])
+            part = F.linear(q, W[:, gi * Kg:(gi + 1) * Kg].float()) * s
+            y = part if y is None else y + part
+        return y.to(x.dtype)
     if W.dtype == x.dtype:
         return F.linear(x, W)
     return F.linear(x.float(), W.float()).to(x.dtype)
@@ -439,10 +446,12 @@ class LlamaOracle:
         return F.embedding(ids, self.W["model.embed_tokens.weight"])
 
     @torch.no_grad()
-    def forward(self, inputs_embeds: torch.Tensor, cache: KVCacheOracle | None, taps: dict | None = None, logits_from: int = 0, act_fp8: bool = False):
+    def forward(self, inputs_embeds: torch.Tensor, cache: KVCacheOracle | None, taps: dict | None = None, logits_from: int = 0, act_fp8: bool = False,
+                act_fp8_tp: int = 1):
         """inputs_embeds [n,H] -> (logits [n,V], cache).  LlamaModel.forward :367-417.
         ``act_fp8``: every decoder-layer projection of THIS call (q/k/v/o, gate/up/down; not the lm_head) quantises its input rows to e4m3
-        (fp8_quantize_rows) — what an fp8 engine with prefill_act_dtype = 1 does on a long input; not a reference feature.
+        (fp8_quantize_rows) — what an fp8 engine with prefill_act_dtype = 1 does on a long input; not a reference feature.  ``act_fp8_tp`` = T: the
+        same under T-way tensor parallelism (the row-sharded o_proj / down_proj quantise per rank: _llm_linear's k_groups).
         ``logits_from`` (test bookkeeping for long cache fills): lm_head only on rows [logits_from, n) — the rows are
         independent, so the rows that are produced equal HF's; n means "no logits" (returns an empty [0,V])."""
         s, W = self.spec, self.W
@@ -477,10 +486,10 @@ class LlamaOracle:
             a = a.transpose(0, 1).reshape(n, nh * hd)
             if taps is not None and i in taps.get("_layers", ()):
                 taps[f"attn{i}"] = a.clone()
-            h = h + _llm_linear(a, W[p + "self_attn.o_proj.weight"], act_fp8)        # :317
+            h = h + _llm_linear(a, W[p + "self_attn.o_proj.weight"], act_fp8, act_fp8_tp)        # :317
             x = rmsnorm(h, W[p + "post_attention_layernorm.weight"], s.rms_eps)
             x = _llm_linear(F.silu(_llm_linear(x, W[p + "mlp.gate_proj.weight"], act_fp8)) * _llm_linear(x, W[p + "mlp.up_proj.weight"], act_fp8),
-                         W[p + "mlp.down_proj.weight"], act_fp8)         # :174-176
+                         W[p + "mlp.down_proj.weight"], act_fp8, act_fp8_tp)         # :174-176
             h = h + x                                                    # :323
             if taps is not None and i in taps.get("_layers", ()):
                 taps[f"h{i}"] = h.clone()

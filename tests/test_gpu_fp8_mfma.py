@@ -119,6 +119,35 @@ def test_fp8_act_prefill_teacher_forced_rows(n_long):
     eng.close()
 
 
+@pytest.mark.parametrize("T", [2, 8])
+def test_fp8_act_prefill_under_tensor_parallelism(T):
+    """The W8A8 prefill over T logical ranks (csrc/tp.hip::tp_prefill through prefill_gemm): column-sharded q|k|v and gate|up quantise the full X row on
+    every rank, the row-sharded o / down quantise each rank's K slice with its own scale (shard K = 512 / 1792 at T = 8: two and seven K tiles), fp32
+    partial matrices summed across the ranks — 3-way against the oracle restating exactly that (act_fp8_tp = T); then a 16-row TP step."""
+    from videollm_online_amd.engine import TpGroup
+    spec = O.LLM_SPECS["llama-3-8b-2l"]
+    w = O.init_llm_weights(spec, seed=9)
+    eng_w, ora_w, keep = _quantized(w)
+    ref, gold = O.LlamaOracle(spec, ora_w, torch.bfloat16, keep_fp32=keep), O.LlamaOracle(spec, ora_w, torch.float32)
+    grp = TpGroup(_cfg(spec, prefill_act_dtype="fp8"), T)
+    grp.load_weights(eng_w)
+    grp.load_weight("rope.inv_freq", O.rope_inv_freq(spec.head_dim, spec.rope_theta))
+    grp.finalize()
+    sess = grp.new_session()
+    g = torch.Generator().manual_seed(37)
+    rc = gc = None
+    for i, (x, long_input) in enumerate([((torch.randn(600, spec.hidden_size, generator=g) * 0.7).bfloat16(), True),
+                                         (torch.randn(11, spec.hidden_size, generator=g).bfloat16(), False)]):
+        rl, rc = ref.forward(x, rc, act_fp8=long_input, act_fp8_tp=T)
+        gl, gc = gold.forward(x, gc, act_fp8=long_input, act_fp8_tp=T)
+        last, allr = grp.llm_step(sess, x.cuda(), want_last=True, want_all=True)
+        torch.cuda.synchronize()
+        assert sess.get_seq_length() == len(rc) and torch.equal(last, allr[-1])
+        _check(f"fp8 mfma 8b-2l tp{T}", i, allr.cpu(), rl, gl)
+    sess.close()
+    grp.close()
+
+
 def test_fp8_act_differs_from_the_bf16_activation_path_by_what_the_rule_predicts():
     """The two prefill arithmetics of an fp8 engine on the same input: W8A8 logits sit a few e4m3 steps (not bf16 ulps) from the bf16-activation
     ones — the figure DESIGN.md quotes for what prefill_act_dtype='fp8' costs — and the oracle predicts the same distance."""
