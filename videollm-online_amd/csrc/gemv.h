@@ -44,17 +44,24 @@ struct GemvArgs {
     // EPI_RESID
     unsigned short *h;            // residual stream, bf16 [16][ldo], updated in place
     float *sq_out;                // [gridDim.x][16] partials of the updated rows
-    // EPI_ROPE
-    const unsigned short *cos_tab, *sin_tab;   // bf16 [pos][hd/2]
-    KvGeom kv;
-    int layer, num_heads;
-    long long pos0;
-    // EPI_PARTIAL_MBOX
-    unsigned long long *mbox[8];  // every rank's mailbox, by global rank (tp_p2p.cuh::P2PPeers)
-    unsigned long long mbox_off;  // granule offset of [slot][this rank][row 0][column 0] in the reduce region; rows are ldo granules apart
-    unsigned mbox_epoch;
-    int mbox_T;
+    // The two epilogues below never meet in one launch and share their bytes: the kernel-argument block keeps the size it had before
+    // EPI_PARTIAL_MBOX existed (88 more bytes of it cost the gate/up GEMV 0.5 us on the same box: 42.5 vs 42.0 us, tools/bench_gemv.py).
+    union {
+        struct {                      // EPI_ROPE
+            const unsigned short *cos_tab, *sin_tab;   // bf16 [pos][hd/2]
+            KvGeom kv;
+            int layer, num_heads;
+            long long pos0;
+        };
+        struct {                      // EPI_PARTIAL_MBOX
+            unsigned long long *mbox[8];  // every rank's mailbox, by global rank (tp_p2p.cuh::P2PPeers)
+            unsigned long long mbox_off;  // granule offset of [slot][this rank][row 0][column 0] in the reduce region; rows are ldo granules apart
+            unsigned mbox_epoch;
+            int mbox_T;
+        };
+    };
 };
+static_assert(sizeof(GemvArgs) <= 232, "GemvArgs grew: see the union above");
 
 struct GemvPlan { int NW, KF, KC, ksplit; };
 
