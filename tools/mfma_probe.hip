@@ -29,7 +29,24 @@ __global__ __launch_bounds__(NT) void mfma_kernel(float *out, int iters, float s
         bb[i] = (__bf16)(float)b[i];
     }
     float r = 0.f;
-    if (SHAPE == 4 || SHAPE == 5) {
+    if (SHAPE == 6) {            // v_mfma_f32_32x32x64_f8f6f4 on e4m3 operands (128 K FLOP)
+        i8v qa, qb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { qa[i] = 0x38383838 + (int)threadIdx.x * 0x01010101 * (i & 1); qb[i] = 0x3c343c34 ^ ((int)threadIdx.x << (i & 3)); }
+        f16v acc[NACC];
+#pragma unroll
+        for (int j = 0; j < NACC; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int j = 0; j < NACC; ++j) acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qa, qb, acc[j], 0, 0, 0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NACC; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) r += acc[j][e];
+    } else if (SHAPE == 4 || SHAPE == 5) {
         i8v qa, qb;
 #pragma unroll
         for (int i = 0; i < 8; ++i) { qa[i] = 0x38383838 + (int)threadIdx.x * 0x01010101 * (i & 1); qb[i] = 0x3c343c34 ^ ((int)threadIdx.x << (i & 3)); }
@@ -96,7 +113,7 @@ static void run(const char *name, float *out, hipStream_t st) {
             float ms;
             CK(hipEventElapsedTime(&ms, e0, e1));
             const double n_mfma = 256.0 * (NT / 64) * (double)iters * NACC;
-            const double flop = n_mfma * (SHAPE == 4 ? 65536.0 : SHAPE == 5 ? 16384.0 : (SHAPE & 1) ? 32768.0 : 16384.0);
+            const double flop = n_mfma * (SHAPE == 6 ? 131072.0 : SHAPE == 4 ? 65536.0 : SHAPE == 5 ? 16384.0 : (SHAPE & 1) ? 32768.0 : 16384.0);
             const double per_simd = n_mfma / (256.0 * 4);
             printf("%-28s %d waves/CU, %d chains/wave: %8.3f ms  %7.0f TFLOP/s  %5.2f cycles per MFMA per SIMD @ 2.4 GHz\n", name, NT / 64, NACC, ms, flop / (ms * 1e-3) / 1e12,
                    ms * 1e-3 * 2.4e9 / per_simd);
@@ -122,5 +139,13 @@ int main() {
     run<4, 4, 256>("v_mfma_f32_16x16x128_f8f6f4 (e4m3)", out, st);
     run<4, 8, 512>("v_mfma_f32_16x16x128_f8f6f4 (e4m3)", out, st);
     run<5, 8, 512>("v_mfma_f32_16x16x32_fp8_fp8", out, st);
+    // ONE wave per SIMD (what a ping-pong schedule's MFMA segment sees: the partner wave is reading), every shape
+    run<2, 4, 256>("v_mfma_f32_16x16x32_bf16", out, st);
+    run<2, 8, 256>("v_mfma_f32_16x16x32_bf16", out, st);
+    run<3, 2, 256>("v_mfma_f32_32x32x16_bf16", out, st);
+    run<3, 4, 256>("v_mfma_f32_32x32x16_bf16", out, st);
+    run<6, 2, 256>("v_mfma_f32_32x32x64_f8f6f4 (e4m3)", out, st);
+    run<6, 4, 256>("v_mfma_f32_32x32x64_f8f6f4 (e4m3)", out, st);
+    run<6, 4, 512>("v_mfma_f32_32x32x64_f8f6f4 (e4m3)", out, st);
     return 0;
 }
