@@ -56,8 +56,6 @@ def build(force=False, sanitize=None):
         # csrc/common.cuh::mfma_fp8_k128_acc — the fp8 MFMA accumulating in place through inline asm, and the software wait states around it
         src = re.sub(r'asm volatile\("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0"\s*:\s*"\+v"\((\w+)\)\s*:\s*"v"\((\w+)\),\s*"v"\((\w+)\)\);',
                      r"\1 = emul_mfma_fp8_16x16x128(\2, \3, \1);", src)
-        src = re.sub(r'asm volatile\("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0"\s*:\s*"\+v"\((\w+)\)\s*:\s*"v"\((\w+)\),\s*"v"\((\w+)\)\);',
-                     r"\1 = emul_mfma_fp8_32x32x64(\2, \3, \1);", src)
         src = re.sub(r'asm volatile\("s_nop[^"]*"(?:\s*:::\s*"memory")?\);', ";", src)
         src = re.sub(r'asm volatile\(""\s*:::\s*"memory"\);', ";", src)                  # compiler-only memory barrier
         src = re.sub(r'asm(?: volatile)?\(""\s*:\s*"\+v"\([\w\[\]]+\)\);', ";", src)      # optimisation barrier on a VGPR value

@@ -180,53 +180,6 @@ static inline V4 emul_mfma_16x16x32(V8 a, V8 b, V4 c) {
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emul_mfma_16x16x32((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) emul_mfma_16x16x32((a), (b), (c))
 
-// v_mfma_f32_32x32x16_{bf16,f16}: D[32x32] = A[32x16] . B[16x32] + C.  A[i][k]: lane l holds i = l % 32, k = (l / 32) * 8 + j; B[k][n]: n = l % 32, same k;
-// D[i][n]: lane l holds n = l % 32 and, in register v, i = 8 (v / 4) + 4 (l / 32) + v % 4
-template <class V8, class V16>
-static inline V16 emul_mfma_32x32x16(V8 a, V8 b, V16 c) {
-    emul_wave_ctx &W = emul_ctx->waves[threadIdx.x >> 6];
-    const int l = threadIdx.x & 63, i = l & 31, kb = (l >> 5) * 8;
-    for (int j = 0; j < 8; ++j) {
-        W.A[i * 16 + kb + j] = (float)a[j];
-        W.B[(kb + j) * 32 + i] = (float)b[j];
-    }
-    pthread_barrier_wait(&W.bar);
-    V16 d = c;
-    for (int v = 0; v < 16; ++v) {
-        const int row = 8 * (v / 4) + 4 * (l >> 5) + (v % 4);
-        float s = c[v];
-        for (int k = 0; k < 16; ++k) s += W.A[row * 16 + k] * W.B[k * 32 + i];
-        d[v] = s;
-    }
-    pthread_barrier_wait(&W.bar);
-    return d;
-}
-#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emul_mfma_32x32x16((a), (b), (c))
-static inline float emul_fp8_e4m3(unsigned b);
-// v_mfma_f32_32x32x64_f8f6f4 on e4m3 bytes: a lane's 32 operand bytes are row / column l % 32 and k slots (l / 32) * 32 + [0, 32): four K-16 passes
-template <class V8I, class V16>
-static inline V16 emul_mfma_fp8_32x32x64(V8I a, V8I b, V16 c) {
-    emul_wave_ctx &W = emul_ctx->waves[threadIdx.x >> 6];
-    const int l = threadIdx.x & 63, i = l & 31, kb = (l >> 5) * 8;
-    V16 d = c;
-    for (int p = 0; p < 4; ++p) {
-        for (int j = 0; j < 8; ++j) {
-            const int byte = p * 8 + j;
-            W.A[i * 16 + kb + j] = emul_fp8_e4m3(((unsigned)a[byte >> 2] >> ((byte & 3) * 8)) & 0xffu);
-            W.B[(kb + j) * 32 + i] = emul_fp8_e4m3(((unsigned)b[byte >> 2] >> ((byte & 3) * 8)) & 0xffu);
-        }
-        pthread_barrier_wait(&W.bar);
-        for (int v = 0; v < 16; ++v) {
-            const int row = 8 * (v / 4) + 4 * (l >> 5) + (v % 4);
-            float s = d[v];
-            for (int k = 0; k < 16; ++k) s += W.A[row * 16 + k] * W.B[k * 32 + i];
-            d[v] = s;
-        }
-        pthread_barrier_wait(&W.bar);
-    }
-    return d;
-}
-
 // v_mfma_f32_16x16x128_f8f6f4 on e4m3 bytes (cbsz = blgp = 0, unscaled): a lane's 32 operand bytes are row / column l & 15 and k slots
 // (l >> 4) * 32 + [0, 32) — four passes of the 16x16x32 scratch.  fp32 accumulation here (the hardware's adder keeps fewer bits: DESIGN.md).
 static inline float emul_fp8_e4m3(unsigned b);

@@ -15,7 +15,6 @@ typedef __attribute__((ext_vector_type(8))) short  frag_ab;    // 8 x 16-bit MFM
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_bf;    // same bits, bf16-typed for the builtin
 typedef __attribute__((ext_vector_type(8))) _Float16 frag_h;   // f16-typed
 typedef __attribute__((ext_vector_type(4))) float  f32x4;
-typedef __attribute__((ext_vector_type(16))) float f32x16;     // accumulator of a 32 x 32 MFMA
 
 #define VLO_DEV __device__ __forceinline__
 

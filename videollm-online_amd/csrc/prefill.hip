@@ -330,13 +330,9 @@ hipError_t llm_gemm_launch(const unsigned short *X, const void *Wp, int M, int N
     while (cb < 8 && tx % (cb * 2) == 0 && (size_t)(N / cb) * K * 2 > ((size_t)9 << 18)) cb *= 2;
     a.cb = cb;
     const int tiles = ((M + bm - 1) / bm) * tx, grid = std::min(tiles, vit_num_cus());
-    static const bool m32 = !(getenv("VLO_LLM_GEMM_M32") && atoi(getenv("VLO_LLM_GEMM_M32")) == 0);     // 0: the 16 x 16 x 32 MFMA loop of rounds 4 - 5 (A/B, tests)
 #define VLO_LLM_GO(EP_)                                                                                         \
     do {                                                                                                        \
-        if (m32) {                                                                                              \
-            if (bm == 256) hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP_, 1, 0, 0, 1>), dim3(grid), dim3(512), 0, st, a); \
-            else hipLaunchKernelGGL((vit_gemm_pp_kernel<128, EP_, 1, 0, 0, 1>), dim3(grid), dim3(512), 0, st, a); \
-        } else if (bm == 256) hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP_>), dim3(grid), dim3(512), 0, st, a); \
+        if (bm == 256) hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP_>), dim3(grid), dim3(512), 0, st, a);     \
         else hipLaunchKernelGGL((vit_gemm_pp_kernel<128, EP_>), dim3(grid), dim3(512), 0, st, a);               \
         return hipGetLastError();                                                                               \
     } while (0)
@@ -407,13 +403,9 @@ hipError_t llm_gemm_fp8_launch(const void *Xq, const float *xscale, const void *
     while (cb < 8 && tx % (cb * 2) == 0 && (size_t)(N / cb) * K > ((size_t)9 << 18)) cb *= 2;
     a.cb = cb;
     const int tiles = ((M + bm - 1) / bm) * tx, grid = std::min(tiles, vit_num_cus());
-    static const bool m32 = !(getenv("VLO_LLM_GEMM_M32") && atoi(getenv("VLO_LLM_GEMM_M32")) == 0);
 #define VLO_LLM8_GO(EP_)                                                                                                  \
     do {                                                                                                                  \
-        if (m32) {                                                                                                        \
-            if (bm == 256) hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP_, 1, 0, 1, 1>), dim3(grid), dim3(512), 0, st, a); \
-            else hipLaunchKernelGGL((vit_gemm_pp_kernel<128, EP_, 1, 0, 1, 1>), dim3(grid), dim3(512), 0, st, a);         \
-        } else if (bm == 256) hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP_, 1, 0, 1>), dim3(grid), dim3(512), 0, st, a); \
+        if (bm == 256) hipLaunchKernelGGL((vit_gemm_pp_kernel<256, EP_, 1, 0, 1>), dim3(grid), dim3(512), 0, st, a);      \
         else hipLaunchKernelGGL((vit_gemm_pp_kernel<128, EP_, 1, 0, 1>), dim3(grid), dim3(512), 0, st, a);                \
         return hipGetLastError();                                                                                         \
     } while (0)
